@@ -1,0 +1,44 @@
+"""Shared test helpers: rebuild the synthetic weights / inputs the golden fixtures were made from."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from candidate_reranking_cir_amd import config as cfgmod, synthetic, weights
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FULL_BERT = dict(hidden_size=768, num_attention_heads=12, num_hidden_layers=12, intermediate_size=3072,
+                 layer_norm_eps=1e-12, vocab_size=30524, max_position_embeddings=512, encoder_width=768)
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def geometry(bert_cfg: dict, vit_cfg: dict):
+    return cfgmod.BertGeometry.from_dict(bert_cfg), cfgmod.VitGeometry(**vit_cfg)
+
+
+def state_dicts(g, v, seed, profile):
+    sd2 = weights.synth_state_dict(weights.nlvr_param_spec(g, v), seed, profile)
+    sd1 = weights.synth_state_dict(weights.retrieval_param_spec(g, v), seed + 1, profile)
+    return sd2, sd1
+
+
+def tiny_setup():
+    z = load("tiny_loop.npz")
+    g, v = geometry(json.loads(str(z["bert_cfg"])), json.loads(str(z["vit_cfg"])))
+    sd2, sd1 = state_dicts(g, v, int(z["seed"]), str(z["profile"]))
+    return z, g, v, sd2, sd1
+
+
+def fiq_caption(pair):
+    """validate_stage2.py:97-100: 'Cap1 and cap2' with '.?, ' stripped and the first capitalised."""
+    a, b = str(pair[0]), str(pair[1])
+    return f"{a.strip('.?, ').capitalize()} and {b.strip('.?, ')}"
+
+
+def tokenize(texts):
+    enc = synthetic.HashTokenizer()(list(texts))
+    return enc.input_ids, enc.attention_mask

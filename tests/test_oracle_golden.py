@@ -1,0 +1,98 @@
+"""The CPU oracle (oracle/cir_oracle.py) against golden vectors produced by the real reference
+(oracle/make_golden.py).  fp32 on both sides: tolerance 2e-5 absolute on O(1) activations."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cir_oracle as O
+from candidate_reranking_cir_amd import synthetic
+from tests import helpers as H
+
+ATOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    z, g, v, sd2, sd1 = H.tiny_setup()
+    with torch.no_grad():
+        feats = O.img_embed(sd2, synthetic.images(range(14), v.image_size))
+    return z, g, v, sd2, sd1, feats
+
+
+def test_vit_tiny(tiny):
+    z, g, v, sd2, sd1, feats = tiny
+    np.testing.assert_allclose(feats[:, :3, :8].numpy(), z["index_features_slice"], atol=ATOL)
+    assert abs(feats.double().sum().item() - float(z["index_features_sum"])) < 1e-2
+
+
+@pytest.mark.parametrize("flavour", ["cirr", "fiq"])
+def test_scoring_loop_tiny(tiny, flavour):
+    z, g, v, sd2, sd1, feats = tiny
+    caps = [str(c) for c in z["cirr_caps"]] if flavour == "cirr" else [H.fiq_caption(p) for p in z["fiq_caps"]]
+    labels = z["labels"]
+    with torch.no_grad():
+        rows, grows = [], []
+        for q, cap in enumerate(caps):
+            ids, mask = H.tokenize([cap])
+            out = O.score_queries(sd2, sd1, feats, [int(z["refs"][q])], z["cand_idx"][q:q + 1], labels[q:q + 1], ids, mask,
+                                  group_index=z["groups"][q:q + 1] if flavour == "cirr" else None)
+            if flavour == "cirr":
+                rows.append(out[0]); grows.append(out[1])
+            else:
+                rows.append(out)
+    logits = torch.cat(rows)
+    np.testing.assert_allclose(logits.numpy(), z[f"{flavour}_logits"], atol=ATOL)
+    assert (logits[0] == O.SKIP_FILL).all()          # skipped row reproduced
+    if flavour == "cirr":
+        glog = torch.cat(grows)
+        np.testing.assert_allclose(glog.numpy(), z["cirr_group_logits"], atol=ATOL)
+        r = O.recall_at(logits, labels, (1, 5, 10, 50))
+        gr = O.group_recall_at(glog, z["groups"], z["targets"])
+        np.testing.assert_allclose(gr + r, z["cirr_metrics"], atol=1e-4)
+    else:
+        np.testing.assert_allclose(O.recall_at(logits, labels, (10, 50)), z["fiq_metrics"], atol=1e-4)
+
+
+def test_padded_masks(tiny):
+    z, g, v, sd2, sd1, feats = tiny
+    m = H.load("masks.npz")
+    ids, mask = torch.tensor(m["input_ids"]), torch.tensor(m["attention_mask"])
+    assert (mask == 0).any()
+    with torch.no_grad():
+        h1 = O.med_forward(sd1, ids, mask, feats[:3])
+        h2 = O.nlvr_forward(sd2, ids, mask, h1, feats[3:6])
+    np.testing.assert_allclose(h1.numpy(), m["stage1_hidden"], atol=ATOL)
+    np.testing.assert_allclose(h2.numpy(), m["stage2_hidden"], atol=ATOL)
+
+
+def test_metrics_large():
+    m = H.load("metrics.npz")
+    logits = torch.tensor(m["logits"])
+    np.testing.assert_allclose(O.recall_at(logits, m["labels"], (10, 50)), m["fiq_metrics"], atol=1e-4)
+    gr = O.group_recall_at(torch.tensor(m["group_logits"]), m["group_members"], m["targets"])
+    r = O.recall_at(logits, m["labels"], (1, 5, 10, 50))
+    np.testing.assert_allclose(gr + r, m["cirr_metrics"], atol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["full224", "full224_spread"])
+def test_full224(tag):
+    z = H.load(tag + ".npz")
+    g, v = H.geometry(H.FULL_BERT, dict(image_size=224))
+    sd2, sd1 = H.state_dicts(g, v, int(z["seed"]), str(z["profile"]))
+    k = int(z["k"])
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        feats = O.img_embed(sd2, synthetic.images(range(k + 1), 224))
+        np.testing.assert_allclose(feats[:, :4, :16].numpy(), z["vit_slice"], atol=1e-4)
+        ids, mask = H.tokenize([synthetic.caption_text(0, 30)])
+        assert ids.shape[1] == 32
+        zt = O.stage1_z_t(sd1, feats[:1], ids, mask)
+        np.testing.assert_allclose(zt[0, 0].numpy(), z["z_t_cls"], atol=1e-4)
+        taps = []
+        logits = O.img_txt_fusion_val(sd2, zt, feats[1:], ids, mask, taps=taps)
+    np.testing.assert_allclose(torch.stack([t[0] for t in taps]).numpy(), z["taps0"], atol=2e-4)
+    np.testing.assert_allclose(torch.stack([t[1] for t in taps]).numpy(), z["taps1"], atol=2e-4)
+    np.testing.assert_allclose(logits.numpy(), z["logits"], atol=1e-4)
+    assert (torch.argsort(logits, descending=True).numpy() == z["order"]).all()
