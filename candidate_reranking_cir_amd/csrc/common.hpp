@@ -1,0 +1,93 @@
+// Shared device/host helpers for libcirrank (gfx950 only: wave64, MFMA, LDS-DMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cirrank.h"
+
+namespace cir {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+constexpr int kWave = 64;
+
+// ---- 16-bit element traits -------------------------------------------------------------------
+template <typename T> struct Elem;
+template <> struct Elem<__bf16> {
+    using x8 = bf16x8;
+    using x4 = bf16x4;
+    static __device__ __forceinline__ f32x4 mfma16(x8 a, x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(x8 a, x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Elem<_Float16> {
+    using x8 = f16x8;
+    using x4 = f16x4;
+    static __device__ __forceinline__ f32x4 mfma16(x8 a, x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma32(x8 a, x8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <typename T> __device__ __forceinline__ T from_f32(float x) { return static_cast<T>(x); }
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return static_cast<float>(x); }
+
+// pack two floats into one dword of two 16-bit elements (low = a, high = b)
+template <typename T> __device__ __forceinline__ unsigned int pack2(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) T t2;
+    t2 v = {static_cast<T>(a), static_cast<T>(b)};
+    return __builtin_bit_cast(unsigned int, v);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// erf with |abs error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26); enough for a 16-bit GELU output.
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = 1.0f - p * __expf(-ax * ax);
+    return copysignf(e, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+
+// bijective XCD remap: consecutive "logical" ids land on one XCD (blocks b and b+8 share an XCD)
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+
+}  // namespace cir
+
+// ---- host side ----------------------------------------------------------------------------------
+#define CIR_CHECK_PTR(p) do { if ((p) == nullptr) return CIR_EINVAL; } while (0)
+#define CIR_LAUNCH_RESULT() do { hipError_t e_ = hipGetLastError(); return e_ == hipSuccess ? CIR_OK : (int)e_; } while (0)
+static inline bool cir_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

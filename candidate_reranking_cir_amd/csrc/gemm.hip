@@ -1,0 +1,227 @@
+// cir_gemm_bias_act: C = act(A * W^T + bias) (+ residual) on MFMA, 16-bit inputs / fp32 accumulate.
+//
+// Bound: MFMA (dense bf16/f16, ~2.5 PFLOP/s peak on MI355X).  Algorithmic work 2*M*N*K flop.
+//
+// Structure (v1: 128x128x64 tile, 4 waves, LDS-DMA staging, two LDS buffers):
+//   * A (activations, M x K) and W (weights, N x K, torch Linear layout) are both K-contiguous, so
+//     a 16-byte chunk of a row is directly one MFMA fragment (8 consecutive k for one row).
+//   * Tiles are staged with global_load_lds (16 B/lane, 1 KiB per wave-instruction = 8 rows x 128 B).
+//     The LDS image is lane-linear, so the bank swizzle lives on the per-lane SOURCE address:
+//     LDS row r, 16-B slot s holds global chunk s ^ (r & 7); fragments are read back with the same
+//     XOR (ds_read_b128, conflict-free for the 16x16x32 operand pattern).
+//   * MFMA orientation is "swapped": weights are the first operand, activations the second, so
+//     the accumulator holds 4 consecutive output FEATURES per register quad for one row.  The W
+//     tile's rows are permuted on their way into LDS so that a lane ends up with 16 consecutive
+//     features of one output row -> 16/32/64-byte vector stores, fp32 bias/residual as float4.
+//   * Workgroup -> tile mapping is XCD-aware (blocks that share an XCD's L2 walk neighbouring
+//     tiles of one row panel, so the A panel is fetched from HBM once per XCD).
+#include "common.hpp"
+
+namespace cir {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kTileBytes = BM * BK * 2;  // 16 KiB per operand tile
+
+struct GemmArgs {
+    const void* A; int64_t lda, sA;
+    const void* W; int64_t ldw, sW;
+    const float* bias; int64_t sBias;
+    const float* R; int64_t ldr, sR;
+    void* C; int64_t ldc, sC;
+    int64_t M; int N, K, batch, act, tiles_m, tiles_n;
+};
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <typename T, bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
+    using X8 = typename Elem<T>::x8;
+    __shared__ __attribute__((aligned(16))) char smem[4 * kTileBytes];  // [buf][A|W]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int r15 = lane & 15, g = lane >> 4;
+
+    // ---- which tile ---------------------------------------------------------------------------
+    const int nblk = gridDim.x;
+    int id = xcd_remap(blockIdx.x, nblk);
+    const int per_batch = a.tiles_m * a.tiles_n;
+    const int z = id / per_batch;
+    id -= z * per_batch;
+    const int tile_m = id / a.tiles_n, tile_n = id - tile_m * a.tiles_n;
+    const int64_t m0 = (int64_t)tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const T* A = reinterpret_cast<const T*>(a.A) + z * a.sA;
+    const T* W = reinterpret_cast<const T*>(a.W) + z * a.sW;
+
+    // ---- per-lane staging sources: 4 wave-instructions of 8 rows for each operand ---------------
+    const int srow = lane >> 3;                 // row inside the 8-row piece
+    const int schunk = (lane & 7) ^ srow;       // global 16-B chunk this lane fetches (swizzle on the source)
+    const T* a_src[4];
+    const T* w_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int lrow = (wave * 4 + j) * 8 + srow;           // LDS row 0..127
+        int64_t gm = m0 + lrow;
+        gm = gm < a.M ? gm : a.M - 1;                         // clamp the ragged M edge (stores are predicated)
+        a_src[j] = A + gm * a.lda + schunk * 8;
+        // W rows are permuted so that lane group g of the accumulator owns 16 consecutive features
+        const int perm = (lrow & 64) + ((lrow & 15) >> 2) * 16 + ((lrow >> 4) & 3) * 4 + (lrow & 3);
+        int gn = n0 + perm;
+        gn = gn < a.N ? gn : a.N - 1;
+        w_src[j] = W + (int64_t)gn * a.ldw + schunk * 8;
+    }
+
+    auto stage = [&](int kt, int buf) {
+        char* base = smem + buf * 2 * kTileBytes + wave * 4096;
+        const int koff = kt * BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[j] + koff), (lptr_t)(base + j * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[j] + koff), (lptr_t)(base + kTileBytes + j * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets (bytes) inside a tile: row*128 + ((kc ^ (row&7)) << 4)
+    const int a_row_off = (wm * 64 + r15) * 128;
+    const int w_row_off = (wn * 64 + r15) * 128;
+    const int swz = r15 & 7;
+
+    const int nk = a.K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();  // (vmcnt(0) + barrier) tile kt landed everywhere; buffer (kt+1)&1 is free again
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const char* As = smem + (kt & 1) * 2 * kTileBytes;
+        const char* Ws = As + kTileBytes;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + g) ^ swz) << 4;
+            X8 af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const X8*>(As + a_row_off + i * 2048 + coff);
+                wf[i] = *reinterpret_cast<const X8*>(Ws + w_row_off + i * 2048 + coff);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Elem<T>::mfma16(wf[ni], af[mi], acc[mi][ni]);
+        }
+    }
+
+    // ---- epilogue: lane (r15, g) owns, per mi, row m and features nb .. nb+15 ----------------------
+    const int nb = n0 + wn * 64 + g * 16;
+    if (nb + 16 > a.N) return;
+    float bias[16];
+    if (a.bias != nullptr) {
+        const float4* bp = reinterpret_cast<const float4*>(a.bias + z * a.sBias + nb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b4 = bp[q];
+            bias[q * 4 + 0] = b4.x; bias[q * 4 + 1] = b4.y; bias[q * 4 + 2] = b4.z; bias[q * 4 + 3] = b4.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bias[q] = 0.f;
+    }
+    const float* R = a.R ? a.R + z * a.sR : nullptr;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int64_t m = m0 + wm * 64 + mi * 16 + r15;
+        if (m >= a.M) continue;
+        float v[16];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) v[ni * 4 + jj] = acc[mi][ni][jj] + bias[ni * 4 + jj];
+        if (a.act == CIR_ACT_GELU) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = gelu_erf(v[q]);
+        } else if (a.act == CIR_ACT_RELU) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = fmaxf(v[q], 0.f);
+        }
+        if (R != nullptr) {
+            const float4* rp = reinterpret_cast<const float4*>(R + m * a.ldr + nb);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 r4 = rp[q];
+                v[q * 4 + 0] += r4.x; v[q * 4 + 1] += r4.y; v[q * 4 + 2] += r4.z; v[q * 4 + 3] += r4.w;
+            }
+        }
+        if constexpr (OUT_F32) {
+            float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + z * a.sC + m * a.ldc + nb);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cp[q] = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
+        } else {
+            u32x4* cp = reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.C) + z * a.sC + m * a.ldc + nb);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                u32x4 o;
+                o.x = pack2<T>(v[q * 8 + 0], v[q * 8 + 1]);
+                o.y = pack2<T>(v[q * 8 + 2], v[q * 8 + 3]);
+                o.z = pack2<T>(v[q * 8 + 4], v[q * 8 + 5]);
+                o.w = pack2<T>(v[q * 8 + 6], v[q * 8 + 7]);
+                cp[q] = o;
+            }
+        }
+    }
+}
+
+}  // namespace cir
+
+extern "C" int cir_gemm_bias_act(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW,
+                                 const float* bias, int64_t strideBias, const float* residual, int64_t ldr, int64_t strideR,
+                                 void* C, int64_t ldc, int64_t strideC, int64_t M, int N, int K, int batch, int act,
+                                 int in_dtype, int out_dtype, void* stream) {
+    using namespace cir;
+    CIR_CHECK_PTR(A); CIR_CHECK_PTR(W); CIR_CHECK_PTR(C);
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return CIR_EINVAL;
+    if (K % BK != 0 || N % 16 != 0) return CIR_ESHAPE;
+    if (in_dtype != CIR_BF16 && in_dtype != CIR_F16) return CIR_EDTYPE;
+    if (out_dtype != in_dtype && out_dtype != CIR_F32) return CIR_EDTYPE;
+    if (act < CIR_ACT_NONE || act > CIR_ACT_RELU) return CIR_EINVAL;
+    const int64_t out_elems_per16 = out_dtype == CIR_F32 ? 4 : 8;
+    if (!cir_aligned16(A) || !cir_aligned16(W) || !cir_aligned16(C) || lda % 8 || ldw % 8 || strideA % 8 || strideW % 8 ||
+        ldc % out_elems_per16 || strideC % out_elems_per16)
+        return CIR_EALIGN;
+    if (bias && (!cir_aligned16(bias) || strideBias % 4)) return CIR_EALIGN;
+    if (residual && (!cir_aligned16(residual) || ldr % 4 || strideR % 4)) return CIR_EALIGN;
+
+    GemmArgs a;
+    a.A = A; a.lda = lda; a.sA = strideA;
+    a.W = W; a.ldw = ldw; a.sW = strideW;
+    a.bias = bias; a.sBias = strideBias;
+    a.R = residual; a.ldr = ldr; a.sR = strideR;
+    a.C = C; a.ldc = ldc; a.sC = strideC;
+    a.M = M; a.N = N; a.K = K; a.batch = batch; a.act = act;
+    a.tiles_m = (int)((M + BM - 1) / BM);
+    a.tiles_n = (N + BN - 1) / BN;
+    const int64_t nblk = (int64_t)a.tiles_m * a.tiles_n * batch;
+    if (nblk > 0x7fffffff) return CIR_ESHAPE;
+    dim3 grid((unsigned)nblk), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool f32out = out_dtype == CIR_F32;
+    if (in_dtype == CIR_BF16) {
+        if (f32out) hipLaunchKernelGGL((gemm_kernel<__bf16, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_kernel<__bf16, false>), grid, block, 0, s, a);
+    } else {
+        if (f32out) hipLaunchKernelGGL((gemm_kernel<_Float16, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_kernel<_Float16, false>), grid, block, 0, s, a);
+    }
+    CIR_LAUNCH_RESULT();
+}

@@ -1,0 +1,178 @@
+// Small HBM-bound kernels around the GEMMs: patch im2col, ViT token assembly, the 768->2 head,
+// per-row descending argsort, plus cir_version / cir_strerror.
+#include "common.hpp"
+
+namespace cir {
+
+// ---- patchify: one thread per (patch, c, ky) moves a 16-pixel row segment (coalesced 32/64-byte reads) ----
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void patchify_kernel(const TI* img, TO* out, int B, int C, int H, int Wd, int p) {
+    const int gw = Wd / p, gh = H / p;
+    const int64_t total = (int64_t)B * gh * gw * C * p;  // row segments
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    // consecutive threads -> consecutive px for fixed (b, c, y): reads stream along image rows
+    int64_t t = gid;
+    const int px = (int)(t % gw); t /= gw;
+    const int ky = (int)(t % p); t /= p;
+    const int py = (int)(t % gh); t /= gh;
+    const int c = (int)(t % C);
+    const int64_t b = t / C;
+    const TI* src = img + ((b * C + c) * H + (py * p + ky)) * (int64_t)Wd + px * p;
+    TO* dst = out + ((b * gh + py) * gw + px) * (int64_t)(C * p * p) + (c * p + ky) * p;
+    for (int kx = 0; kx < p; ++kx) dst[kx] = static_cast<TO>(static_cast<float>(src[kx]));
+}
+
+// ---- x[b][0] = cls + pos[0]; x[b][1+i] = proj[b*P+i] + pos[1+i] (float4 per thread) ----------------------
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const float* proj, const float* cls, const float* pos, float* x,
+                                                           int B, int P, int D) {
+    const int d4 = D / 4;
+    const int64_t total = (int64_t)B * (P + 1) * d4;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c = (int)(gid % d4);
+    const int64_t row = gid / d4;
+    const int tok = (int)(row % (P + 1));
+    const int64_t b = row / (P + 1);
+    const float4 pe = reinterpret_cast<const float4*>(pos + (int64_t)tok * D)[c];
+    const float4 v = tok == 0 ? reinterpret_cast<const float4*>(cls)[c]
+                              : reinterpret_cast<const float4*>(proj + (b * P + tok - 1) * D)[c];
+    reinterpret_cast<float4*>(x + row * D)[c] = make_float4(v.x + pe.x, v.y + pe.y, v.z + pe.z, v.w + pe.w);
+}
+
+// ---- y[m][n] = x[m] . W[n] + bias[n], N <= 8, one wave per row ---------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void small_linear_kernel(const T* x, int64_t ldx, const T* W, const float* bias, float* y,
+                                                           int64_t M, int N, int K) {
+    using X8 = typename Elem<T>::x8;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float acc[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc[n] = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        const X8 xv = *reinterpret_cast<const X8*>(x + row * ldx + k);
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            if (n < N) {
+                const X8 wv = *reinterpret_cast<const X8*>(W + (int64_t)n * K + k);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[n] = fmaf(static_cast<float>(xv[j]), static_cast<float>(wv[j]), acc[n]);
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        if (n < N) {
+            const float s = wave_sum(acc[n]);
+            if (lane == 0) y[row * N + n] = s + (bias ? bias[n] : 0.f);
+        }
+    }
+}
+
+// ---- descending argsort of one row per workgroup: bitonic network on (value, index) in LDS ------------------
+__global__ __launch_bounds__(256) void topk_desc_kernel(const float* logits, int64_t* idx, int K, int n_pow2) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    float* val = reinterpret_cast<float*>(dyn);
+    int* ind = reinterpret_cast<int*>(dyn + (size_t)n_pow2 * 4);
+    const float* row = logits + (int64_t)blockIdx.x * K;
+    for (int i = threadIdx.x; i < n_pow2; i += blockDim.x) {
+        float v = i < K ? row[i] : -INFINITY;
+        if (v != v) v = -INFINITY;  // NaN sorts last
+        val[i] = v;
+        ind[i] = i < K ? i : 0x7fffffff;
+    }
+    __syncthreads();
+    // "a before b" <=> a.val > b.val, or equal values and a.idx < b.idx (padding has idx = INT_MAX)
+    for (int size = 2; size <= n_pow2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < n_pow2 / 2; t += blockDim.x) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool asc_block = ((lo & size) != 0);  // alternate direction to build bitonic runs
+                const float va = val[lo], vb = val[hi];
+                const int ia = ind[lo], ib = ind[hi];
+                const bool a_first = (va > vb) || (va == vb && ia < ib);
+                const bool swap = asc_block ? a_first : !a_first;
+                if (swap) { val[lo] = vb; val[hi] = va; ind[lo] = ib; ind[hi] = ia; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < K; i += blockDim.x) idx[(int64_t)blockIdx.x * K + i] = ind[i];
+}
+
+}  // namespace cir
+
+extern "C" int cir_version(void) { return CIR_ABI_VERSION; }
+
+extern "C" const char* cir_strerror(int code) {
+    switch (code) {
+        case CIR_OK: return "ok";
+        case CIR_EINVAL: return "invalid argument (null pointer or non-positive extent)";
+        case CIR_ESHAPE: return "extent not supported by the gfx950 kernels";
+        case CIR_EALIGN: return "pointer or stride not aligned for 16-byte vector access";
+        case CIR_EDTYPE: return "dtype code not supported by this entry point";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown cirrank error";
+    }
+}
+
+extern "C" int cir_patchify(const void* image, int img_dtype, void* patches, int dtype16, int B, int C, int H, int Wd,
+                            int patch, void* stream) {
+    using namespace cir;
+    CIR_CHECK_PTR(image); CIR_CHECK_PTR(patches);
+    if (B <= 0 || C <= 0 || H <= 0 || Wd <= 0 || patch <= 0) return CIR_EINVAL;
+    if (H % patch || Wd % patch) return CIR_ESHAPE;
+    if (dtype16 != CIR_BF16 && dtype16 != CIR_F16) return CIR_EDTYPE;
+    if (img_dtype != CIR_F32 && img_dtype != dtype16) return CIR_EDTYPE;
+    const int64_t total = (int64_t)B * C * H * (Wd / patch);
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype16 == CIR_BF16) {
+        if (img_dtype == CIR_F32) hipLaunchKernelGGL((patchify_kernel<float, __bf16>), grid, block, 0, s, (const float*)image, (__bf16*)patches, B, C, H, Wd, patch);
+        else hipLaunchKernelGGL((patchify_kernel<__bf16, __bf16>), grid, block, 0, s, (const __bf16*)image, (__bf16*)patches, B, C, H, Wd, patch);
+    } else {
+        if (img_dtype == CIR_F32) hipLaunchKernelGGL((patchify_kernel<float, _Float16>), grid, block, 0, s, (const float*)image, (_Float16*)patches, B, C, H, Wd, patch);
+        else hipLaunchKernelGGL((patchify_kernel<_Float16, _Float16>), grid, block, 0, s, (const _Float16*)image, (_Float16*)patches, B, C, H, Wd, patch);
+    }
+    CIR_LAUNCH_RESULT();
+}
+
+extern "C" int cir_vit_assemble(const float* proj, const float* cls, const float* pos, float* x, int B, int P, int D,
+                                void* stream) {
+    CIR_CHECK_PTR(proj); CIR_CHECK_PTR(cls); CIR_CHECK_PTR(pos); CIR_CHECK_PTR(x);
+    if (B <= 0 || P <= 0 || D <= 0) return CIR_EINVAL;
+    if (D % 4) return CIR_ESHAPE;
+    if (!cir_aligned16(proj) || !cir_aligned16(cls) || !cir_aligned16(pos) || !cir_aligned16(x)) return CIR_EALIGN;
+    const int64_t total = (int64_t)B * (P + 1) * (D / 4);
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipLaunchKernelGGL(cir::vit_assemble_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), proj, cls, pos, x, B, P, D);
+    CIR_LAUNCH_RESULT();
+}
+
+extern "C" int cir_small_linear(const void* x, int64_t ldx, const void* W, const float* bias, float* y, int64_t M, int N,
+                                int K, int dtype, void* stream) {
+    using namespace cir;
+    CIR_CHECK_PTR(x); CIR_CHECK_PTR(W); CIR_CHECK_PTR(y);
+    if (M <= 0 || N <= 0 || K <= 0) return CIR_EINVAL;
+    if (N > 8 || K % 8) return CIR_ESHAPE;
+    if (dtype != CIR_BF16 && dtype != CIR_F16) return CIR_EDTYPE;
+    if (!cir_aligned16(x) || !cir_aligned16(W) || ldx % 8) return CIR_EALIGN;
+    dim3 grid((unsigned)((M + 3) / 4)), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == CIR_BF16) hipLaunchKernelGGL((small_linear_kernel<__bf16>), grid, block, 0, s, (const __bf16*)x, ldx, (const __bf16*)W, bias, y, M, N, K);
+    else hipLaunchKernelGGL((small_linear_kernel<_Float16>), grid, block, 0, s, (const _Float16*)x, ldx, (const _Float16*)W, bias, y, M, N, K);
+    CIR_LAUNCH_RESULT();
+}
+
+extern "C" int cir_topk_desc(const float* logits, int64_t* idx, int Q, int K, void* stream) {
+    CIR_CHECK_PTR(logits); CIR_CHECK_PTR(idx);
+    if (Q <= 0 || K <= 0) return CIR_EINVAL;
+    if (K > 2048) return CIR_ESHAPE;
+    int n = 2;
+    while (n < K) n <<= 1;
+    dim3 grid((unsigned)Q), block(256);
+    hipLaunchKernelGGL(cir::topk_desc_kernel, grid, block, (size_t)n * 8, reinterpret_cast<hipStream_t>(stream), logits, idx, K, n);
+    CIR_LAUNCH_RESULT();
+}

@@ -1,0 +1,71 @@
+"""ctypes binding of libcirrank.so (C ABI in include/cirrank.h).
+
+The product path has no fallback: if the HIP library is missing or an entry point fails, the
+caller gets an exception - never a silent PyTorch/CPU substitute.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcirrank.so")
+
+CIR_BF16, CIR_F16, CIR_F32 = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+# name -> argtypes; mirrors include/cirrank.h declaration by declaration
+SIGNATURES = {
+    "cir_version": (c_int, []),
+    "cir_strerror": (c_char_p, [c_int]),
+    "cir_gemm_bias_act": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                                  c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                  c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "cir_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                              c_int64, c_int64, c_int, c_int, c_float, c_int, c_void_p]),
+    "cir_attention": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
+                              c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                              c_void_p, c_int64, c_int64, c_int64,
+                              c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "cir_embed_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_int64, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "cir_patchify": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "cir_vit_assemble": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "cir_small_linear": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "cir_topk_desc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+class CirrankError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load libcirrank.so once; raise loudly (no fallback) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the gfx950 kernels first "
+            f"(`python -c 'import __graft_entry__ as g; g.build()'` or `make -C candidate_reranking_cir_amd/csrc`). "
+            f"There is no CPU/PyTorch fallback for this path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    from . import ABI_VERSION
+    if lib.cir_version() != ABI_VERSION:
+        raise ImportError(f"libcirrank.so ABI {lib.cir_version()} != expected {ABI_VERSION}: rebuild")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().cir_strerror(code).decode()
+        raise CirrankError(f"{what} failed: {msg} (code {code})")

@@ -1,0 +1,177 @@
+"""Torch-tensor front end of the C ABI (include/cirrank.h): argument marshalling only.
+
+Every function enqueues HIP kernels from libcirrank.so on torch's current stream and returns
+torch tensors that own the memory.  Nothing here computes with torch ops; there is no fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import lib as _lib
+from .lib import ACT_GELU, ACT_NONE, ACT_RELU, CIR_BF16, CIR_F16, CIR_F32  # noqa: F401
+
+_DT = {torch.bfloat16: CIR_BF16, torch.float16: CIR_F16, torch.float32: CIR_F32}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.CirrankError("cirrank ops need device tensors (no CPU fallback exists)")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+         act: int = ACT_NONE, out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act(a @ w.T + bias) (+ residual).  a (M,K) or (B,M,K) 16-bit with contiguous rows (any
+    row stride); w (N,K) / (B,N,K); bias fp32 (N) / (B,N); residual fp32 like out; out 16-bit or fp32."""
+    _need_cuda(a, w, bias, residual, out)
+    batched = a.dim() == 3
+    if not batched:
+        a3, w3 = a.unsqueeze(0), w.unsqueeze(0)
+    else:
+        a3, w3 = a, w
+    nb, m, k = a3.shape
+    n = w3.shape[1]
+    assert w3.shape[0] == nb and w3.shape[2] == k and a3.stride(2) == 1 and w3.stride(2) == 1
+    out_dtype = out_dtype or a.dtype
+    if out is None:
+        out = torch.empty((nb, m, n) if batched else (m, n), dtype=out_dtype, device=a.device)
+    o3 = out if out.dim() == 3 else out.unsqueeze(0)
+    assert o3.shape == (nb, m, n) and o3.stride(2) == 1 and o3.dtype == out_dtype
+    sb = 0
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.stride(-1) == 1
+        sb = bias.stride(0) if bias.dim() == 2 else 0
+    ldr = sr = 0
+    if residual is not None:
+        r3 = residual if residual.dim() == 3 else residual.unsqueeze(0)
+        assert r3.dtype == torch.float32 and r3.shape == (nb, m, n) and r3.stride(2) == 1
+        ldr, sr = r3.stride(1), r3.stride(0)
+    code = _lib.load().cir_gemm_bias_act(
+        a3.data_ptr(), a3.stride(1), a3.stride(0), w3.data_ptr(), w3.stride(1), w3.stride(0),
+        _ptr(bias), sb, _ptr(residual), ldr, sr, o3.data_ptr(), o3.stride(1), o3.stride(0),
+        m, n, k, nb, act, _DT[a.dtype], _DT[out_dtype], _stream())
+    _lib.check(code, "cir_gemm_bias_act")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, residual: Optional[torch.Tensor] = None,
+              out32: Optional[torch.Tensor] = None, out16: Optional[torch.Tensor] = None, want32: bool = True,
+              dtype16: Optional[torch.dtype] = torch.bfloat16):
+    """LayerNorm over the last dim of fp32 x (rows, cols) or (B, rows, cols) [+ residual]; returns
+    (y32 or None, y16 or None).  gamma/beta (cols) or (B, cols); x/residual may be batch-broadcast
+    (stride 0) views.  `dtype16=None` skips the 16-bit copy."""
+    _need_cuda(x, gamma, beta, residual)
+    x3 = x if x.dim() == 3 else x.unsqueeze(0)
+    nb = max(x3.shape[0], gamma.shape[0] if gamma.dim() == 2 else 1, (residual.shape[0] if residual is not None and residual.dim() == 3 else 1))
+    rows, cols = x3.shape[1], x3.shape[2]
+    assert x3.dtype == torch.float32 and x3.stride(2) == 1 and x3.stride(1) == cols
+    shape = (nb, rows, cols) if (x.dim() == 3 or nb > 1) else (rows, cols)
+    if out32 is None and want32:
+        out32 = torch.empty(shape, dtype=torch.float32, device=x.device)
+    if out16 is None and dtype16 is not None:
+        out16 = torch.empty(shape, dtype=dtype16, device=x.device)
+    sx = x3.stride(0) if x3.shape[0] > 1 else 0
+    sr = 0
+    if residual is not None:
+        r3 = residual if residual.dim() == 3 else residual.unsqueeze(0)
+        assert r3.dtype == torch.float32 and r3.stride(2) == 1 and r3.stride(1) == cols
+        sr = r3.stride(0) if r3.shape[0] > 1 else 0
+    sg = gamma.stride(0) if gamma.dim() == 2 else 0
+    d16 = _DT[out16.dtype] if out16 is not None else CIR_BF16
+    code = _lib.load().cir_layernorm(x3.data_ptr(), sx, _ptr(residual), sr, gamma.data_ptr(), beta.data_ptr(), sg,
+                                     _ptr(out32), _ptr(out16), rows * cols, rows, cols, nb, float(eps), d16, _stream())
+    _lib.check(code, "cir_layernorm")
+    return out32, out16
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, scale: float,
+              mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q/out: (B1, B0, Lq, H*64) views, k/v: (B1, B0, Lk, H*64) views (any strides, unit last stride);
+    mask: additive fp32 (B1, B0, Lk) view or None.  Writes `out` and returns it."""
+    _need_cuda(q, k, v, out, mask)
+    b1, b0, lq, d = q.shape
+    lk = k.shape[2]
+    assert d % 64 == 0 and k.shape == (b1, b0, lk, d) and v.shape == k.shape and out.shape == q.shape
+    assert q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1 and out.stride(3) == 1
+    assert q.dtype == k.dtype == v.dtype == out.dtype
+    ms1 = ms0 = 0
+    if mask is not None:
+        assert mask.dtype == torch.float32 and mask.shape == (b1, b0, lk) and mask.stride(2) == 1
+        ms1, ms0 = mask.stride(0), mask.stride(1)
+    code = _lib.load().cir_attention(
+        q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), k.data_ptr(), k.stride(0), k.stride(1), k.stride(2),
+        v.data_ptr(), v.stride(0), v.stride(1), v.stride(2), _ptr(mask), ms1, ms0,
+        out.data_ptr(), out.stride(0), out.stride(1), out.stride(2), b1, b0, d // 64, lq, lk, float(scale), _DT[q.dtype], _stream())
+    _lib.check(code, "cir_attention")
+    return out
+
+
+def embed_layernorm(ids: torch.Tensor, word: torch.Tensor, pos: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                    eps: float, dtype16: torch.dtype = torch.bfloat16):
+    """BERT embeddings: LayerNorm(word[ids] + pos[:L]); ids (R, L) int64 -> (y32, y16) of shape (R, L, cols)."""
+    _need_cuda(ids, word, pos, gamma, beta)
+    r, l = ids.shape
+    cols = word.shape[1]
+    ids = ids.contiguous()
+    y32 = torch.empty((r, l, cols), dtype=torch.float32, device=ids.device)
+    y16 = torch.empty((r, l, cols), dtype=dtype16, device=ids.device)
+    code = _lib.load().cir_embed_layernorm(ids.data_ptr(), word.data_ptr(), pos.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                           y32.data_ptr(), y16.data_ptr(), r * l, l, cols, word.shape[0], float(eps),
+                                           _DT[dtype16], _stream())
+    _lib.check(code, "cir_embed_layernorm")
+    return y32, y16
+
+
+def patchify(image: torch.Tensor, patch: int, dtype16: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """(B,C,H,W) fp32 or 16-bit -> (B*gh*gw, C*patch*patch) 16-bit, column order (c, ky, kx)."""
+    _need_cuda(image)
+    image = image.contiguous()
+    b, c, h, w = image.shape
+    out = torch.empty((b * (h // patch) * (w // patch), c * patch * patch), dtype=dtype16, device=image.device)
+    code = _lib.load().cir_patchify(image.data_ptr(), _DT[image.dtype], out.data_ptr(), _DT[dtype16], b, c, h, w, patch, _stream())
+    _lib.check(code, "cir_patchify")
+    return out
+
+
+def vit_assemble(proj: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, batch: int) -> torch.Tensor:
+    """proj (B*P, D) fp32, cls (D), pos (P+1, D) -> x (B, P+1, D) fp32."""
+    _need_cuda(proj, cls, pos)
+    p = proj.shape[0] // batch
+    d = proj.shape[1]
+    x = torch.empty((batch, p + 1, d), dtype=torch.float32, device=proj.device)
+    code = _lib.load().cir_vit_assemble(proj.data_ptr(), cls.data_ptr(), pos.data_ptr(), x.data_ptr(), batch, p, d, _stream())
+    _lib.check(code, "cir_vit_assemble")
+    return x
+
+
+def small_linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """(M,K) 16-bit @ (N<=8, K)^T + bias -> (M,N) fp32."""
+    _need_cuda(x, w, bias)
+    m, k = x.shape
+    n = w.shape[0]
+    assert x.stride(1) == 1 and w.is_contiguous()
+    y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    code = _lib.load().cir_small_linear(x.data_ptr(), x.stride(0), w.data_ptr(), _ptr(bias), y.data_ptr(), m, n, k, _DT[x.dtype], _stream())
+    _lib.check(code, "cir_small_linear")
+    return y
+
+
+def argsort_desc(logits: torch.Tensor) -> torch.Tensor:
+    """Row-wise descending argsort of fp32 (Q,K), ties -> lower index first (int64)."""
+    _need_cuda(logits)
+    logits = logits.contiguous()
+    q, k = logits.shape
+    idx = torch.empty((q, k), dtype=torch.int64, device=logits.device)
+    code = _lib.load().cir_topk_desc(logits.data_ptr(), idx.data_ptr(), q, k, _stream())
+    _lib.check(code, "cir_topk_desc")
+    return idx

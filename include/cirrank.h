@@ -1,0 +1,132 @@
+/*
+ * cirrank.h - C ABI of libcirrank.so, the MI355X (gfx950) kernel library behind the stage-II
+ * candidate re-ranking forward path of Cuberick-Orion/Candidate-Reranking-CIR.
+ *
+ * The reference has no native code and no FFI: its "operators" are PyTorch-eager op sequences
+ * inside three Python files.  Each entry point below replaces one such sequence; the citation
+ * names the reference lines whose arithmetic it computes (paths relative to the reference's src/).
+ * The Python host (candidate_reranking_cir_amd/) binds these with ctypes; INTEGRATION.md shows
+ * the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (tensor.data_ptr()); the caller owns all buffers; the
+ *     library allocates nothing, keeps no state, never synchronises the device;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     work is enqueued on it and nowhere else;
+ *   - leading dimensions / strides are in ELEMENTS of the tensor they describe;
+ *   - dtype codes: CIR_BF16 / CIR_F16 for 16-bit activations and weights (fp32 accumulate
+ *     everywhere), CIR_F32 for fp32 tensors;
+ *   - return 0 on success, a negative CIR_E* code for an argument error detected before launch,
+ *     or a positive hipError_t from the launch.  Nothing throws or aborts across the ABI.
+ *   - functions are re-entrant and may be called from any host thread.
+ */
+#ifndef CIRRANK_H
+#define CIRRANK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CIR_ABI_VERSION 1
+
+enum { CIR_BF16 = 0, CIR_F16 = 1, CIR_F32 = 2 };
+enum { CIR_ACT_NONE = 0, CIR_ACT_GELU = 1, CIR_ACT_RELU = 2 };
+enum {
+    CIR_OK = 0,
+    CIR_EINVAL = -1,   /* null pointer / non-positive extent */
+    CIR_ESHAPE = -2,   /* extent not supported by the kernels (see each function) */
+    CIR_EALIGN = -3,   /* pointer or leading dimension not 16-byte aligned */
+    CIR_EDTYPE = -4    /* dtype code not supported here */
+};
+
+int cir_version(void);
+const char* cir_strerror(int code);
+
+/*
+ * C[b] = act(A[b] * W[b]^T + bias[b]) (+ residual[b]),   b = 0..batch-1
+ *   A (M,K) 16-bit row-major (lda), W (N,K) 16-bit row-major "torch Linear" layout (ldw),
+ *   bias fp32 (N) or NULL, residual fp32 (M,N) (ldr) or NULL (added after the activation),
+ *   C (M,N) 16-bit (in_dtype) or fp32 (out_dtype = CIR_F32), ldc.  C may alias residual.
+ *   Requirements: K % 64 == 0, N % 16 == 0, 16-byte aligned rows.
+ * Replaces every nn.Linear on the path: vit.py:35-41,72,84; med.py:158-168,250-251,319-333;
+ * nlvr_encoder.py:150-168,250-264,383-396; blip_stage2.py:50-54 (first layer); the erf GELU is
+ * ACT2FN['gelu'] (nlvr_encoder.py:376-379) / nn.GELU (vit.py:26).
+ */
+int cir_gemm_bias_act(const void* A, int64_t lda, int64_t strideA,
+                      const void* W, int64_t ldw, int64_t strideW,
+                      const float* bias, int64_t strideBias,
+                      const float* residual, int64_t ldr, int64_t strideR,
+                      void* C, int64_t ldc, int64_t strideC,
+                      int64_t M, int N, int K, int batch,
+                      int act, int in_dtype, int out_dtype, void* stream);
+
+/*
+ * y[b] = LayerNorm(x[b] (+ residual[b]); gamma[b], beta[b], eps) over the last dimension.
+ *   x, residual fp32 (rows, cols); gamma/beta fp32 (cols); y32 fp32 and/or y16 16-bit outputs
+ *   (either may be NULL).  cols % 4 == 0, cols <= 1024.  Strides select the per-batch slice
+ *   (stride 0 = shared).  Replaces nn.LayerNorm at vit.py:107-110,192 (eps 1e-6) and
+ *   med.py:253 / nlvr_encoder.py:252-264,395 (eps 1e-12), including the twin LayerNormA/B.
+ */
+int cir_layernorm(const float* x, int64_t strideX, const float* residual, int64_t strideR,
+                  const float* gamma, const float* beta, int64_t strideG,
+                  float* y32, void* y16, int64_t strideY,
+                  int64_t rows, int cols, int batch, float eps, int dtype16, void* stream);
+
+/*
+ * out = softmax(q k^T * scale + mask) v per (batch item, head), head_dim fixed at 64.
+ *   Batch items are indexed (b1, b0), b1 < B1, b0 < B0; element (b1,b0,row,h,d) of q lives at
+ *   q + b1*q_s1 + b0*q_s0 + row*q_rs + h*64 + d (same scheme for k, v, out); mask is an additive
+ *   fp32 key mask (Lk) per item at mask + b1*m_s1 + b0*m_s0, or NULL.  16-bit in/out, fp32
+ *   softmax.  Replaces BertSelfAttention.forward (nlvr_encoder.py:140-222, med.py:158-240: the
+ *   transpose_for_scores / matmul / scale / mask / softmax / matmul / merge-heads sequence) and
+ *   Attention.forward's core (vit.py:73-83).
+ */
+int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t q_rs,
+                  const void* k, int64_t k_s1, int64_t k_s0, int64_t k_rs,
+                  const void* v, int64_t v_s1, int64_t v_s0, int64_t v_rs,
+                  const float* mask, int64_t m_s1, int64_t m_s0,
+                  void* out, int64_t o_s1, int64_t o_s0, int64_t o_rs,
+                  int B1, int B0, int H, int Lq, int Lk, float scale, int dtype, void* stream);
+
+/*
+ * BertEmbeddings.forward (nlvr_encoder.py:68-91, med.py:87-110):
+ *   y[r] = LayerNorm(word[ids[r]] + pos[r % L]) for r < rows; fp32 tables, outputs as cir_layernorm.
+ */
+int cir_embed_layernorm(const int64_t* ids, const float* word, const float* pos,
+                        const float* gamma, const float* beta, float* y32, void* y16,
+                        int64_t rows, int L, int cols, int vocab, float eps, int dtype16, void* stream);
+
+/*
+ * timm PatchEmbed's im2col (vit.py:182; Conv2d k=p s=p == GEMM over flattened patches):
+ *   patches[(b*gh+py)*gw+px][c*p*p + ky*p + kx] = image[b][c][py*p+ky][px*p+kx]
+ *   image fp32 or 16-bit (img_dtype), patches 16-bit (dtype16).
+ */
+int cir_patchify(const void* image, int img_dtype, void* patches, int dtype16,
+                 int B, int C, int H, int Wd, int patch, void* stream);
+
+/*
+ * Token assembly (vit.py:184-187): x[b][0] = cls + pos[0]; x[b][1+i] = proj[b*P+i] + pos[1+i].
+ *   proj fp32 (B*P, D) (patch-embed GEMM output incl. bias), cls (D), pos (P+1, D) fp32 -> x fp32.
+ */
+int cir_vit_assemble(const float* proj, const float* cls, const float* pos, float* x,
+                     int B, int P, int D, void* stream);
+
+/*
+ * y (M, N) fp32 = x (M, K) 16-bit * W (N, K) 16-bit ^T + bias, for tiny N (<= 8): the last
+ * Linear of cls_head (blip_stage2.py:53, 134-136).  K % 8 == 0.
+ */
+int cir_small_linear(const void* x, int64_t ldx, const void* W, const float* bias, float* y,
+                     int64_t M, int N, int K, int dtype, void* stream);
+
+/*
+ * Per-row descending argsort (validate_stage2.py:53,174,188: torch.argsort(..., descending=True)):
+ *   idx[q][j] = index of the j-th largest logit of row q, ties broken by lower index.  K <= 2048.
+ */
+int cir_topk_desc(const float* logits, int64_t* idx, int Q, int K, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CIRRANK_H */

@@ -1,0 +1,251 @@
+"""Per-kernel parity on a real MI355X: each C-ABI entry point against a plain torch fp32 reference
+of the same op on the same (16-bit-rounded) inputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.bfloat16, torch.float16]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from candidate_reranking_cir_amd import ops as _ops
+    return _ops
+
+
+def _rand(shape, dtype, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).cuda()
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,n,k", [(1, 16, 64), (16, 128, 64), (130, 128, 128), (257, 768, 768), (300, 2304, 768), (64, 768, 3072), (1000, 1536, 1536)])
+def test_gemm_exact_integers(ops, dtype, m, n, k):
+    """Small-integer operands make every product and sum exact: any fragment/layout slip shows up
+    as a wrong integer (asymmetric data on both sides)."""
+    g = torch.Generator(device="cpu").manual_seed(m * 7 + n)
+    a = torch.randint(-3, 4, (m, k), generator=g).to(dtype).cuda()
+    w = torch.randint(-3, 4, (n, k), generator=g).to(dtype).cuda()
+    bias = torch.randint(-5, 6, (n,), generator=g).float().cuda()
+    ref = a.float() @ w.float().T + bias
+    out = ops.gemm(a, w, bias, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("out32", [True, False])
+def test_gemm_epilogues(ops, dtype, act, out32):
+    m, n, k = 333, 256, 192
+    a, w = _rand((m, k), dtype, seed=1), _rand((n, k), dtype, 0.1, seed=2)
+    bias = _rand((n,), torch.float32, seed=3)
+    res = _rand((m, n), torch.float32, seed=4)
+    y = a.float() @ w.float().T + bias
+    y = F.gelu(y) if act == 1 else (F.relu(y) if act == 2 else y)
+    ref = y + res
+    out = ops.gemm(a, w, bias, residual=res, act=act, out_dtype=torch.float32 if out32 else dtype)
+    torch.cuda.synchronize()
+    tol = 1e-4 if out32 else (2e-2 if dtype == torch.bfloat16 else 3e-3)
+    assert out.dtype == (torch.float32 if out32 else dtype)
+    torch.testing.assert_close(out.float(), ref, atol=tol * 4, rtol=tol)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_batched_strided_inplace_residual(ops, dtype):
+    nb, m, n, k = 2, 200, 128, 256
+    big = _rand((nb, m, k + 64), dtype, seed=5)
+    a = big[:, :, :k]                       # row stride k+64
+    w = _rand((nb, n, k), dtype, 0.1, seed=6)
+    bias = _rand((nb, n), torch.float32, seed=7)
+    res = _rand((nb, m, n), torch.float32, seed=8)
+    ref = torch.einsum("bmk,bnk->bmn", a.float(), w.float()) + bias[:, None, :] + res
+    cbuf = torch.zeros((m, nb, n), dtype=torch.float32, device="cuda")
+    out = ops.gemm(a, w, bias, residual=res, out_dtype=torch.float32, out=cbuf.permute(1, 0, 2))  # interleaved output
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out, ref, atol=1e-3, rtol=1e-4)
+    # C aliasing the residual (x += f(x) pattern of the ViT blocks)
+    x = res.clone()
+    ops.gemm(a, w, bias, residual=x, out_dtype=torch.float32, out=x)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(x, ref, atol=1e-3, rtol=1e-4)
+
+
+def test_gemm_argument_errors(ops):
+    from candidate_reranking_cir_amd.lib import CirrankError
+    a = torch.zeros((4, 60), dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros((16, 60), dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(CirrankError):
+        ops.gemm(a, w)                       # K % 64 != 0
+    with pytest.raises(CirrankError):
+        ops.gemm(a.cpu(), w.cpu())           # no CPU fallback
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cols,eps", [(768, 1e-12), (768, 1e-6), (128, 1e-12), (1024, 1e-6), (64, 1e-5)])
+def test_layernorm(ops, dtype, cols, eps):
+    rows = 203
+    x = _rand((rows, cols), torch.float32, 2.0, seed=1) + 0.5
+    res = _rand((rows, cols), torch.float32, seed=2)
+    g, b = _rand((cols,), torch.float32, seed=3), _rand((cols,), torch.float32, seed=4)
+    ref = F.layer_norm(x + res, (cols,), g, b, eps)
+    y32, y16 = ops.layernorm(x, g, b, eps, residual=res, dtype16=dtype)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y32, ref, atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(y16.float(), ref.to(dtype).float(), atol=1e-3, rtol=8e-3 if dtype == torch.bfloat16 else 1e-3)  # <= 1 ulp
+
+
+def test_layernorm_twin_shared_input(ops):
+    """LayerNormA(m + h0), LayerNormB(m + h1): shared x, per-branch residual and affine."""
+    rows, cols = 70, 768
+    m = _rand((rows, cols), torch.float32, seed=1)
+    h = _rand((2, rows, cols), torch.float32, seed=2)
+    g, b = _rand((2, cols), torch.float32, seed=3), _rand((2, cols), torch.float32, seed=4)
+    y32, y16 = ops.layernorm(m, g, b, 1e-12, residual=h)
+    torch.cuda.synchronize()
+    for br in (0, 1):
+        torch.testing.assert_close(y32[br], F.layer_norm(m + h[br], (cols,), g[br], b[br], 1e-12), atol=2e-5, rtol=1e-5)
+    assert y16.shape == (2, rows, cols)
+
+
+def test_embed_layernorm(ops):
+    vocab, cols, r, l = 1000, 768, 7, 13
+    word, pos = _rand((vocab, cols), torch.float32, seed=1), _rand((512, cols), torch.float32, seed=2)
+    g, b = _rand((cols,), torch.float32, seed=3), _rand((cols,), torch.float32, seed=4)
+    ids = torch.randint(0, vocab, (r, l), generator=torch.Generator().manual_seed(0)).cuda()
+    ref = F.layer_norm(word[ids] + pos[:l][None], (cols,), g, b, 1e-12)
+    y32, y16 = ops.embed_layernorm(ids, word, pos, g, b, 1e-12)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y32, ref, atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(y16.float(), ref.bfloat16().float(), atol=1e-3, rtol=8e-3)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, scale, mask):
+    b1, b0, lq, d = q.shape
+    h = d // 64
+    qh = q.float().reshape(b1, b0, lq, h, 64).transpose(2, 3)
+    kh = k.float().reshape(b1, b0, -1, h, 64).transpose(2, 3)
+    vh = v.float().reshape(b1, b0, -1, h, 64).transpose(2, 3)
+    s = qh @ kh.transpose(-1, -2) * scale
+    if mask is not None:
+        s = s + mask[:, :, None, None, :]
+    return (torch.softmax(s, -1) @ vh).transpose(2, 3).reshape(b1, b0, lq, d)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("lq,lk", [(1, 1), (5, 7), (32, 32), (33, 64), (32, 197), (197, 197), (11, 577), (64, 40)])
+def test_attention_shapes(ops, dtype, lq, lk):
+    b1, b0, h = 3, 2, 2
+    q, k, v = _rand((b1, b0, lq, h * 64), dtype, seed=1), _rand((b1, b0, lk, h * 64), dtype, seed=2), _rand((b1, b0, lk, h * 64), dtype, seed=3)
+    out = torch.full_like(q, float("nan"))
+    ops.attention(q, k, v, out, 0.125)
+    torch.cuda.synchronize()
+    ref = _attn_ref(q, k, v, 0.125, None)
+    torch.testing.assert_close(out.float(), ref, atol=2e-2 if dtype == torch.bfloat16 else 4e-3, rtol=0)
+
+
+def test_attention_exact_uniform(ops):
+    """q = 0 -> uniform softmax -> out = mean of v over the valid keys: checks the V^T fragment
+    addressing / key masking with values whose mean is exactly representable."""
+    lq, lk, h = 40, 48, 1
+    q = torch.zeros((1, 1, lq, 64), dtype=torch.bfloat16, device="cuda")
+    k = _rand((1, 1, lk, 64), torch.bfloat16, seed=1)
+    v = torch.zeros((1, 1, lk, 64), dtype=torch.bfloat16, device="cuda")
+    key_ids = torch.arange(lk, device="cuda")
+    v[0, 0] = ((key_ids[:, None] % 4) * 16 + torch.arange(64, device="cuda")[None] % 16).to(torch.bfloat16)
+    out = torch.empty_like(q)
+    ops.attention(q, k, v, out, 0.125)
+    torch.cuda.synchronize()
+    ref = v.float().mean(dim=2, keepdim=True).expand(-1, -1, lq, -1)
+    torch.testing.assert_close(out.float(), ref, atol=0.13, rtol=0)   # bf16 rounding of 1/48 weights
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_mask_and_strides(ops, dtype):
+    """ViT-style packed qkv, BERT-style additive key masks (-10000) and the cross-attention layout
+    (keys/values interleaved per branch, output interleaved per branch)."""
+    b, n, h = 4, 50, 3
+    d = h * 64
+    qkv = _rand((b, n, 3, d), dtype, seed=1)
+    out = torch.empty((b, n, d), dtype=dtype, device="cuda")
+    ops.attention(qkv[:, :, 0].unsqueeze(1), qkv[:, :, 1].unsqueeze(1), qkv[:, :, 2].unsqueeze(1), out.unsqueeze(1), 0.125)
+    ref = _attn_ref(qkv[:, :, 0].unsqueeze(1), qkv[:, :, 1].unsqueeze(1), qkv[:, :, 2].unsqueeze(1), 0.125, None)[:, 0]
+    torch.cuda.synchronize()
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    torch.testing.assert_close(out.float(), ref, atol=tol, rtol=0)
+
+    t, l, nk = 5, 12, 37
+    qb = _rand((2, t, l, d), dtype, seed=2)
+    kv = _rand((t, nk, 4, d), dtype, seed=3)                # [K0, V0, K1, V1]
+    cc = torch.empty((t, l, 2, d), dtype=dtype, device="cuda")
+    valid = torch.tensor([37, 30, 1, 36, 20], device="cuda")
+    mask = ((torch.arange(nk, device="cuda")[None] >= valid[:, None]).float() * -10000.0)  # (t, nk)
+    q4 = qb.permute(1, 0, 2, 3)
+    k4 = kv[:, :, 0::2].permute(0, 2, 1, 3)
+    v4 = kv[:, :, 1::2].permute(0, 2, 1, 3)
+    m3 = mask[:, None, :].expand(t, 2, nk)
+    ops.attention(q4, k4, v4, cc.permute(0, 2, 1, 3), 0.125, mask=m3)
+    torch.cuda.synchronize()
+    ref = _attn_ref(q4, k4, v4, 0.125, m3)
+    torch.testing.assert_close(cc.permute(0, 2, 1, 3).float(), ref, atol=tol, rtol=0)
+    # finfo.min style encoder mask on every key -> uniform attention, like the reference's softmax
+    mall = torch.full((t, 2, nk), torch.finfo(torch.float32).min, device="cuda")
+    ops.attention(q4, k4, v4, cc.permute(0, 2, 1, 3), 0.125, mask=mall)
+    torch.cuda.synchronize()
+    ref = _attn_ref(q4, k4, v4, 0.125, mall)
+    assert torch.isfinite(cc.float()).all()
+    torch.testing.assert_close(cc.permute(0, 2, 1, 3).float(), ref, atol=tol, rtol=0)
+
+
+# ------------------------------------------------------------------------------------------------ small ops
+@pytest.mark.parametrize("src", [torch.float32, torch.bfloat16])
+def test_patchify_matches_conv(ops, src):
+    b, c, hw, p, d = 3, 3, 64, 16, 128
+    img = _rand((b, c, hw, hw), src, seed=1)
+    wconv = _rand((d, c, p, p), torch.bfloat16, 0.05, seed=2)
+    patches = ops.patchify(img, p)
+    torch.cuda.synchronize()
+    ref_patches = F.unfold(img.float(), kernel_size=p, stride=p).transpose(1, 2).reshape(-1, c * p * p)
+    assert torch.equal(patches.float(), ref_patches.bfloat16().float())
+    out = ops.gemm(patches, wconv.reshape(d, -1), out_dtype=torch.float32)
+    ref = F.conv2d(img.bfloat16().float(), wconv.float(), stride=p).flatten(2).transpose(1, 2).reshape(-1, d)
+    torch.testing.assert_close(out, ref, atol=2e-3, rtol=1e-3)
+
+
+def test_vit_assemble(ops):
+    b, p, d = 3, 16, 128
+    proj, cls, pos = _rand((b * p, d), torch.float32, seed=1), _rand((d,), torch.float32, seed=2), _rand((p + 1, d), torch.float32, seed=3)
+    x = ops.vit_assemble(proj, cls, pos, b)
+    ref = torch.cat([cls.expand(b, 1, d), proj.view(b, p, d)], 1) + pos[None]
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+
+
+def test_small_linear(ops):
+    m, n, k = 101, 2, 768
+    x, w, bias = _rand((m, k), torch.bfloat16, seed=1), _rand((n, k), torch.bfloat16, 0.1, seed=2), _rand((n,), torch.float32, seed=3)
+    y = ops.small_linear(x, w, bias)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y, x.float() @ w.float().T + bias, atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("q,k", [(1, 1), (7, 5), (33, 100), (4, 205), (3, 2048)])
+def test_argsort_desc(ops, q, k):
+    g = torch.Generator().manual_seed(k)
+    logits = torch.randn((q, k), generator=g)
+    logits[0, : k // 2] = -99999.99                       # skipped-row style ties
+    if k > 3:
+        logits[-1, 1] = logits[-1, 3]
+    idx = ops.argsort_desc(logits.cuda())
+    torch.cuda.synchronize()
+    ref = torch.argsort(logits, dim=-1, descending=True, stable=True)
+    assert torch.equal(idx.cpu(), ref)
