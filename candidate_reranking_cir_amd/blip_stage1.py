@@ -1,0 +1,79 @@
+"""Stage-I model surface used by the stage-II scoring loop: `BLIP_Retrieval.img_txt_fusion(...,
+train=False, return_raw=True)` produces z_t (reference: blip_stage1.py:67-92; called at
+validate_stage2.py:106, 244, 264).  State-dict layout = the reference's `["BLIP_Retrieval"]` entry
+(472 keys).  Only the text encoder runs here: the stage-II scripts feed it image tokens from the
+stage-II ViT (validate_stage2.py:139, 293); stage-I retrieval itself (validate.py) is SURVEY
+section 8(f) row 2 and not built yet.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Union
+
+import torch
+
+from . import ops
+from .blip_stage2 import _EngineHost, encode_text, load_bert_geometry
+from .config import BertGeometry, VitGeometry
+from .engine import MedEngine, VitEngine
+from .param_tree import populate
+from .synthetic import HashTokenizer
+from .weights import retrieval_param_spec
+
+
+class EncoderOutput:
+    """What callers read from the HF output object: `.last_hidden_state` (blip_stage2.py:106)."""
+
+    def __init__(self, last_hidden_state: torch.Tensor, last_hidden_state16: Optional[torch.Tensor] = None):
+        self.last_hidden_state = last_hidden_state
+        self.last_hidden_state16 = last_hidden_state16
+
+
+class BLIP_Retrieval(_EngineHost):
+    def __init__(self, med_config: Union[str, dict, BertGeometry] = "configs/med_config.json", image_size: int = 384,
+                 vit: str = "base", vit_grad_ckpt: bool = False, vit_ckpt_layer: int = 0, embed_dim: int = 256, *,
+                 vit_geometry: Optional[VitGeometry] = None, tokenizer=None):
+        super().__init__()
+        self.vit_geometry = vit_geometry or VitGeometry.named(vit, image_size)
+        self.bert_geometry = load_bert_geometry(med_config)
+        self.bert_geometry.encoder_width = self.vit_geometry.width
+        self.tokenizer = tokenizer if tokenizer is not None else HashTokenizer()
+        populate(self, retrieval_param_spec(self.bert_geometry, self.vit_geometry, embed_dim))
+        self.text_encoder.config = self.bert_geometry
+
+    def engines(self):
+        if self._engines is None:
+            dev = self.device
+            if dev.type != "cuda":
+                raise RuntimeError("BLIP_Retrieval runs on an MI355X only: move the model to 'cuda' (no CPU path)")
+            self._engines = (MedEngine(self.state_dict(), self.bert_geometry, self.compute_dtype, dev),)
+        return self._engines
+
+    @torch.no_grad()
+    def z_t(self, ref_tokens: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> EncoderOutput:
+        """Batched z_t: reference-image tokens (Q, N, D), ids/mask (Q, L) with [ENC] set."""
+        t = ref_tokens.to(self.device)
+        if t.dtype != self.compute_dtype:
+            t = ops.gather_rows(t if t.dtype == torch.float32 else t.float(), None, self.compute_dtype)
+        h32, h16 = self.engines()[0].forward(input_ids, attention_mask, t)
+        return EncoderOutput(h32, h16)
+
+    @torch.no_grad()
+    def img_txt_fusion(self, r_image_embeds, t_image_embeds, text, train=True, return_raw=False):
+        if train or not return_raw:
+            raise NotImplementedError("only img_txt_fusion(..., train=False, return_raw=True) is on the stage-II path")
+        ids, mask = encode_text(self.tokenizer, text, self.device)          # blip_stage1.py:72-73
+        return self.z_t(r_image_embeds, ids, mask)
+
+
+def blip_stage1(pretrained: str = "", **kwargs) -> BLIP_Retrieval:
+    model = BLIP_Retrieval(**kwargs)
+    if pretrained:
+        if not os.path.isfile(pretrained):
+            raise RuntimeError("checkpoint url or path is invalid")
+        ckpt = torch.load(pretrained, map_location="cpu")
+        sd = ckpt.get("BLIP_Retrieval", ckpt.get("model", ckpt))
+        msg = model.load_state_dict(sd, strict=False)
+        print("missing keys:")
+        print(msg.missing_keys)
+    return model

@@ -1,0 +1,174 @@
+"""Drop-in `blip_stage2` model surface on the MI355X kernel library.
+
+Mirrors the public surface of the reference's src/blip_stage2.py (factory `blip_stage2(pretrained,
+**kwargs)`, class `BLIP_NLVR` with `img_embed`, `img_txt_fusion_val`, `img_txt_fusion`, the
+attributes `visual_encoder`, `text_encoder`, `tokenizer`, `cls_head`, and a `state_dict` with the
+same 723 keys/shapes) so the reference's validate/test scripts can construct and call it unchanged
+(validate_stage2.py:352-362, 118, 254, 268; cirr_test_submission_stage2.py:157, 168; utils.py:51).
+Forward arithmetic runs in libcirrank's HIP kernels (`engine.NlvrEngine`, `engine.VitEngine`);
+parameters stay fp32 `nn.Parameter`s (what `load_state_dict` fills) and are packed to 16-bit on
+first use.  Inference only: no autograd graph is built.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Sequence, Union
+
+import torch
+from torch import nn
+
+from . import ops
+from .config import BertGeometry, VitGeometry
+from .engine import NlvrEngine, VitEngine
+from .param_tree import ParamNode, populate
+from .synthetic import HashTokenizer
+from .weights import nlvr_param_spec
+
+_PKG_CONFIG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "med_config.json")
+
+
+def load_bert_geometry(med_config) -> BertGeometry:
+    if isinstance(med_config, BertGeometry):
+        return med_config
+    if isinstance(med_config, dict):
+        return BertGeometry.from_dict(med_config)
+    if not os.path.isfile(med_config) and med_config == "configs/med_config.json":
+        med_config = _PKG_CONFIG  # same default path as the reference, resolved next to the package
+    return BertGeometry.from_json_file(med_config)
+
+
+def encode_text(tokenizer, text, device):
+    """`text` is a list of strings (tokenised like blip_stage2.py:113-114) or an already tokenised
+    object/dict with `input_ids` and `attention_mask`.  Returns ids with ids[:,0] = [ENC]."""
+    if isinstance(text, dict):
+        ids, mask = text["input_ids"], text["attention_mask"]
+    elif hasattr(text, "input_ids"):
+        ids, mask = text.input_ids, text.attention_mask
+    else:
+        if tokenizer is None:
+            raise RuntimeError("no tokenizer set: pass token ids or assign model.tokenizer")
+        enc = tokenizer(text, padding="longest", return_tensors="pt")
+        ids, mask = enc.input_ids, enc.attention_mask
+    ids = ids.to(device=device, dtype=torch.int64).clone()
+    ids[:, 0] = getattr(tokenizer, "enc_token_id", 30523)
+    return ids, mask.to(device=device, dtype=torch.int64)
+
+
+class _EngineHost(nn.Module):
+    """Shared plumbing: lazily packed engines, invalidated when parameters move or are reloaded."""
+
+    def __init__(self):
+        super().__init__()
+        self._engines = None
+        self.compute_dtype = torch.bfloat16
+
+    def set_compute_dtype(self, dtype: torch.dtype):
+        if dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError("compute dtype must be torch.bfloat16 or torch.float16 (fp32 accumulate either way)")
+        self.compute_dtype = dtype
+        self._engines = None
+        return self
+
+    def _apply(self, fn, *a, **k):
+        self._engines = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._engines = None
+        return super().load_state_dict(*a, **k)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+
+class BLIP_NLVR(_EngineHost):
+    """Stage-II re-ranker: ViT-B/16 + two-branch BERT + cls_head (reference: blip_stage2.py:19-136)."""
+
+    def __init__(self, med_config: Union[str, dict, BertGeometry] = "configs/med_config.json", image_size: int = 480,
+                 vit: str = "base", vit_grad_ckpt: bool = False, vit_ckpt_layer: int = 0, *,
+                 vit_geometry: Optional[VitGeometry] = None, tokenizer=None, fold_merge: bool = True):
+        super().__init__()
+        self.vit_geometry = vit_geometry or VitGeometry.named(vit, image_size)
+        self.bert_geometry = load_bert_geometry(med_config)
+        self.bert_geometry.encoder_width = self.vit_geometry.width          # blip_stage2.py:47
+        self.fold_merge = fold_merge
+        self.tokenizer = tokenizer if tokenizer is not None else HashTokenizer()
+        populate(self, nlvr_param_spec(self.bert_geometry, self.vit_geometry))
+        self.text_encoder.config = self.bert_geometry                        # callers read .config.hidden_size
+
+    # ------------------------------------------------------------------------------------------
+    def engines(self):
+        if self._engines is None:
+            dev = self.device
+            if dev.type != "cuda":
+                raise RuntimeError("BLIP_NLVR runs on an MI355X only: move the model to 'cuda' (no CPU path)")
+            sd = self.state_dict()
+            self._engines = (VitEngine(sd, self.vit_geometry, self.compute_dtype, dev),
+                             NlvrEngine(sd, self.bert_geometry, self.compute_dtype, dev, fold_merge=self.fold_merge))
+        return self._engines
+
+    @torch.no_grad()
+    def img_embed(self, image, train=True, atts=False):
+        """(B,3,H,W) -> (B, N, D) fp32 image tokens [+ ones (B, N) int64], blip_stage2.py:57-63."""
+        y32, _ = self.engines()[0].forward(image.to(self.device), want32=True)
+        if atts:
+            return y32, torch.ones(y32.shape[:-1], dtype=torch.long, device=y32.device)
+        return y32
+
+    @torch.no_grad()
+    def img_embed16(self, image) -> torch.Tensor:
+        """Same tokens in the 16-bit compute dtype (what the fusion GEMMs consume)."""
+        return self.engines()[0].forward(image.to(self.device), want32=False)[1]
+
+    def _cand16(self, t_image_embeds: torch.Tensor) -> torch.Tensor:
+        t = t_image_embeds.to(self.device)
+        if t.dtype == self.compute_dtype:
+            return t
+        return ops.gather_rows(t if t.dtype == torch.float32 else t.float(), None, self.compute_dtype)
+
+    @torch.no_grad()
+    def score(self, z_t: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor, cand: torch.Tensor,
+              qidx: torch.Tensor, taps: Optional[list] = None) -> torch.Tensor:
+        """Batched scoring: z_t (Q,L,D), ids/mask (Q,L) with [ENC] already set, cand (T,N,D),
+        qidx (T,) -> (T,) fp32 logits (column 0 of cls_head)."""
+        out = self.engines()[1].forward(input_ids, attention_mask, z_t.to(self.device), self._cand16(cand),
+                                        qidx.to(self.device), taps=taps)
+        return out[:, 0]
+
+    @torch.no_grad()
+    def img_txt_fusion_val(self, r_image_embeds, t_image_embeds, text):
+        """One query, K candidates -> (K,) logits (blip_stage2.py:101-136)."""
+        z = r_image_embeds.last_hidden_state if hasattr(r_image_embeds, "last_hidden_state") else r_image_embeds
+        assert z.shape[0] == 1                                               # blip_stage2.py:108
+        ids, mask = encode_text(self.tokenizer, text, self.device)
+        k = t_image_embeds.shape[0]
+        qidx = torch.zeros((k,), dtype=torch.int64, device=self.device)
+        return self.score(z, ids, mask, t_image_embeds, qidx)
+
+    @torch.no_grad()
+    def img_txt_fusion(self, r_image_embeds, t_image_embeds, text, train=True):
+        """B queries x B candidates -> (B, B) logits (blip_stage2.py:65-99), forward only."""
+        z = r_image_embeds.last_hidden_state if hasattr(r_image_embeds, "last_hidden_state") else r_image_embeds
+        ids, mask = encode_text(self.tokenizer, text, self.device)
+        b = z.shape[0]
+        cand = self._cand16(t_image_embeds)
+        qidx = torch.arange(b, device=self.device).repeat_interleave(b)
+        rows = torch.arange(b, device=self.device).repeat(b)
+        logits = self.score(z, ids, mask, ops.gather_rows(cand, rows), qidx)
+        return logits.view(b, b)
+
+
+def blip_stage2(pretrained: str = "", **kwargs) -> BLIP_NLVR:
+    """Factory with the reference's signature (blip_stage2.py:139-145).  `pretrained` may name a
+    local checkpoint holding either {'BLIP_NLVR': state_dict} (utils.py:145-150) or a plain state dict."""
+    model = BLIP_NLVR(**kwargs)
+    if pretrained:
+        if not os.path.isfile(pretrained):
+            raise RuntimeError("checkpoint url or path is invalid")        # no network on this path
+        ckpt = torch.load(pretrained, map_location="cpu")
+        sd = ckpt.get("BLIP_NLVR", ckpt.get("model", ckpt))
+        msg = model.load_state_dict(sd, strict=False)
+        print("missing keys:")
+        print(msg.missing_keys)
+    return model

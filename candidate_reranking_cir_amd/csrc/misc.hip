@@ -71,6 +71,41 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const T* x, int64_t l
     }
 }
 
+
+// ---- dst[i] = convert(src[index[i]]) for whole rows: candidate gather from the index-feature bank (the
+// reference's torch.stack(itemgetter(*names)(name_to_feat)), validate_stage2.py:115,251), per-query ->
+// per-candidate expansion of hidden states, and dtype conversion at the API boundary. 8 elements per thread. ----
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const TI* src, const int64_t* index, TO* dst, int64_t n_rows,
+                                                          int64_t row_elems, int64_t src_rows) {
+    const int64_t vec_per_row = row_elems / 8;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_rows * vec_per_row) return;
+    const int64_t row = gid / vec_per_row, c = (gid - row * vec_per_row) * 8;
+    int64_t sr = index ? index[row] : row;
+    sr = sr < 0 ? 0 : (sr >= src_rows ? src_rows - 1 : sr);
+    const TI* s = src + sr * row_elems + c;
+    TO* d = dst + row * row_elems + c;
+    float v[8];
+    if constexpr (sizeof(TI) == 4) {
+        const float4 a = reinterpret_cast<const float4*>(s)[0], b = reinterpret_cast<const float4*>(s)[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        typedef __attribute__((ext_vector_type(8))) TI ti8;
+        const ti8 a = *reinterpret_cast<const ti8*>(s);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = static_cast<float>(a[j]);
+    }
+    if constexpr (sizeof(TO) == 4) {
+        reinterpret_cast<float4*>(d)[0] = make_float4(v[0], v[1], v[2], v[3]);
+        reinterpret_cast<float4*>(d)[1] = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        u32x4 o;
+        o.x = pack2<TO>(v[0], v[1]); o.y = pack2<TO>(v[2], v[3]); o.z = pack2<TO>(v[4], v[5]); o.w = pack2<TO>(v[6], v[7]);
+        *reinterpret_cast<u32x4*>(d) = o;
+    }
+}
+
 // ---- descending argsort of one row per workgroup: bitonic network on (value, index) in LDS ------------------
 __global__ __launch_bounds__(256) void topk_desc_kernel(const float* logits, int64_t* idx, int K, int n_pow2) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
@@ -175,4 +210,34 @@ extern "C" int cir_topk_desc(const float* logits, int64_t* idx, int Q, int K, vo
     dim3 grid((unsigned)Q), block(256);
     hipLaunchKernelGGL(cir::topk_desc_kernel, grid, block, (size_t)n * 8, reinterpret_cast<hipStream_t>(stream), logits, idx, K, n);
     CIR_LAUNCH_RESULT();
+}
+
+namespace cir {
+template <typename TI, typename TO>
+static void launch_gather(const void* src, const int64_t* index, void* dst, int64_t n_rows, int64_t row_elems, int64_t src_rows, hipStream_t s) {
+    const int64_t total = n_rows * (row_elems / 8);
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipLaunchKernelGGL((gather_rows_kernel<TI, TO>), grid, block, 0, s, (const TI*)src, index, (TO*)dst, n_rows, row_elems, src_rows);
+}
+}  // namespace cir
+
+extern "C" int cir_gather_rows(const void* src, int src_dtype, const int64_t* index, void* dst, int dst_dtype, int64_t n_rows,
+                               int64_t row_elems, int64_t src_rows, void* stream) {
+    using namespace cir;
+    CIR_CHECK_PTR(src); CIR_CHECK_PTR(dst);
+    if (n_rows <= 0 || row_elems <= 0 || src_rows <= 0) return CIR_EINVAL;
+    if (row_elems % 8) return CIR_ESHAPE;
+    if (!cir_aligned16(src) || !cir_aligned16(dst)) return CIR_EALIGN;
+    if (n_rows * (row_elems / 8) > 0x7fffffffLL * 256) return CIR_ESHAPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define CIR_G(SD, DD, TI, TO) if (src_dtype == SD && dst_dtype == DD) { launch_gather<TI, TO>(src, index, dst, n_rows, row_elems, src_rows, s); CIR_LAUNCH_RESULT(); }
+    CIR_G(CIR_F32, CIR_F32, float, float)
+    CIR_G(CIR_F32, CIR_BF16, float, __bf16)
+    CIR_G(CIR_F32, CIR_F16, float, _Float16)
+    CIR_G(CIR_BF16, CIR_BF16, __bf16, __bf16)
+    CIR_G(CIR_F16, CIR_F16, _Float16, _Float16)
+    CIR_G(CIR_BF16, CIR_F32, __bf16, float)
+    CIR_G(CIR_F16, CIR_F32, _Float16, float)
+#undef CIR_G
+    return CIR_EDTYPE;
 }

@@ -1,0 +1,293 @@
+"""Kernel schedules for the three encoders on the path (Python host, HIP kernels via `ops`).
+
+Each engine packs a reference-layout fp32 state dict once (16-bit weight matrices, fused QKV /
+K|V concatenations, folded merge weights; fp32 biases and LayerNorm affines) and then issues a
+fixed sequence of libcirrank launches per forward.  Precision plan: GEMM operands and attention
+tiles are 16-bit (bf16 or fp16), every accumulation, softmax, LayerNorm and the residual stream
+are fp32.
+
+Reference arithmetic being scheduled (cited per method): vit.py:180-194, med.py:348-398 / 685-821,
+nlvr_encoder.py:414-476 / 777-908, blip_stage2.py:101-136.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .config import BertGeometry, VitGeometry
+
+SD = Dict[str, torch.Tensor]
+
+
+def _w16(t: torch.Tensor, dtype, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).to(dtype).contiguous()
+
+
+def _f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def additive_self_mask(attention_mask: torch.Tensor) -> torch.Tensor:
+    """(R, L) ones/zeros -> fp32 additive key mask (1 - m) * -10000 (nlvr_encoder.py:773-774)."""
+    return ((1.0 - attention_mask.to(torch.float32)) * -10000.0).contiguous()
+
+
+def additive_encoder_mask(attention_mask: torch.Tensor) -> torch.Tensor:
+    """transformers' invert_attention_mask: (1 - m) * finfo(float32).min (called nlvr_encoder.py:863-868)."""
+    return ((1.0 - attention_mask.to(torch.float32)) * torch.finfo(torch.float32).min).contiguous()
+
+
+# =================================================================================================
+class VitEngine:
+    """ViT-B/16 patch encoder (vit.py:113-194 + timm PatchEmbed) as 7 launches per block."""
+
+    def __init__(self, sd: SD, geo: VitGeometry, dtype: torch.dtype, device, prefix: str = "visual_encoder."):
+        geo.validate()
+        self.geo, self.dtype, self.device = geo, dtype, device
+        d = geo.width
+        p = prefix
+        self.w_patch = _w16(sd[p + "patch_embed.proj.weight"].reshape(d, -1), dtype, device)
+        self.b_patch = _f32(sd[p + "patch_embed.proj.bias"], device)
+        self.cls = _f32(sd[p + "cls_token"].reshape(d), device)
+        self.pos = _f32(sd[p + "pos_embed"].reshape(-1, d), device)
+        self.blocks = []
+        for i in range(geo.depth):
+            b = f"{p}blocks.{i}."
+            self.blocks.append(dict(
+                g1=_f32(sd[b + "norm1.weight"], device), b1=_f32(sd[b + "norm1.bias"], device),
+                wqkv=_w16(sd[b + "attn.qkv.weight"], dtype, device), bqkv=_f32(sd[b + "attn.qkv.bias"], device),
+                wo=_w16(sd[b + "attn.proj.weight"], dtype, device), bo=_f32(sd[b + "attn.proj.bias"], device),
+                g2=_f32(sd[b + "norm2.weight"], device), b2=_f32(sd[b + "norm2.bias"], device),
+                w1=_w16(sd[b + "mlp.fc1.weight"], dtype, device), c1=_f32(sd[b + "mlp.fc1.bias"], device),
+                w2=_w16(sd[b + "mlp.fc2.weight"], dtype, device), c2=_f32(sd[b + "mlp.fc2.bias"], device)))
+        self.gf, self.bf = _f32(sd[p + "norm.weight"], device), _f32(sd[p + "norm.bias"], device)
+
+    def forward(self, image: torch.Tensor, want32: bool = False, chunk: int = 256):
+        """(B,3,H,W) fp32/16-bit -> tokens (B, N, D): 16-bit always, fp32 too if `want32`."""
+        if image.shape[0] > chunk:
+            parts = [self.forward(image[i:i + chunk], want32, chunk) for i in range(0, image.shape[0], chunk)]
+            return (torch.cat([p[0] for p in parts]) if want32 else None), torch.cat([p[1] for p in parts])
+        geo, dt = self.geo, self.dtype
+        bsz, d, n = image.shape[0], geo.width, geo.num_tokens
+        if image.shape[-1] != geo.image_size or image.shape[-2] != geo.image_size:
+            raise ValueError(f"image size {tuple(image.shape[-2:])} != model image_size {geo.image_size}")
+        if image.dtype not in (torch.float32, dt):
+            image = image.float()
+        scale = 64 ** -0.5                                                     # vit.py:50
+        patches = ops.patchify(image, geo.patch_size, dt)                      # PatchEmbed im2col
+        proj = ops.gemm(patches, self.w_patch, self.b_patch, out_dtype=torch.float32)
+        x = ops.vit_assemble(proj, self.cls, self.pos, bsz).view(bsz * n, d)   # vit.py:184-187
+        ctx = torch.empty((bsz, n, d), dtype=dt, device=x.device)
+        for blk in self.blocks:
+            _, xb = ops.layernorm(x, blk["g1"], blk["b1"], geo.layer_norm_eps, want32=False, dtype16=dt)
+            qkv = ops.gemm(xb, blk["wqkv"], blk["bqkv"]).view(bsz, n, 3, d)    # vit.py:72
+            ops.attention(qkv[:, :, 0].unsqueeze(1), qkv[:, :, 1].unsqueeze(1), qkv[:, :, 2].unsqueeze(1),
+                          ctx.unsqueeze(1), scale)                             # vit.py:73-83
+            ops.gemm(ctx.view(bsz * n, d), blk["wo"], blk["bo"], residual=x, out_dtype=torch.float32, out=x)  # :84,:108
+            _, xb = ops.layernorm(x, blk["g2"], blk["b2"], geo.layer_norm_eps, want32=False, dtype16=dt)
+            f = ops.gemm(xb, blk["w1"], blk["c1"], act=ops.ACT_GELU)           # vit.py:36-37
+            ops.gemm(f, blk["w2"], blk["c2"], residual=x, out_dtype=torch.float32, out=x)  # vit.py:39, :109
+        y32, y16 = ops.layernorm(x, self.gf, self.bf, geo.layer_norm_eps, want32=want32, dtype16=dt)  # vit.py:192
+        return (y32.view(bsz, n, d) if want32 else None), y16.view(bsz, n, d)
+
+
+# =================================================================================================
+def _cat(sd: SD, keys, suffix: str) -> torch.Tensor:
+    return torch.cat([sd[k + suffix].detach().float() for k in keys], dim=0)
+
+
+class MedEngine:
+    """Stage-I BERT/MED text encoder with image cross-attention (med.py:348-398, 685-821) -> z_t."""
+
+    def __init__(self, sd: SD, geo: BertGeometry, dtype: torch.dtype, device, prefix: str = "text_encoder."):
+        geo.validate()
+        self.geo, self.dtype, self.device = geo, dtype, device
+        e = prefix + "embeddings."
+        self.word, self.posemb = _f32(sd[e + "word_embeddings.weight"], device), _f32(sd[e + "position_embeddings.weight"], device)
+        self.ge, self.be = _f32(sd[e + "LayerNorm.weight"], device), _f32(sd[e + "LayerNorm.bias"], device)
+        self.layers = []
+        for i in range(geo.num_hidden_layers):
+            p = f"{prefix}encoder.layer.{i}."
+            sa, ca = p + "attention.self.", p + "crossattention.self."
+            self.layers.append(dict(
+                wqkv=_w16(_cat(sd, [sa + "query", sa + "key", sa + "value"], ".weight"), dtype, device),
+                bqkv=_f32(_cat(sd, [sa + "query", sa + "key", sa + "value"], ".bias"), device),
+                wo=_w16(sd[p + "attention.output.dense.weight"], dtype, device), bo=_f32(sd[p + "attention.output.dense.bias"], device),
+                g1=_f32(sd[p + "attention.output.LayerNorm.weight"], device), b1=_f32(sd[p + "attention.output.LayerNorm.bias"], device),
+                wq=_w16(sd[ca + "query.weight"], dtype, device), bq=_f32(sd[ca + "query.bias"], device),
+                wkv=_w16(_cat(sd, [ca + "key", ca + "value"], ".weight"), dtype, device),
+                bkv=_f32(_cat(sd, [ca + "key", ca + "value"], ".bias"), device),
+                wco=_w16(sd[p + "crossattention.output.dense.weight"], dtype, device), bco=_f32(sd[p + "crossattention.output.dense.bias"], device),
+                g2=_f32(sd[p + "crossattention.output.LayerNorm.weight"], device), b2=_f32(sd[p + "crossattention.output.LayerNorm.bias"], device),
+                w1=_w16(sd[p + "intermediate.dense.weight"], dtype, device), c1=_f32(sd[p + "intermediate.dense.bias"], device),
+                w2=_w16(sd[p + "output.dense.weight"], dtype, device), c2=_f32(sd[p + "output.dense.bias"], device),
+                g3=_f32(sd[p + "output.LayerNorm.weight"], device), b3=_f32(sd[p + "output.LayerNorm.bias"], device)))
+
+    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, enc16: torch.Tensor,
+                enc_mask: Optional[torch.Tensor] = None):
+        """ids/mask (Q, L), image tokens (Q, N, Dv) 16-bit -> last hidden state (Q, L, D): (fp32, 16-bit)."""
+        geo, dt = self.geo, self.dtype
+        q_n, l = input_ids.shape
+        d, n = geo.hidden_size, enc16.shape[1]
+        r = q_n * l
+        eps, scale = geo.layer_norm_eps, 64 ** -0.5
+        h32, h16 = ops.embed_layernorm(input_ids, self.word, self.posemb, self.ge, self.be, eps, dt)  # med.py:87-110
+        h32, h16 = h32.view(r, d), h16.view(r, d)
+        smask = additive_self_mask(attention_mask).view(q_n, 1, l)
+        emask = additive_encoder_mask(enc_mask).view(q_n, 1, n) if enc_mask is not None else None
+        enc2 = enc16.reshape(q_n * n, enc16.shape[2])
+        ctx = torch.empty((q_n, 1, l, d), dtype=dt, device=h32.device)
+        for ly in self.layers:
+            qkv = ops.gemm(h16, ly["wqkv"], ly["bqkv"]).view(q_n, 1, l, 3 * d)
+            ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], ctx, scale, smask)       # med.py:158-240
+            t = ops.gemm(ctx.view(r, d), ly["wo"], ly["bo"], residual=h32, out_dtype=torch.float32)
+            a32, a16 = ops.layernorm(t, ly["g1"], ly["b1"], eps, dtype16=dt)                           # med.py:250-253
+            qc = ops.gemm(a16, ly["wq"], ly["bq"]).view(q_n, 1, l, d)
+            kv = ops.gemm(enc2, ly["wkv"], ly["bkv"]).view(q_n, 1, n, 2 * d)
+            ops.attention(qc, kv[..., :d], kv[..., d:], ctx, scale, emask)                             # med.py:361-376
+            t = ops.gemm(ctx.view(r, d), ly["wco"], ly["bco"], residual=a32, out_dtype=torch.float32)
+            c32, c16 = ops.layernorm(t, ly["g2"], ly["b2"], eps, dtype16=dt)
+            f = ops.gemm(c16, ly["w1"], ly["c1"], act=ops.ACT_GELU)                                    # med.py:319-322
+            t = ops.gemm(f, ly["w2"], ly["c2"], residual=c32, out_dtype=torch.float32)
+            h32, h16 = ops.layernorm(t, ly["g3"], ly["b3"], eps, dtype16=dt)                           # med.py:331-335
+        return h32.view(q_n, l, d), h16.view(q_n, l, d)
+
+
+# =================================================================================================
+class NlvrEngine:
+    """Stage-II two-branch BERT + cls_head (nlvr_encoder.py:414-476, 777-908; blip_stage2.py:50-54, 101-136).
+
+    Layout: hidden states are (branch, row, D) with row = candidate * L + token.  Per layer:
+    batched(2) QKV GEMM -> self-attention -> batched out-proj(+residual) -> LayerNormA/B ->
+    batched cross-Q GEMM; ONE K|V GEMM over the candidate tokens for both branches
+    ([K0;V0;K1;V1] stacked, N = 4D); cross-attention writes [c0|c1] rows; the merge is a single
+    K = 2D GEMM ([.5 W0 | .5 W1] for the averaging layers, [Wm_a W0 | Wm_b W1] folded for the
+    merge_layer ones - `fold_merge=False` keeps dense0/dense1 and merge_layer as separate GEMMs);
+    twin LayerNorm with the shared merged tensor; FFN on both branches as one M = 2R GEMM pair.
+    Layer 0's self-attention block is candidate-independent and runs once per QUERY.
+    """
+
+    def __init__(self, sd: SD, geo: BertGeometry, dtype: torch.dtype, device, prefix: str = "text_encoder.", fold_merge: bool = True):
+        geo.validate()
+        self.geo, self.dtype, self.device, self.fold_merge = geo, dtype, device, fold_merge
+        e = prefix + "embeddings."
+        self.word, self.posemb = _f32(sd[e + "word_embeddings.weight"], device), _f32(sd[e + "position_embeddings.weight"], device)
+        self.ge, self.be = _f32(sd[e + "LayerNorm.weight"], device), _f32(sd[e + "LayerNorm.bias"], device)
+        d = geo.hidden_size
+        self.layers = []
+        for i in range(geo.num_hidden_layers):
+            p = f"{prefix}encoder.layer.{i}."
+            ly = {}
+            sa = [p + f"attention.self{b}." for b in (0, 1)]
+            ca = [p + f"crossattention.self{b}." for b in (0, 1)]
+            ly["wqkv"] = _w16(torch.stack([_cat(sd, [s + "query", s + "key", s + "value"], ".weight") for s in sa]), dtype, device)
+            ly["bqkv"] = _f32(torch.stack([_cat(sd, [s + "query", s + "key", s + "value"], ".bias") for s in sa]), device)
+            ly["wo"] = _w16(torch.stack([sd[p + f"attention.output.dense{b}.weight"].float() for b in (0, 1)]), dtype, device)
+            ly["bo"] = _f32(torch.stack([sd[p + f"attention.output.dense{b}.bias"].float() for b in (0, 1)]), device)
+            ly["g1"] = _f32(torch.stack([sd[p + f"attention.output.LayerNorm{c}.weight"] for c in "AB"]), device)
+            ly["b1"] = _f32(torch.stack([sd[p + f"attention.output.LayerNorm{c}.bias"] for c in "AB"]), device)
+            ly["wq"] = _w16(torch.stack([sd[c + "query.weight"].float() for c in ca]), dtype, device)
+            ly["bq"] = _f32(torch.stack([sd[c + "query.bias"].float() for c in ca]), device)
+            kv_keys = [ca[0] + "key", ca[0] + "value", ca[1] + "key", ca[1] + "value"]
+            ly["wkv"] = _w16(_cat(sd, kv_keys, ".weight"), dtype, device)         # (4D, Dv)
+            ly["bkv"] = _f32(_cat(sd, kv_keys, ".bias"), device)
+            w0 = sd[p + "crossattention.output.dense0.weight"].double()
+            w1 = sd[p + "crossattention.output.dense1.weight"].double()
+            c0 = sd[p + "crossattention.output.dense0.bias"].double()
+            c1 = sd[p + "crossattention.output.dense1.bias"].double()
+            mk = p + "crossattention.output.merge_layer"
+            if mk + ".weight" in sd:                                               # layers >= 6: nlvr_encoder.py:252-256
+                wm, bm = sd[mk + ".weight"].double(), sd[mk + ".bias"].double()
+                if fold_merge:
+                    ly["wm"] = _w16(torch.cat([wm[:, :d] @ w0, wm[:, d:] @ w1], dim=1).float(), dtype, device)
+                    ly["bm"] = _f32((wm[:, :d] @ c0 + wm[:, d:] @ c1 + bm).float(), device)
+                else:
+                    ly["wd"] = _w16(torch.stack([w0, w1]).float(), dtype, device)
+                    ly["bd"] = _f32(torch.stack([c0, c1]).float(), device)
+                    ly["wm"] = _w16(wm.float(), dtype, device)
+                    ly["bm"] = _f32(bm.float(), device)
+            else:                                                                  # layers < 6: nlvr_encoder.py:257-260
+                ly["wm"] = _w16(torch.cat([0.5 * w0, 0.5 * w1], dim=1).float(), dtype, device)
+                ly["bm"] = _f32((0.5 * (c0 + c1)).float(), device)
+            ly["g2"] = _f32(torch.stack([sd[p + f"crossattention.output.LayerNorm{c}.weight"] for c in "AB"]), device)
+            ly["b2"] = _f32(torch.stack([sd[p + f"crossattention.output.LayerNorm{c}.bias"] for c in "AB"]), device)
+            ly["w1"] = _w16(sd[p + "intermediate.dense.weight"], dtype, device)
+            ly["c1"] = _f32(sd[p + "intermediate.dense.bias"], device)
+            ly["w2"] = _w16(sd[p + "output.dense.weight"], dtype, device)
+            ly["c2"] = _f32(sd[p + "output.dense.bias"], device)
+            ly["g3"] = _f32(sd[p + "output.LayerNorm.weight"], device)
+            ly["b3"] = _f32(sd[p + "output.LayerNorm.bias"], device)
+            self.layers.append(ly)
+        self.wc0, self.bc0 = _w16(sd["cls_head.0.weight"], dtype, device), _f32(sd["cls_head.0.bias"], device)
+        self.wc2, self.bc2 = _w16(sd["cls_head.2.weight"], dtype, device), _f32(sd["cls_head.2.bias"], device)
+
+    # ---------------------------------------------------------------------------------------------
+    def _self_block(self, ly, h32, h16, items, l, smask):
+        """Twin self-attention + LayerNormA/B on (2, items*L, D) hidden states (nlvr_encoder.py:427-433, 262-264)."""
+        d, dt, eps = self.geo.hidden_size, self.dtype, self.geo.layer_norm_eps
+        r = items * l
+        qkv = ops.gemm(h16, ly["wqkv"], ly["bqkv"]).view(2, items, l, 3 * d)
+        ctx = torch.empty((2, items, l, d), dtype=dt, device=h32.device)
+        ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], ctx, 64 ** -0.5, smask.unsqueeze(0).expand(2, items, l))
+        t = ops.gemm(ctx.view(2, r, d), ly["wo"], ly["bo"], residual=h32, out_dtype=torch.float32)
+        return ops.layernorm(t, ly["g1"], ly["b1"], eps, dtype16=dt)
+
+    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, z_t32: torch.Tensor, cand16: torch.Tensor,
+                qidx: torch.Tensor, cand_mask: Optional[torch.Tensor] = None, taps: Optional[list] = None) -> torch.Tensor:
+        """ids/mask (Q, L), z_t (Q, L, D) fp32, candidate tokens (T, N, Dv) 16-bit, qidx (T,) int64 = the
+        query each candidate belongs to -> logits (T, 2) fp32 (column 0 is the score)."""
+        geo, dt = self.geo, self.dtype
+        q_n, l = input_ids.shape
+        t_n, n = cand16.shape[0], cand16.shape[1]
+        d, eps, scale = geo.hidden_size, geo.layer_norm_eps, 64 ** -0.5
+        r = t_n * l
+        emb32, _ = ops.embed_layernorm(input_ids, self.word, self.posemb, self.ge, self.be, eps, dt)   # nlvr_encoder.py:880-886
+        if tuple(z_t32.shape) != tuple(emb32.shape):
+            raise AssertionError("left and right inputs shall be the same shape")                         # nlvr_encoder.py:891
+        hq32 = torch.stack([z_t32.reshape(q_n * l, d).float(), emb32.view(q_n * l, d)])                   # (2, Q*L, D): [z_t, emb] :892
+        hq16 = ops.gather_rows(hq32.view(2 * q_n * l, d), None, dt).view(2, q_n * l, d)
+        smask_q = additive_self_mask(attention_mask)                                                     # (Q, L)
+        # layer 0 self-attention block depends only on (z_t, caption): once per query, then expand to candidates
+        a32q, _ = self._self_block(self.layers[0], hq32, hq16, q_n, l, smask_q)
+        both = torch.cat([qidx, qidx + q_n])                                                              # rows of (2*Q, L*D)
+        a32 = ops.gather_rows(a32q.view(2 * q_n, l * d), both, torch.float32).view(2, r, d)
+        a16 = ops.gather_rows(a32q.view(2 * q_n, l * d), both, dt).view(2, r, d)
+        smask = ops.gather_rows(_pad8(smask_q), qidx, torch.float32)[:, :l]                             # (T, L) view
+        emask = additive_encoder_mask(cand_mask).view(t_n, 1, n).expand(t_n, 2, n) if cand_mask is not None else None
+        cand2 = cand16.reshape(t_n * n, cand16.shape[2])
+        cc = torch.empty((t_n, l, 2, d), dtype=dt, device=cand16.device)
+        h32 = h16 = None
+        for i, ly in enumerate(self.layers):
+            if i > 0:
+                a32, a16 = self._self_block(ly, h32, h16, t_n, l, smask)
+            qc = ops.gemm(a16, ly["wq"], ly["bq"]).view(2, t_n, l, d).permute(1, 0, 2, 3)               # (T, 2, L, D) view
+            kv = ops.gemm(cand2, ly["wkv"], ly["bkv"]).view(t_n, n, 4, d)                                 # [K0 V0 K1 V1]
+            ops.attention(qc, kv[:, :, 0::2].permute(0, 2, 1, 3), kv[:, :, 1::2].permute(0, 2, 1, 3),
+                          cc.permute(0, 2, 1, 3), scale, emask)                                           # nlvr_encoder.py:321-344
+            if "wd" in ly:                                                                                # unfolded merge_layer
+                dd = torch.empty((r, 2, d), dtype=dt, device=cc.device)
+                ops.gemm(cc.view(r, 2, d).permute(1, 0, 2), ly["wd"], ly["bd"], out=dd.permute(1, 0, 2))
+                m = ops.gemm(dd.view(r, 2 * d), ly["wm"], ly["bm"], out_dtype=torch.float32)
+            else:
+                m = ops.gemm(cc.view(r, 2 * d), ly["wm"], ly["bm"], out_dtype=torch.float32)             # :252-260
+            x32, x16 = ops.layernorm(m, ly["g2"], ly["b2"], eps, residual=a32, dtype16=dt)               # LayerNormA/B(m + att_b)
+            f = ops.gemm(x16.view(2 * r, d), ly["w1"], ly["c1"], act=ops.ACT_GELU)                        # shared FFN :469-476
+            t = ops.gemm(f, ly["w2"], ly["c2"], residual=x32.view(2 * r, d), out_dtype=torch.float32)
+            h32, h16 = ops.layernorm(t, ly["g3"], ly["b3"], eps, dtype16=dt)
+            h32, h16 = h32.view(2, r, d), h16.view(2, r, d)
+            if taps is not None:
+                hv = h32.view(2, t_n, l, d)
+                taps.append((hv[0, :, 0, :8].clone(), hv[1, :, 0, :8].clone()))
+        hid = h16.view(2, t_n, l, d)[:, :, 0, :].permute(1, 0, 2).reshape(t_n, 2 * d)                     # cat(CLS_0, CLS_1) :906-908
+        y = ops.gemm(hid, self.wc0, self.bc0, act=ops.ACT_RELU)                                           # blip_stage2.py:50-52
+        return ops.small_linear(y, self.wc2, self.bc2)                                                    # blip_stage2.py:53
+
+
+def _pad8(m: torch.Tensor) -> torch.Tensor:
+    """Pad the last dim of a small fp32 matrix to a multiple of 8 (vector width of cir_gather_rows)."""
+    pad = (-m.shape[1]) % 8
+    if pad == 0:
+        return m.contiguous()
+    return torch.cat([m, m.new_zeros((m.shape[0], pad))], dim=1).contiguous()

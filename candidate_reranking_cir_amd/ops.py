@@ -175,3 +175,19 @@ def argsort_desc(logits: torch.Tensor) -> torch.Tensor:
     code = _lib.load().cir_topk_desc(logits.data_ptr(), idx.data_ptr(), q, k, _stream())
     _lib.check(code, "cir_topk_desc")
     return idx
+
+
+def gather_rows(src: torch.Tensor, index: Optional[torch.Tensor], dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """dst[i] = src[index[i]] converted to `dtype`; rows are src.shape[1:] flattened (index None = plain convert)."""
+    _need_cuda(src, index)
+    src = src.contiguous()
+    dtype = dtype or src.dtype
+    row_elems = src[0].numel()
+    n = src.shape[0] if index is None else index.numel()
+    dst = torch.empty((n,) + tuple(src.shape[1:]), dtype=dtype, device=src.device)
+    if index is not None:
+        index = index.to(torch.int64).contiguous()
+    code = _lib.load().cir_gather_rows(src.data_ptr(), _DT[src.dtype], _ptr(index), dst.data_ptr(), _DT[dtype], n, row_elems,
+                                       src.shape[0], _stream())
+    _lib.check(code, "cir_gather_rows")
+    return dst

@@ -1,0 +1,155 @@
+"""Stage-II scoring loop and Recall@k - the build's counterpart of the reference's
+src/validate_stage2.py:33-298, batched over queries and shardable over GPUs.
+
+Semantics kept from the reference (pinned by tests/golden/tiny_loop.npz, produced by the
+reference's own loop):
+  * a query is scored only if its `K_labels` row holds a positive, otherwise its row of logits is
+    filled with -99999.99 (validate_stage2.py:95/123, 239/258);
+  * candidates are scored in the order of the top-K file (`cand_index` row order) (:115, :251);
+  * FashionIQ joins its two captions as "Cap1 and cap2" (:97-100) - `fiq_caption`;
+  * CIRR additionally scores the 5 non-reference group members with the same z_t (:261-269);
+  * metrics: argsort descending -> gather labels -> 100 * sum(labels[:, :k]) / Q (:53-62, :174-200).
+What changes is the schedule: the reference runs one query per step (batch 1, :104, :242); here
+`query_batch` queries go through stage I together and all their candidates form one stage-II
+batch, z_t is computed once per query (the reference recomputes it for the CIRR subset, :264), and
+names are integer rows of the index-feature bank (no Python dict of tensors, no O(Q^2) vstack).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .blip_stage2 import encode_text
+
+SKIP_FILL = -99999.99
+
+
+@dataclass
+class RelativeValSet:
+    """Tensor form of a 'relative' validation split with its top-K file (data_utils.py:166-179,
+    290-305): every name is an integer row of the index-feature bank."""
+    ref_index: np.ndarray                 # (Q,)   reference image of each query
+    cand_index: np.ndarray                # (Q, K) stage-I top-K candidates, best first
+    labels: np.ndarray                    # (Q, K) bool, K_labels
+    captions: Optional[List[str]] = None  # one caption per query (FashionIQ: already joined)
+    input_ids: Optional[torch.Tensor] = None       # or pre-tokenised (Q, L)
+    attention_mask: Optional[torch.Tensor] = None
+    group_index: Optional[np.ndarray] = None       # (Q, 5) CIRR subset members without the reference
+    target_index: Optional[np.ndarray] = None      # (Q,)   CIRR target_hard
+
+    @property
+    def K(self) -> int:
+        return self.cand_index.shape[1]
+
+    def __len__(self) -> int:
+        return self.cand_index.shape[0]
+
+
+def fiq_caption(cap1: str, cap2: str) -> str:
+    """validate_stage2.py:97-100."""
+    return f"{cap1.strip('.?, ').capitalize()} and {cap2.strip('.?, ')}"
+
+
+@torch.no_grad()
+def extract_index_features(images: torch.Tensor, model, batch_size: int = 64, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """ViT over the whole index (utils.py:43-55), sized from the model instead of the reference's
+    hard-coded (n, 577, 768).  Returns the bank in the model's 16-bit compute dtype by default."""
+    outs = []
+    for i in range(0, images.shape[0], batch_size):
+        chunk = images[i:i + batch_size].to(model.device)
+        outs.append(model.img_embed(chunk) if dtype == torch.float32 else model.img_embed16(chunk))
+    return torch.cat(outs)
+
+
+def _tokenise(ds: RelativeValSet, tokenizer, rows: Sequence[int], length: int, device):
+    if ds.input_ids is not None:
+        sel = list(rows)
+        enc = {"input_ids": ds.input_ids[sel][:, :length], "attention_mask": ds.attention_mask[sel][:, :length]}
+        return encode_text(tokenizer, enc, device)
+    return encode_text(tokenizer, [ds.captions[i] for i in rows], device)
+
+
+def _length_buckets(ds: RelativeValSet, tokenizer, rows: Sequence[int]):
+    """Group queries by token count so a batch never pads (the reference always runs batch 1 with
+    padding='longest', i.e. no padding: blip_stage2.py:113).  Pre-tokenised input is right-padded."""
+    if ds.input_ids is not None:
+        lens = ds.attention_mask[list(rows)].sum(1).tolist()
+    else:
+        lens = [int(tokenizer(ds.captions[i]).input_ids.shape[1]) for i in rows]
+    buckets = {}
+    for r, n in zip(rows, lens):
+        buckets.setdefault(int(n), []).append(r)
+    return buckets
+
+
+@torch.no_grad()
+def generate_val_predictions(blip_model, model_stage1, ds: RelativeValSet, index_features: torch.Tensor,
+                             query_batch: int = 8, rows: Optional[Sequence[int]] = None):
+    """Logits (len(rows), K) [and (len(rows), 5) subset logits when `ds.group_index` is set].
+    `rows` selects a shard of the queries (default: all)."""
+    dev = blip_model.device
+    rows = list(range(len(ds))) if rows is None else list(rows)
+    pos = {r: i for i, r in enumerate(rows)}
+    k = ds.K
+    logits = torch.full((len(rows), k), SKIP_FILL, dtype=torch.float32, device=dev)
+    glogits = torch.empty((len(rows), ds.group_index.shape[1]), dtype=torch.float32, device=dev) if ds.group_index is not None else None
+    has_pos = ds.labels.any(axis=1)
+    # which queries need a forward at all: positives in the top-K (skip rule) or a subset to score
+    active = [r for r in rows if has_pos[r] or ds.group_index is not None]
+    for length, bucket in sorted(_length_buckets(ds, blip_model.tokenizer, active).items()):
+        for s in range(0, len(bucket), query_batch):
+            qs = bucket[s:s + query_batch]
+            ids, mask = _tokenise(ds, blip_model.tokenizer, qs, length, dev)
+            ref = ops.gather_rows(index_features, torch.as_tensor(ds.ref_index[qs], device=dev))
+            z = model_stage1.z_t(ref, ids, mask)                           # once per query
+            cand_rows, qidx, slots = [], [], []
+            for j, q in enumerate(qs):
+                if has_pos[q]:
+                    cand_rows.append(ds.cand_index[q]); qidx += [j] * k; slots.append((pos[q], 0, k))
+                if ds.group_index is not None:
+                    g = ds.group_index[q]
+                    cand_rows.append(g); qidx += [j] * len(g); slots.append((pos[q], 1, len(g)))
+            cand = ops.gather_rows(index_features, torch.as_tensor(np.concatenate(cand_rows), device=dev))
+            out = blip_model.score(z.last_hidden_state, ids, mask, cand, torch.as_tensor(qidx, device=dev))
+            o = 0
+            for row, which, n in slots:
+                (glogits if which else logits)[row] = out[o:o + n]
+                o += n
+    return (logits, glogits) if glogits is not None else logits
+
+
+def generate_fiq_val_predictions(blip_model, model_stage1, relative_val_dataset: RelativeValSet, index_features, **kw):
+    return generate_val_predictions(blip_model, model_stage1, relative_val_dataset, index_features, **kw)
+
+
+def generate_cirr_val_predictions(blip_model, model_stage1, relative_val_dataset: RelativeValSet, index_features, **kw):
+    return generate_val_predictions(blip_model, model_stage1, relative_val_dataset, index_features, **kw)
+
+
+# ------------------------------------------------------------------------------------------------ metrics
+def sorted_labels(logits: torch.Tensor, labels: np.ndarray) -> torch.Tensor:
+    """argsort(desc) on the GPU kernel, then np.take_along_axis like validate_stage2.py:53-57."""
+    order = ops.argsort_desc(logits).cpu().numpy() if logits.is_cuda else torch.argsort(logits, dim=-1, descending=True, stable=True).numpy()
+    return torch.tensor(np.take_along_axis(labels, order, axis=1))
+
+
+def recall_at(lab: torch.Tensor, k: int) -> float:
+    return (torch.sum(lab[:, :k]) / len(lab)).item() * 100
+
+
+def compute_fiq_val_metrics(logits: torch.Tensor, ds: RelativeValSet) -> Tuple[float, float]:
+    """(R@10, R@50), validate_stage2.py:53-66."""
+    lab = sorted_labels(logits, ds.labels)
+    return recall_at(lab, 10), recall_at(lab, 50)
+
+
+def compute_cirr_val_metrics(logits: torch.Tensor, group_logits: torch.Tensor, ds: RelativeValSet):
+    """(Rs@1, Rs@2, Rs@3, R@1, R@5, R@10, R@50), validate_stage2.py:174-206."""
+    lab = sorted_labels(logits, ds.labels)
+    glab = sorted_labels(group_logits, ds.group_index == ds.target_index[:, None])
+    return (recall_at(glab, 1), recall_at(glab, 2), recall_at(glab, 3),
+            recall_at(lab, 1), recall_at(lab, 5), recall_at(lab, 10), recall_at(lab, 50))

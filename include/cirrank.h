@@ -121,6 +121,16 @@ int cir_small_linear(const void* x, int64_t ldx, const void* W, const float* bia
                      int64_t M, int N, int K, int dtype, void* stream);
 
 /*
+ * dst[i] = convert(src[index[i]]) for rows of `row_elems` elements (index NULL = identity).
+ * Replaces the per-query candidate gather torch.stack(itemgetter(*names)(name_to_feat))
+ * (validate_stage2.py:115, 251, 266), the `.expand(K, ...)` of z_t / ids to the K candidates
+ * (blip_stage2.py:118-121) and dtype conversion at the boundary.  row_elems % 8 == 0; dtype pairs:
+ * f32->f32/bf16/f16, bf16->bf16/f32, f16->f16/f32.  Indices are clamped to [0, src_rows).
+ */
+int cir_gather_rows(const void* src, int src_dtype, const int64_t* index, void* dst, int dst_dtype,
+                    int64_t n_rows, int64_t row_elems, int64_t src_rows, void* stream);
+
+/*
  * Per-row descending argsort (validate_stage2.py:53,174,188: torch.argsort(..., descending=True)):
  *   idx[q][j] = index of the j-th largest logit of row q, ties broken by lower index.  K <= 2048.
  */

@@ -249,3 +249,14 @@ def test_argsort_desc(ops, q, k):
     torch.cuda.synchronize()
     ref = torch.argsort(logits, dim=-1, descending=True, stable=True)
     assert torch.equal(idx.cpu(), ref)
+
+
+@pytest.mark.parametrize("src,dst", [(torch.float32, torch.bfloat16), (torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
+                                     (torch.float16, torch.float32), (torch.float32, torch.float16)])
+def test_gather_rows(ops, src, dst):
+    bank = _rand((9, 5, 64), src, seed=1)
+    idx = torch.tensor([3, 3, 0, 8, 1, 7], device="cuda")
+    out = ops.gather_rows(bank, idx, dst)
+    torch.cuda.synchronize()
+    assert torch.equal(out, bank[idx].to(dst))
+    assert torch.equal(ops.gather_rows(bank, None, dst), bank.to(dst))
