@@ -67,7 +67,9 @@ class VitEngine:
     def forward(self, image: torch.Tensor, want32: bool = False, chunk: int = 256):
         """(B,3,H,W) fp32/16-bit -> tokens (B, N, D): 16-bit always, fp32 too if `want32`."""
         if image.shape[0] > chunk:
-            parts = [self.forward(image[i:i + chunk], want32, chunk) for i in range(0, image.shape[0], chunk)]
+            n_parts = -(-image.shape[0] // chunk)
+            size = -(-image.shape[0] // n_parts)                              # balanced chunks (no ragged tail)
+            parts = [self.forward(image[i:i + size], want32, chunk) for i in range(0, image.shape[0], size)]
             return (torch.cat([p[0] for p in parts]) if want32 else None), torch.cat([p[1] for p in parts])
         geo, dt = self.geo, self.dtype
         bsz, d, n = image.shape[0], geo.width, geo.num_tokens

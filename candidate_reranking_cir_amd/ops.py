@@ -15,6 +15,10 @@ from .lib import ACT_GELU, ACT_NONE, ACT_RELU, CIR_BF16, CIR_F16, CIR_F32  # noq
 _DT = {torch.bfloat16: CIR_BF16, torch.float16: CIR_F16, torch.float32: CIR_F32}
 
 
+# bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream
+PROFILE_GEMM = None
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -56,10 +60,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         r3 = residual if residual.dim() == 3 else residual.unsqueeze(0)
         assert r3.dtype == torch.float32 and r3.shape == (nb, m, n) and r3.stride(2) == 1
         ldr, sr = r3.stride(1), r3.stride(0)
+    if PROFILE_GEMM is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     code = _lib.load().cir_gemm_bias_act(
         a3.data_ptr(), a3.stride(1), a3.stride(0), w3.data_ptr(), w3.stride(1), w3.stride(0),
         _ptr(bias), sb, _ptr(residual), ldr, sr, o3.data_ptr(), o3.stride(1), o3.stride(0),
         m, n, k, nb, act, _DT[a.dtype], _DT[out_dtype], _stream())
+    if PROFILE_GEMM is not None:
+        ev1.record()
+        PROFILE_GEMM.append((2.0 * nb * m * n * k, ev0, ev1))
     _lib.check(code, "cir_gemm_bias_act")
     return out
 
