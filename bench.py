@@ -50,6 +50,18 @@ def algorithmic_gflop(n_tok: int, l: int, k: int):
     return dict(vit=vit / 1e9, fuse=fuse / 1e9, s1=s1 / 1e9, per_triplet=(vit + fuse + (vit + s1) / k) / 1e9)
 
 
+def usable_cpus() -> int:
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(threads: int):
     """Oracle (fp32 CPU port of the reference op sequence) on a bounded sample: 4 images through the
     ViT, 1 query through stage I, 8 candidates through the fusion; composed to triplets/s at K=100."""
@@ -183,7 +195,7 @@ def main():
                          "gemm_share_of_step": round(gemm_ms / step_ms, 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline(usable_cpus())
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

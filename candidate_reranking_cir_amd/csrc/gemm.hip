@@ -15,24 +15,15 @@
 //     features of one output row -> 16/32/64-byte vector stores, fp32 bias/residual as float4.
 //   * Workgroup -> tile mapping is XCD-aware (blocks that share an XCD's L2 walk neighbouring
 //     tiles of one row panel, so the A panel is fetched from HBM once per XCD).
-#include "common.hpp"
+#include <stdlib.h>
+
+#include "gemm_args.hpp"
 
 namespace cir {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int kTileBytes = BM * BK * 2;  // 16 KiB per operand tile
 
-struct GemmArgs {
-    const void* A; int64_t lda, sA;
-    const void* W; int64_t ldw, sW;
-    const float* bias; int64_t sBias;
-    const float* R; int64_t ldr, sR;
-    void* C; int64_t ldc, sC;
-    int64_t M; int N, K, batch, act, tiles_m, tiles_n;
-};
-
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <typename T, bool OUT_F32>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
@@ -213,9 +204,21 @@ extern "C" int cir_gemm_bias_act(const void* A, int64_t lda, int64_t strideA, co
     a.tiles_n = (N + BN - 1) / BN;
     const int64_t nblk = (int64_t)a.tiles_m * a.tiles_n * batch;
     if (nblk > 0x7fffffff) return CIR_ESHAPE;
-    dim3 grid((unsigned)nblk), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool f32out = out_dtype == CIR_F32;
+    // Tile choice: the 256x256 8-phase kernel needs about a full wave of workgroups (256 CUs) to pay;
+    // small problems keep the 128x128 kernel (more, smaller tiles).  CIR_GEMM_TILE=128|256 forces one (tests, A/B).
+    const int64_t nblk256 = ((M + 255) / 256) * ((N + 255) / 256) * batch;
+    bool use256 = N >= 256 && nblk256 >= 192;
+    if (const char* force = getenv("CIR_GEMM_TILE")) {
+        if (force[0] == '1') use256 = false;
+        else if (force[0] == '2') use256 = true;
+    }
+    if (use256) {
+        launch_gemm256(a, in_dtype, f32out, s);
+        CIR_LAUNCH_RESULT();
+    }
+    dim3 grid((unsigned)nblk), block(256);
     if (in_dtype == CIR_BF16) {
         if (f32out) hipLaunchKernelGGL((gemm_kernel<__bf16, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((gemm_kernel<__bf16, false>), grid, block, 0, s, a);

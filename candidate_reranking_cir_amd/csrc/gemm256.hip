@@ -1,0 +1,241 @@
+// 256x256x64-tile MFMA GEMM for the large shapes of the path (M in the tens of thousands):
+// 8 waves (2 along M x 4 along N), each wave owns 128 x 64 outputs = 128 fp32 accumulators per lane.
+//
+// Schedule (after the 8-phase structure of the CDNA4 programming guide, re-derived with conservative
+// hazards; see DESIGN.md "GEMM"):
+//   * LDS holds two K-tiles (dbuf 0/1), each as four 16-KiB half-tiles A0 A1 (activation rows 0-127 /
+//     128-255 of the tile) and B0 B1 (weight rows 0-127 / 128-255); 128 KiB in total, one block per CU.
+//   * a K-tile is consumed in four phases, one 64x32 output quadrant per wave and phase (16 MFMAs):
+//       q0 = (A0,B0)  reads B0 then A0 (12 ds_read_b128)      q1 = (A0,B1)  reads B1 (4)
+//       q2 = (A1,B1)  reads A1 (8)                             q3 = (A1,B0)  reads B0 (4)
+//   * every phase also issues ONE half-tile refill by LDS-DMA (2 x global_load_lds_dwordx4 per lane),
+//     always into a half-tile whose last read lies two phases back:
+//       phase:   1        2        3        4        5        6        7        8
+//       refill:  A1>d1    B0>d1    A0>d0    B1>d0    A1>d0    B0>d0    A0>d1    B1>d1
+//       tile:    t+1      t+1      t+2      t+2      t+2      t+2      t+3      t+3
+//     The only vector-memory waits in the loop are a counted `s_waitcnt vmcnt(4)` in phases 4 and 8
+//     (the two newest half-tiles stay in flight across the K-tile boundary); the buffer they retire is
+//     first read one phase later, behind a barrier.
+//   * the two wave groups (waves 0-3 / 4-7 = the two waves of each SIMD) run staggered by one barrier,
+//     so one group's MFMA segment overlaps the other group's LDS-read / DMA-issue segment.
+// Operand layout, swizzle, swapped MFMA orientation and epilogue are those of gemm.hip.
+#include "gemm_args.hpp"
+
+namespace cir {
+
+constexpr int T256 = 256;
+constexpr int kHalf = 16384;       // one half-tile: 128 rows x 64 k x 2 B
+constexpr int kDbuf = 4 * kHalf;   // A0 A1 B0 B1
+
+template <typename T, bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
+    using X8 = typename Elem<T>::x8;
+    __shared__ __attribute__((aligned(16))) char smem[2 * kDbuf];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;   // wr doubles as the stagger group (SIMD partners differ in wr)
+    const int r15 = lane & 15, g = lane >> 4;
+
+    int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_batch = a.tiles_m * a.tiles_n;
+    const int z = id / per_batch;
+    id -= z * per_batch;
+    const int tile_m = id / a.tiles_n, tile_n = id - tile_m * a.tiles_n;
+    const int64_t m0 = (int64_t)tile_m * T256;
+    const int n0 = tile_n * T256;
+
+    const T* A = reinterpret_cast<const T*>(a.A) + z * a.sA;
+    const T* W = reinterpret_cast<const T*>(a.W) + z * a.sW;
+
+    // ---- staging sources: every half-tile is 16 wave-instructions of 8 rows; wave w issues pieces 2w, 2w+1 ----
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;
+    const T* a_src[2][2];
+    const T* w_src[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int lr = (wave * 2 + j) * 8 + srow;             // LDS row inside the half-tile
+            int64_t gm = m0 + h * 128 + lr;
+            gm = gm < a.M ? gm : a.M - 1;
+            a_src[h][j] = A + gm * a.lda + schunk * 8;
+            // weight rows permuted so that accumulator lane group g owns 8 consecutive features per half
+            const int feat = (lr & ~31) + ((lr & 15) >> 2) * 8 + ((lr >> 4) & 1) * 4 + (lr & 3);
+            int gn = n0 + h * 128 + feat;
+            gn = gn < a.N ? gn : a.N - 1;
+            w_src[h][j] = W + (int64_t)gn * a.ldw + schunk * 8;
+        }
+    const int nk = a.K >> 6;
+    char* const stage_base = smem + wave * 2048;
+
+#define ISSUE_A(H, DB, KT)                                                                                              \
+    if ((KT) < nk) {                                                                                                    \
+        __builtin_amdgcn_global_load_lds((gptr_t)(a_src[H][0] + (KT) * 64), (lptr_t)(stage_base + (DB) * kDbuf + (H) * kHalf), 16, 0, 0);        \
+        __builtin_amdgcn_global_load_lds((gptr_t)(a_src[H][1] + (KT) * 64), (lptr_t)(stage_base + (DB) * kDbuf + (H) * kHalf + 1024), 16, 0, 0); \
+    }
+#define ISSUE_B(H, DB, KT)                                                                                              \
+    if ((KT) < nk) {                                                                                                    \
+        __builtin_amdgcn_global_load_lds((gptr_t)(w_src[H][0] + (KT) * 64), (lptr_t)(stage_base + (DB) * kDbuf + (2 + (H)) * kHalf), 16, 0, 0);        \
+        __builtin_amdgcn_global_load_lds((gptr_t)(w_src[H][1] + (KT) * 64), (lptr_t)(stage_base + (DB) * kDbuf + (2 + (H)) * kHalf + 1024), 16, 0, 0); \
+    }
+
+    f32x4 acc[2][4][2][2];  // [m-half][m-tile][n-half][n-tile]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int l = 0; l < 2; ++l) acc[i][j][k][l] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int swz = r15 & 7;
+    const int c0 = ((0 + g) ^ swz) << 4, c1 = ((4 + g) ^ swz) << 4;   // 16-byte chunk offsets of the two k-steps
+    const char* const a_rd = smem + (wr * 64 + r15) * 128;
+    const char* const b_rd = smem + 2 * kHalf + (wc * 32 + r15) * 128;
+    X8 af[4][2], wf[2][2];
+
+#define READ_A(H, DB)                                                                                  \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                 \
+        af[mi][0] = *reinterpret_cast<const X8*>(a_rd + (DB) * kDbuf + (H) * kHalf + mi * 2048 + c0);  \
+        af[mi][1] = *reinterpret_cast<const X8*>(a_rd + (DB) * kDbuf + (H) * kHalf + mi * 2048 + c1);  \
+    }
+#define READ_B(H, DB)                                                                                  \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                                 \
+        wf[ni][0] = *reinterpret_cast<const X8*>(b_rd + (DB) * kDbuf + (H) * kHalf + ni * 2048 + c0);  \
+        wf[ni][1] = *reinterpret_cast<const X8*>(b_rd + (DB) * kDbuf + (H) * kHalf + ni * 2048 + c1);  \
+    }
+#define MMA(MH, NH)                                                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                   \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                               \
+            _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                           \
+                acc[MH][mi][NH][ni] = Elem<T>::mfma16(wf[ni][ks], af[mi][ks], acc[MH][mi][NH][ni]);
+#define SYNC()                                   \
+    __builtin_amdgcn_sched_barrier(0);           \
+    __builtin_amdgcn_s_barrier();                \
+    __builtin_amdgcn_sched_barrier(0);
+#define COMPUTE(ON, MH, NH)                      \
+    SYNC();                                      \
+    if (ON) {                                    \
+        __builtin_amdgcn_s_setprio(1);           \
+        MMA(MH, NH);                             \
+        __builtin_amdgcn_s_setprio(0);           \
+    }                                            \
+    SYNC();
+#define WAIT_TILE(NEXT_KT)                                                        \
+    if ((NEXT_KT) < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- prologue: tile 0 complete in dbuf 0, first two half-tiles of tile 1 in flight --------------------
+    ISSUE_A(0, 0, 0) ISSUE_A(1, 0, 0) ISSUE_B(0, 0, 0) ISSUE_B(1, 0, 0)
+    ISSUE_A(0, 1, 1) ISSUE_B(1, 1, 1)
+    WAIT_TILE(1)
+    SYNC();
+    if (wr == 1) { SYNC(); }   // stagger: waves 4-7 run one barrier behind waves 0-3
+
+    const int niter = (nk + 1) >> 1;
+    for (int it = 0; it < niter; ++it) {
+        const int t0 = 2 * it, t1 = t0 + 1;
+        const bool odd = t1 < nk;
+        // ---- K-tile t0 in dbuf 0 -------------------------------------------------------------------------
+        READ_B(0, 0) READ_A(0, 0) ISSUE_A(1, 1, t1)                      COMPUTE(true, 0, 0)   // phase 1
+        READ_B(1, 0)              ISSUE_B(0, 1, t1)                      COMPUTE(true, 0, 1)   // phase 2
+        READ_A(1, 0)              ISSUE_A(0, 0, t0 + 2)                  COMPUTE(true, 1, 1)   // phase 3
+        READ_B(0, 0)              ISSUE_B(1, 0, t0 + 2) WAIT_TILE(t0 + 2) COMPUTE(true, 1, 0)  // phase 4
+        // ---- K-tile t1 in dbuf 1 -------------------------------------------------------------------------
+        if (odd) { READ_B(0, 1) READ_A(0, 1) }
+        ISSUE_A(1, 0, t0 + 2)                                            COMPUTE(odd, 0, 0)    // phase 5
+        if (odd) { READ_B(1, 1) }
+        ISSUE_B(0, 0, t0 + 2)                                            COMPUTE(odd, 0, 1)    // phase 6
+        if (odd) { READ_A(1, 1) }
+        ISSUE_A(0, 1, t1 + 2)                                            COMPUTE(odd, 1, 1)    // phase 7
+        if (odd) { READ_B(0, 1) }
+        ISSUE_B(1, 1, t1 + 2) WAIT_TILE(t1 + 2)                          COMPUTE(odd, 1, 0)    // phase 8
+    }
+    if (wr == 0) { SYNC(); }   // pair the trailing barrier of the staggered group
+#undef ISSUE_A
+#undef ISSUE_B
+#undef READ_A
+#undef READ_B
+#undef MMA
+#undef SYNC
+#undef COMPUTE
+#undef WAIT_TILE
+
+    // ---- epilogue: lane (r15, g) owns rows m0 + mh*128 + wr*64 + mi*16 + r15, features nb(nh) .. nb+7 ---------
+    float bias[2][8];
+    bool n_ok[2];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+        const int nb = n0 + nh * 128 + wc * 32 + g * 8;
+        n_ok[nh] = nb + 8 <= a.N;
+        if (a.bias != nullptr && n_ok[nh]) {
+            const float4* bp = reinterpret_cast<const float4*>(a.bias + z * a.sBias + nb);
+            const float4 b0 = bp[0], b1 = bp[1];
+            bias[nh][0] = b0.x; bias[nh][1] = b0.y; bias[nh][2] = b0.z; bias[nh][3] = b0.w;
+            bias[nh][4] = b1.x; bias[nh][5] = b1.y; bias[nh][6] = b1.z; bias[nh][7] = b1.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bias[nh][q] = 0.f;
+        }
+    }
+    const float* R = a.R ? a.R + z * a.sR : nullptr;
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int64_t m = m0 + mh * 128 + wr * 64 + mi * 16 + r15;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+                if (!n_ok[nh]) continue;
+                const int nb = n0 + nh * 128 + wc * 32 + g * 8;
+                float v[8];
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) v[ni * 4 + jj] = acc[mh][mi][nh][ni][jj] + bias[nh][ni * 4 + jj];
+                if (a.act == CIR_ACT_GELU) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = gelu_erf(v[q]);
+                } else if (a.act == CIR_ACT_RELU) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+                }
+                if (R != nullptr) {
+                    const float4* rp = reinterpret_cast<const float4*>(R + m * a.ldr + nb);
+                    const float4 r0 = rp[0], r1 = rp[1];
+                    v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                    v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                }
+                if constexpr (OUT_F32) {
+                    float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + z * a.sC + m * a.ldc + nb);
+                    cp[0] = make_float4(v[0], v[1], v[2], v[3]);
+                    cp[1] = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+                    u32x4 o;
+                    o.x = pack2<T>(v[0], v[1]); o.y = pack2<T>(v[2], v[3]); o.z = pack2<T>(v[4], v[5]); o.w = pack2<T>(v[6], v[7]);
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.C) + z * a.sC + m * a.ldc + nb) = o;
+                }
+            }
+        }
+}
+
+void launch_gemm256(const GemmArgs& a_in, int in_dtype, bool f32out, hipStream_t s) {
+    GemmArgs a = a_in;
+    a.tiles_m = (int)((a.M + T256 - 1) / T256);
+    a.tiles_n = (a.N + T256 - 1) / T256;
+    dim3 grid((unsigned)((int64_t)a.tiles_m * a.tiles_n * a.batch)), block(512);
+    if (in_dtype == CIR_BF16) {
+        if (f32out) hipLaunchKernelGGL((gemm256_kernel<__bf16, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm256_kernel<__bf16, false>), grid, block, 0, s, a);
+    } else {
+        if (f32out) hipLaunchKernelGGL((gemm256_kernel<_Float16, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm256_kernel<_Float16, false>), grid, block, 0, s, a);
+    }
+}
+
+}  // namespace cir

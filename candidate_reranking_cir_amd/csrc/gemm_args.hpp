@@ -1,0 +1,22 @@
+// Shared GEMM argument block and launcher declarations (gemm.hip = 128x128 tiles, gemm256.hip = 256x256 tiles).
+#pragma once
+#include "common.hpp"
+
+namespace cir {
+
+struct GemmArgs {
+    const void* A; int64_t lda, sA;
+    const void* W; int64_t ldw, sW;
+    const float* bias; int64_t sBias;
+    const float* R; int64_t ldr, sR;
+    void* C; int64_t ldc, sC;
+    int64_t M; int N, K, batch, act, tiles_m, tiles_n;
+};
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// 256x256x64 tiles, 8 waves, staggered 8-phase schedule (gemm256.hip)
+void launch_gemm256(const GemmArgs& a, int in_dtype, bool f32out, hipStream_t s);
+
+}  // namespace cir

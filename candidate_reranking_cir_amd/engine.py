@@ -195,13 +195,14 @@ class NlvrEngine:
             kv_keys = [ca[0] + "key", ca[0] + "value", ca[1] + "key", ca[1] + "value"]
             ly["wkv"] = _w16(_cat(sd, kv_keys, ".weight"), dtype, device)         # (4D, Dv)
             ly["bkv"] = _f32(_cat(sd, kv_keys, ".bias"), device)
-            w0 = sd[p + "crossattention.output.dense0.weight"].double()
-            w1 = sd[p + "crossattention.output.dense1.weight"].double()
-            c0 = sd[p + "crossattention.output.dense0.bias"].double()
-            c1 = sd[p + "crossattention.output.dense1.bias"].double()
+            # one-time weight preparation in fp64 on the host (keeps library GEMMs out of the device timeline)
+            w0 = sd[p + "crossattention.output.dense0.weight"].detach().cpu().double()
+            w1 = sd[p + "crossattention.output.dense1.weight"].detach().cpu().double()
+            c0 = sd[p + "crossattention.output.dense0.bias"].detach().cpu().double()
+            c1 = sd[p + "crossattention.output.dense1.bias"].detach().cpu().double()
             mk = p + "crossattention.output.merge_layer"
             if mk + ".weight" in sd:                                               # layers >= 6: nlvr_encoder.py:252-256
-                wm, bm = sd[mk + ".weight"].double(), sd[mk + ".bias"].double()
+                wm, bm = sd[mk + ".weight"].detach().cpu().double(), sd[mk + ".bias"].detach().cpu().double()
                 if fold_merge:
                     ly["wm"] = _w16(torch.cat([wm[:, :d] @ w0, wm[:, d:] @ w1], dim=1).float(), dtype, device)
                     ly["bm"] = _f32((wm[:, :d] @ c0 + wm[:, d:] @ c1 + bm).float(), device)

@@ -25,9 +25,16 @@ def _rand(shape, dtype, scale=1.0, seed=0):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
+@pytest.fixture(params=["128", "256"])
+def gemm_tile(request, monkeypatch):
+    """Run the GEMM tests once per kernel (CIR_GEMM_TILE forces the 128x128 or the 256x256 8-phase kernel)."""
+    monkeypatch.setenv("CIR_GEMM_TILE", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("m,n,k", [(1, 16, 64), (16, 128, 64), (130, 128, 128), (257, 768, 768), (300, 2304, 768), (64, 768, 3072), (1000, 1536, 1536)])
-def test_gemm_exact_integers(ops, dtype, m, n, k):
+@pytest.mark.parametrize("m,n,k", [(1, 16, 64), (16, 128, 64), (130, 128, 128), (257, 768, 768), (300, 2304, 768), (64, 768, 3072), (1000, 1536, 1536), (515, 528, 192), (700, 256, 64), (513, 768, 128)])
+def test_gemm_exact_integers(ops, gemm_tile, dtype, m, n, k):
     """Small-integer operands make every product and sum exact: any fragment/layout slip shows up
     as a wrong integer (asymmetric data on both sides)."""
     g = torch.Generator(device="cpu").manual_seed(m * 7 + n)
@@ -43,7 +50,7 @@ def test_gemm_exact_integers(ops, dtype, m, n, k):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("act", [0, 1, 2])
 @pytest.mark.parametrize("out32", [True, False])
-def test_gemm_epilogues(ops, dtype, act, out32):
+def test_gemm_epilogues(ops, gemm_tile, dtype, act, out32):
     m, n, k = 333, 256, 192
     a, w = _rand((m, k), dtype, seed=1), _rand((n, k), dtype, 0.1, seed=2)
     bias = _rand((n,), torch.float32, seed=3)
@@ -59,7 +66,7 @@ def test_gemm_epilogues(ops, dtype, act, out32):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_gemm_batched_strided_inplace_residual(ops, dtype):
+def test_gemm_batched_strided_inplace_residual(ops, gemm_tile, dtype):
     nb, m, n, k = 2, 200, 128, 256
     big = _rand((nb, m, k + 64), dtype, seed=5)
     a = big[:, :, :k]                       # row stride k+64
