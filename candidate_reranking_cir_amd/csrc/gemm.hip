@@ -199,7 +199,7 @@ extern "C" int cir_gemm_bias_act(const void* A, int64_t lda, int64_t strideA, co
     a.bias = bias; a.sBias = strideBias;
     a.R = residual; a.ldr = ldr; a.sR = strideR;
     a.C = C; a.ldc = ldc; a.sC = strideC;
-    a.M = M; a.N = N; a.K = K; a.batch = batch; a.act = act;
+    a.M = M; a.N = N; a.K = K; a.batch = batch; a.act = act; a.group_w = 1;
     a.tiles_m = (int)((M + BM - 1) / BM);
     a.tiles_n = (N + BN - 1) / BN;
     const int64_t nblk = (int64_t)a.tiles_m * a.tiles_n * batch;
@@ -209,12 +209,14 @@ extern "C" int cir_gemm_bias_act(const void* A, int64_t lda, int64_t strideA, co
     // Tile choice: the 256x256 8-phase kernel needs about a full wave of workgroups (256 CUs) to pay;
     // small problems keep the 128x128 kernel (more, smaller tiles).  CIR_GEMM_TILE=128|256 forces one (tests, A/B).
     const int64_t nblk256 = ((M + 255) / 256) * ((N + 255) / 256) * batch;
+    // (the 256 kernel folds the residual into the accumulator: linear epilogues only; 32-bit operand offsets)
     bool use256 = N >= 256 && nblk256 >= 192;
+    const bool can256 = !(residual && act != CIR_ACT_NONE) && (M * lda * 2 < (1LL << 32)) && ((int64_t)N * ldw * 2 < (1LL << 32));
     if (const char* force = getenv("CIR_GEMM_TILE")) {
         if (force[0] == '1') use256 = false;
         else if (force[0] == '2') use256 = true;
     }
-    if (use256) {
+    if (use256 && can256) {
         launch_gemm256(a, in_dtype, f32out, s);
         CIR_LAUNCH_RESULT();
     }

@@ -1,8 +1,14 @@
 // 256x256x64-tile MFMA GEMM for the large shapes of the path (M in the tens of thousands):
 // 8 waves (2 along M x 4 along N), each wave owns 128 x 64 outputs = 128 fp32 accumulators per lane.
+// PERSISTENT: one workgroup per CU walks tiles t, t + grid, ...; the K loop of this path is short
+// (K = 768 -> 12 K-tiles), so the per-tile fixed cost matters as much as the main loop:
+//   * the next tile's first K-tile is requested (LDS-DMA) BEFORE the current tile's epilogue, so its
+//     HBM/L2 latency hides behind the epilogue's VALU work and store issue;
+//   * bias (and, for linear epilogues, the fp32 residual) initialise the accumulators, so the epilogue
+//     itself issues no loads: activation, 16-bit pack, 16-byte stores that drain during the next main loop.
 //
-// Schedule (after the 8-phase structure of the CDNA4 programming guide, re-derived with conservative
-// hazards; see DESIGN.md "GEMM"):
+// Main-loop schedule (after the 8-phase structure of the CDNA4 programming guide, re-derived with
+// conservative hazards; see DESIGN.md "GEMM"):
 //   * LDS holds two K-tiles (dbuf 0/1), each as four 16-KiB half-tiles A0 A1 (activation rows 0-127 /
 //     128-255 of the tile) and B0 B1 (weight rows 0-127 / 128-255); 128 KiB in total, one block per CU.
 //   * a K-tile is consumed in four phases, one 64x32 output quadrant per wave and phase (16 MFMAs):
@@ -18,7 +24,9 @@
 //     first read one phase later, behind a barrier.
 //   * the two wave groups (waves 0-3 / 4-7 = the two waves of each SIMD) run staggered by one barrier,
 //     so one group's MFMA segment overlaps the other group's LDS-read / DMA-issue segment.
-// Operand layout, swizzle, swapped MFMA orientation and epilogue are those of gemm.hip.
+// Operand layout, swizzle and the swapped MFMA orientation are those of gemm.hip.
+#include <stdlib.h>
+
 #include "gemm_args.hpp"
 
 namespace cir {
@@ -37,61 +45,69 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;   // wr doubles as the stagger group (SIMD partners differ in wr)
     const int r15 = lane & 15, g = lane >> 4;
-
-    int id = xcd_remap(blockIdx.x, gridDim.x);
-    const int per_batch = a.tiles_m * a.tiles_n;
-    const int z = id / per_batch;
-    id -= z * per_batch;
-    const int tile_m = id / a.tiles_n, tile_n = id - tile_m * a.tiles_n;
-    const int64_t m0 = (int64_t)tile_m * T256;
-    const int n0 = tile_n * T256;
-
-    const T* A = reinterpret_cast<const T*>(a.A) + z * a.sA;
-    const T* W = reinterpret_cast<const T*>(a.W) + z * a.sW;
-
-    // ---- staging sources: every half-tile is 16 wave-instructions of 8 rows; wave w issues pieces 2w, 2w+1 ----
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;
-    const T* a_src[2][2];
-    const T* w_src[2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int lr = (wave * 2 + j) * 8 + srow;             // LDS row inside the half-tile
-            int64_t gm = m0 + h * 128 + lr;
-            gm = gm < a.M ? gm : a.M - 1;
-            a_src[h][j] = A + gm * a.lda + schunk * 8;
-            // weight rows permuted so that accumulator lane group g owns 8 consecutive features per half
-            const int feat = (lr & ~31) + ((lr & 15) >> 2) * 8 + ((lr >> 4) & 1) * 4 + (lr & 3);
-            int gn = n0 + h * 128 + feat;
-            gn = gn < a.N ? gn : a.N - 1;
-            w_src[h][j] = W + (int64_t)gn * a.ldw + schunk * 8;
-        }
     const int nk = a.K >> 6;
+    const int per_batch = a.tiles_m * a.tiles_n;
+    const int ntiles = per_batch * a.batch;
     char* const stage_base = smem + wave * 2048;
+
+    // ---- per-tile state ----------------------------------------------------------------------------------------
+    int64_t m0 = 0;
+    int n0 = 0, z = 0;
+    const char* A_z = nullptr;   // wave-uniform bases (SGPRs) + 32-bit per-lane byte offsets: 8 VGPRs of addressing
+    const char* W_z = nullptr;
+    unsigned a_off[2][2], w_off[2][2];
+    auto setup = [&](int t) {
+        int id = xcd_remap(t, ntiles);
+        z = id / per_batch;
+        id -= z * per_batch;
+        // column groups of `group_w` weight panels: an XCD's 32 concurrent tiles then share few weight panels
+        // (resident in its 4 MiB L2) and stream the activation panels, each used by group_w tiles at once
+        const int gsz = a.tiles_m * a.group_w;
+        const int grp = id / gsz, rem = id - grp * gsz;
+        const int first_n = grp * a.group_w;
+        const int gw = min(a.group_w, a.tiles_n - first_n);
+        const int tile_m = rem / gw, tile_n = first_n + (rem - tile_m * gw);
+        m0 = (int64_t)tile_m * T256;
+        n0 = tile_n * T256;
+        A_z = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.A) + z * a.sA);
+        W_z = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.W) + z * a.sW);
+        // staging sources: every half-tile is 16 wave-instructions of 8 rows; wave w issues pieces 2w, 2w+1
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int lr = (wave * 2 + j) * 8 + srow;             // LDS row inside the half-tile
+                int64_t gm = m0 + h * 128 + lr;
+                gm = gm < a.M ? gm : a.M - 1;
+                a_off[h][j] = (unsigned)((gm * a.lda + schunk * 8) * 2);
+                // weight rows permuted so that accumulator lane group g owns 8 consecutive features per half
+                const int feat = (lr & ~31) + ((lr & 15) >> 2) * 8 + ((lr >> 4) & 1) * 4 + (lr & 3);
+                int gn = n0 + h * 128 + feat;
+                gn = gn < a.N ? gn : a.N - 1;
+                w_off[h][j] = (unsigned)(((int64_t)gn * a.ldw + schunk * 8) * 2);
+            }
+    };
 
 #define ISSUE_A(H, DB, KT)                                                                                              \
     if ((KT) < nk) {                                                                                                    \
-        __builtin_amdgcn_global_load_lds((gptr_t)(a_src[H][0] + (KT) * 64), (lptr_t)(stage_base + (DB) * kDbuf + (H) * kHalf), 16, 0, 0);        \
-        __builtin_amdgcn_global_load_lds((gptr_t)(a_src[H][1] + (KT) * 64), (lptr_t)(stage_base + (DB) * kDbuf + (H) * kHalf + 1024), 16, 0, 0); \
+        const char* kb_ = A_z + (KT) * 128;                                                                            \
+        __builtin_amdgcn_global_load_lds((gptr_t)(kb_ + a_off[H][0]), (lptr_t)(stage_base + (DB) * kDbuf + (H) * kHalf), 16, 0, 0);        \
+        __builtin_amdgcn_global_load_lds((gptr_t)(kb_ + a_off[H][1]), (lptr_t)(stage_base + (DB) * kDbuf + (H) * kHalf + 1024), 16, 0, 0); \
     }
 #define ISSUE_B(H, DB, KT)                                                                                              \
     if ((KT) < nk) {                                                                                                    \
-        __builtin_amdgcn_global_load_lds((gptr_t)(w_src[H][0] + (KT) * 64), (lptr_t)(stage_base + (DB) * kDbuf + (2 + (H)) * kHalf), 16, 0, 0);        \
-        __builtin_amdgcn_global_load_lds((gptr_t)(w_src[H][1] + (KT) * 64), (lptr_t)(stage_base + (DB) * kDbuf + (2 + (H)) * kHalf + 1024), 16, 0, 0); \
+        const char* kb_ = W_z + (KT) * 128;                                                                            \
+        __builtin_amdgcn_global_load_lds((gptr_t)(kb_ + w_off[H][0]), (lptr_t)(stage_base + (DB) * kDbuf + (2 + (H)) * kHalf), 16, 0, 0);        \
+        __builtin_amdgcn_global_load_lds((gptr_t)(kb_ + w_off[H][1]), (lptr_t)(stage_base + (DB) * kDbuf + (2 + (H)) * kHalf + 1024), 16, 0, 0); \
     }
+    // first K-tile complete in dbuf 0 plus the first two half-tiles of K-tile 1 (what phases 7, 8 would have issued)
+#define ISSUE_PROLOGUE()                                                \
+    ISSUE_A(0, 0, 0) ISSUE_A(1, 0, 0) ISSUE_B(0, 0, 0) ISSUE_B(1, 0, 0) \
+    ISSUE_A(0, 1, 1) ISSUE_B(1, 1, 1)
 
     f32x4 acc[2][4][2][2];  // [m-half][m-tile][n-half][n-tile]
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int l = 0; l < 2; ++l) acc[i][j][k][l] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     const int swz = r15 & 7;
     const int c0 = ((0 + g) ^ swz) << 4, c1 = ((4 + g) ^ swz) << 4;   // 16-byte chunk offsets of the two k-steps
     const char* const a_rd = smem + (wr * 64 + r15) * 128;
@@ -129,106 +145,166 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     if ((NEXT_KT) < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- prologue: tile 0 complete in dbuf 0, first two half-tiles of tile 1 in flight --------------------
-    ISSUE_A(0, 0, 0) ISSUE_A(1, 0, 0) ISSUE_B(0, 0, 0) ISSUE_B(1, 0, 0)
-    ISSUE_A(0, 1, 1) ISSUE_B(1, 1, 1)
-    WAIT_TILE(1)
-    SYNC();
-    if (wr == 1) { SYNC(); }   // stagger: waves 4-7 run one barrier behind waves 0-3
+    const bool res_in_acc = a.R != nullptr;   // linear epilogues only (dispatcher): the residual rides in the accumulator
 
-    const int niter = (nk + 1) >> 1;
-    for (int it = 0; it < niter; ++it) {
-        const int t0 = 2 * it, t1 = t0 + 1;
-        const bool odd = t1 < nk;
-        // ---- K-tile t0 in dbuf 0 -------------------------------------------------------------------------
-        READ_B(0, 0) READ_A(0, 0) ISSUE_A(1, 1, t1)                      COMPUTE(true, 0, 0)   // phase 1
-        READ_B(1, 0)              ISSUE_B(0, 1, t1)                      COMPUTE(true, 0, 1)   // phase 2
-        READ_A(1, 0)              ISSUE_A(0, 0, t0 + 2)                  COMPUTE(true, 1, 1)   // phase 3
-        READ_B(0, 0)              ISSUE_B(1, 0, t0 + 2) WAIT_TILE(t0 + 2) COMPUTE(true, 1, 0)  // phase 4
-        // ---- K-tile t1 in dbuf 1 -------------------------------------------------------------------------
-        if (odd) { READ_B(0, 1) READ_A(0, 1) }
-        ISSUE_A(1, 0, t0 + 2)                                            COMPUTE(odd, 0, 0)    // phase 5
-        if (odd) { READ_B(1, 1) }
-        ISSUE_B(0, 0, t0 + 2)                                            COMPUTE(odd, 0, 1)    // phase 6
-        if (odd) { READ_A(1, 1) }
-        ISSUE_A(0, 1, t1 + 2)                                            COMPUTE(odd, 1, 1)    // phase 7
-        if (odd) { READ_B(0, 1) }
-        ISSUE_B(1, 1, t1 + 2) WAIT_TILE(t1 + 2)                          COMPUTE(odd, 1, 0)    // phase 8
+    int t = blockIdx.x;
+    setup(t);
+    ISSUE_PROLOGUE()
+
+    for (;;) {
+        const int64_t cm0 = m0;
+        const int cn0 = n0, cz = z;
+        // ---- accumulators start at bias (+ residual): the epilogue then needs no loads --------------------------
+        {
+            float bias[2][8];
+            bool n_ok[2];
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+                const int nb = cn0 + nh * 128 + wc * 32 + g * 8;
+                n_ok[nh] = nb + 8 <= a.N;
+                if (a.bias != nullptr && n_ok[nh]) {
+                    const float4* bp = reinterpret_cast<const float4*>(a.bias + cz * a.sBias + nb);
+                    const float4 b0 = bp[0], b1 = bp[1];
+                    bias[nh][0] = b0.x; bias[nh][1] = b0.y; bias[nh][2] = b0.z; bias[nh][3] = b0.w;
+                    bias[nh][4] = b1.x; bias[nh][5] = b1.y; bias[nh][6] = b1.z; bias[nh][7] = b1.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) bias[nh][q] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    const int64_t m = cm0 + mh * 128 + wr * 64 + mi * 16 + r15;
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh) {
+                        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+                        if (res_in_acc && m < a.M && n_ok[nh]) {
+                            const float4* rp = reinterpret_cast<const float4*>(a.R + cz * a.sR + m * a.ldr + cn0 + nh * 128 + wc * 32 + g * 8);
+                            r0 = rp[0];
+                            r1 = rp[1];
+                        }
+                        acc[mh][mi][nh][0] = f32x4{bias[nh][0] + r0.x, bias[nh][1] + r0.y, bias[nh][2] + r0.z, bias[nh][3] + r0.w};
+                        acc[mh][mi][nh][1] = f32x4{bias[nh][4] + r1.x, bias[nh][5] + r1.y, bias[nh][6] + r1.z, bias[nh][7] + r1.w};
+                    }
+                }
+            // materialise every accumulator now, so the compiler's own wait for these loads sits here (once per
+            // tile) and not in front of the first MFMA of each phase inside the K loop
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh) {
+                        asm volatile("" : "+v"(acc[mh][mi][nh][0]), "+v"(acc[mh][mi][nh][1]));
+                    }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // prologue half-tiles landed (and the previous tile's stores)
+        SYNC();
+        if (wr == 1) { SYNC(); }   // stagger: waves 4-7 run one barrier behind waves 0-3
+
+        const int niter = (nk + 1) >> 1;
+        for (int it = 0; it < niter; ++it) {
+            const int t0 = 2 * it, t1 = t0 + 1;
+            const bool odd = t1 < nk;
+            // ---- K-tile t0 in dbuf 0 ---------------------------------------------------------------------------
+            READ_B(0, 0) READ_A(0, 0) ISSUE_A(1, 1, t1)                      COMPUTE(true, 0, 0)   // phase 1
+            READ_B(1, 0)              ISSUE_B(0, 1, t1)                      COMPUTE(true, 0, 1)   // phase 2
+            READ_A(1, 0)              ISSUE_A(0, 0, t0 + 2)                  COMPUTE(true, 1, 1)   // phase 3
+            READ_B(0, 0)              ISSUE_B(1, 0, t0 + 2) WAIT_TILE(t0 + 2) COMPUTE(true, 1, 0)  // phase 4
+            // ---- K-tile t1 in dbuf 1 ---------------------------------------------------------------------------
+            if (odd) { READ_B(0, 1) READ_A(0, 1) }
+            ISSUE_A(1, 0, t0 + 2)                                            COMPUTE(odd, 0, 0)    // phase 5
+            if (odd) { READ_B(1, 1) }
+            ISSUE_B(0, 0, t0 + 2)                                            COMPUTE(odd, 0, 1)    // phase 6
+            if (odd) { READ_A(1, 1) }
+            ISSUE_A(0, 1, t1 + 2)                                            COMPUTE(odd, 1, 1)    // phase 7
+            if (odd) { READ_B(0, 1) }
+            ISSUE_B(1, 1, t1 + 2) WAIT_TILE(t1 + 2)                          COMPUTE(odd, 1, 0)    // phase 8
+        }
+        if (wr == 0) { SYNC(); }   // pair the trailing barrier of the staggered group: all LDS reads of this tile are done
+
+        // ---- request the next tile's first K-tile before this tile's epilogue ----------------------------------------
+        const int tn = t + (int)gridDim.x;
+        const bool more = tn < ntiles;
+        if (more) {
+            setup(tn);
+            ISSUE_PROLOGUE()
+        }
+
+        // ---- epilogue: lane (r15, g) owns rows cm0 + mh*128 + wr*64 + mi*16 + r15, features nb(nh) .. nb+7 -----------
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int64_t m = cm0 + mh * 128 + wr * 64 + mi * 16 + r15;
+                if (m >= a.M) continue;
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    const int nb = cn0 + nh * 128 + wc * 32 + g * 8;
+                    if (nb + 8 > a.N) continue;
+                    float v[8];
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) v[ni * 4 + jj] = acc[mh][mi][nh][ni][jj];
+                    if (a.act == CIR_ACT_GELU) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = gelu_erf(v[q]);
+                    } else if (a.act == CIR_ACT_RELU) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+                    }
+                    if constexpr (OUT_F32) {
+                        float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + cz * a.sC + m * a.ldc + nb);
+                        cp[0] = make_float4(v[0], v[1], v[2], v[3]);
+                        cp[1] = make_float4(v[4], v[5], v[6], v[7]);
+                    } else {
+                        u32x4 o;
+                        o.x = pack2<T>(v[0], v[1]); o.y = pack2<T>(v[2], v[3]); o.z = pack2<T>(v[4], v[5]); o.w = pack2<T>(v[6], v[7]);
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.C) + cz * a.sC + m * a.ldc + nb) = o;
+                    }
+                }
+            }
+        if (!more) break;
+        t = tn;
     }
-    if (wr == 0) { SYNC(); }   // pair the trailing barrier of the staggered group
 #undef ISSUE_A
 #undef ISSUE_B
+#undef ISSUE_PROLOGUE
 #undef READ_A
 #undef READ_B
 #undef MMA
 #undef SYNC
 #undef COMPUTE
 #undef WAIT_TILE
+}
 
-    // ---- epilogue: lane (r15, g) owns rows m0 + mh*128 + wr*64 + mi*16 + r15, features nb(nh) .. nb+7 ---------
-    float bias[2][8];
-    bool n_ok[2];
-#pragma unroll
-    for (int nh = 0; nh < 2; ++nh) {
-        const int nb = n0 + nh * 128 + wc * 32 + g * 8;
-        n_ok[nh] = nb + 8 <= a.N;
-        if (a.bias != nullptr && n_ok[nh]) {
-            const float4* bp = reinterpret_cast<const float4*>(a.bias + z * a.sBias + nb);
-            const float4 b0 = bp[0], b1 = bp[1];
-            bias[nh][0] = b0.x; bias[nh][1] = b0.y; bias[nh][2] = b0.z; bias[nh][3] = b0.w;
-            bias[nh][4] = b1.x; bias[nh][5] = b1.y; bias[nh][6] = b1.z; bias[nh][7] = b1.w;
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) bias[nh][q] = 0.f;
-        }
+static int persistent_grid() {
+    static int cus = 0;   // lazily read device constant (number of CUs); the only state this library keeps
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 256;
     }
-    const float* R = a.R ? a.R + z * a.sR : nullptr;
-#pragma unroll
-    for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int64_t m = m0 + mh * 128 + wr * 64 + mi * 16 + r15;
-            if (m >= a.M) continue;
-#pragma unroll
-            for (int nh = 0; nh < 2; ++nh) {
-                if (!n_ok[nh]) continue;
-                const int nb = n0 + nh * 128 + wc * 32 + g * 8;
-                float v[8];
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) v[ni * 4 + jj] = acc[mh][mi][nh][ni][jj] + bias[nh][ni * 4 + jj];
-                if (a.act == CIR_ACT_GELU) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = gelu_erf(v[q]);
-                } else if (a.act == CIR_ACT_RELU) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
-                }
-                if (R != nullptr) {
-                    const float4* rp = reinterpret_cast<const float4*>(R + m * a.ldr + nb);
-                    const float4 r0 = rp[0], r1 = rp[1];
-                    v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-                    v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-                }
-                if constexpr (OUT_F32) {
-                    float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + z * a.sC + m * a.ldc + nb);
-                    cp[0] = make_float4(v[0], v[1], v[2], v[3]);
-                    cp[1] = make_float4(v[4], v[5], v[6], v[7]);
-                } else {
-                    u32x4 o;
-                    o.x = pack2<T>(v[0], v[1]); o.y = pack2<T>(v[2], v[3]); o.z = pack2<T>(v[4], v[5]); o.w = pack2<T>(v[6], v[7]);
-                    *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.C) + z * a.sC + m * a.ldc + nb) = o;
-                }
-            }
-        }
+    return cus;
 }
 
 void launch_gemm256(const GemmArgs& a_in, int in_dtype, bool f32out, hipStream_t s) {
     GemmArgs a = a_in;
     a.tiles_m = (int)((a.M + T256 - 1) / T256);
     a.tiles_n = (a.N + T256 - 1) / T256;
-    dim3 grid((unsigned)((int64_t)a.tiles_m * a.tiles_n * a.batch)), block(512);
+    const int64_t ntiles = (int64_t)a.tiles_m * a.tiles_n * a.batch;
+    // widest divisor of tiles_n whose weight panels (256 x K 16-bit each) fit in ~2 MiB of an XCD's L2
+    const int64_t panel = 256LL * a.K * 2;
+    int gw = 1;
+    for (int d = 1; d <= a.tiles_n; ++d)
+        if (a.tiles_n % d == 0 && d * panel <= (2LL << 20)) gw = d;
+    if (const char* e = getenv("CIR_GEMM_GW")) { const int v = atoi(e); if (v > 0) gw = v < a.tiles_n ? v : a.tiles_n; }
+    a.group_w = gw;
+    const int64_t g = persistent_grid();
+    dim3 grid((unsigned)(ntiles < g ? ntiles : g)), block(512);
     if (in_dtype == CIR_BF16) {
         if (f32out) hipLaunchKernelGGL((gemm256_kernel<__bf16, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((gemm256_kernel<__bf16, false>), grid, block, 0, s, a);

@@ -11,6 +11,7 @@ struct GemmArgs {
     const float* R; int64_t ldr, sR;
     void* C; int64_t ldc, sC;
     int64_t M; int N, K, batch, act, tiles_m, tiles_n;
+    int group_w;   // gemm256: tiles are walked in column groups of this many n-panels (weights stay L2-resident)
 };
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
