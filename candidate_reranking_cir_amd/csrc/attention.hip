@@ -1,7 +1,7 @@
-// cir_attention: softmax(q k^T * scale + mask) v for head_dim 64, one wave per (item, head, 32 queries).
+// cir_attention: softmax(q k^T * scale + mask) v for head_dim 64, one wave per 32 queries.
 //
-// Bound: MFMA in principle (4*Lq*Lk*64 flop per head), VALU (exp/rescale) in practice at these tiny
-// extents; the path spends < 5 % of its flops here.
+// Bound: MFMA in principle (4*Lq*Lk*64 flop per head), VALU (exp / rescale) and operand delivery in
+// practice at these small extents; the path spends < 5 % of its flops here.
 //
 // Formulation ("keys on rows"): with the 32x32x16 MFMA the score tile is computed TRANSPOSED,
 //   S^T[key][query] = K_tile * Q^T,
@@ -10,9 +10,17 @@
 // has the register layout of the B operand of the second product
 //   O^T[dh][query] += V_tile^T * P^T,
 // (accumulator-as-operand, no LDS round trip for P).  V^T fragments come from a row-major LDS copy
-// of the V tile through ds_read_b64_tr_b16 (hardware transpose).  Q and K fragments are 16-byte
-// vectors straight from global memory (a head's row slice is one 128-byte line).
-// Ragged extents: rows beyond Lq / Lk are clamped on load; scores of keys >= Lk are set to -inf.
+// of V through ds_read_b64_tr_b16 (hardware transpose).
+//
+// Two kernels share that tile update:
+//   * attn_shared_kernel - one workgroup per (item, head); the head's whole K and V (Lk <= 256 keys, 64 KiB)
+//     are staged ONCE into LDS (bank-swizzled) and every 32-query wave of the workgroup reads them from
+//     there: the ViT case (197 x 197), where 7 query tiles would otherwise each re-read K/V from L2.
+//   * attn_stream_kernel - one wave per (item, head, 32 queries), K straight from global memory into
+//     MFMA fragments, V through a private 4-KiB LDS tile, next tile prefetched into registers while the
+//     current one is processed: the text-side cases (32 x 32 self-attention, 32 x 197 / 32 x 577
+//     cross-attention) where nothing is shared between waves, and any Lk > 256.
+// Ragged extents: rows beyond Lq / Lk are clamped or zero-filled on load; scores of keys >= Lk are -inf.
 #include "common.hpp"
 
 namespace cir {
@@ -29,9 +37,188 @@ struct AttnArgs {
 };
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+constexpr float kLog2e = 1.4426950408889634f;
+
+// Online-softmax state of one 32-query tile: lane = (query r, key/dh half hh).
+struct Softmax {
+    float m_run, l_run;
+    f32x16 o[2];
+    __device__ __forceinline__ void init() {
+        m_run = -INFINITY;
+        l_run = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+    }
+};
+
+// scores (already in the log2 domain) -> probabilities, running max / sum, rescale of O; returns P^T packed
+template <typename T>
+__device__ __forceinline__ void softmax_tile(Softmax& st, f32x16& s, float sl, const float* mp, int key0, int hh, int Lk,
+                                             typename Elem<T>::x8 (&pf)[2]) {
+    float sv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sv[i] = s[i] * sl;
+    if (mp != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            // clamp keeps finfo.min-style masks finite in the log2 domain (all-masked rows stay uniform, like the reference)
+            sv[i] = fmaf(fmaxf(mp[min(key, Lk - 1)], -2.0e38f), kLog2e, sv[i]);
+        }
+    }
+    if (key0 + 32 > Lk) {   // wave-uniform: only the last key tile is ragged
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            sv[i] = key < Lk ? sv[i] : -INFINITY;
+        }
+    }
+    float mx = fmaxf(fmaxf(sv[0], sv[1]), sv[2]);
+#pragma unroll
+    for (int i = 3; i < 15; i += 2) mx = fmaxf(fmaxf(mx, sv[i]), sv[i + 1]);
+    mx = fmaxf(mx, sv[15]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(st.m_run, mx);     // finite: every tile holds at least one valid key
+    if (!__all(m_new == st.m_run)) {             // skip the O-wide rescale when no row maximum moved
+        const float alpha = __builtin_amdgcn_exp2f(st.m_run - m_new);
+        st.l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { st.o[0][i] *= alpha; st.o[1][i] *= alpha; }
+        st.m_run = m_new;
+    }
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float p = __builtin_amdgcn_exp2f(sv[i] - st.m_run);
+        sv[i] = p;
+        psum += p;
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    st.l_run += psum;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[s2][j] = static_cast<T>(sv[8 * s2 + j]);
+}
+
+// O^T += V_tile^T * P^T with V row-major in LDS at `vt` (128-byte rows, 64-byte halves swapped on rows with
+// bit 1 set so that the 4-row transposed reads of a 32-lane half hit 64 distinct banks)
+template <typename T>
+__device__ __forceinline__ void pv_tile(Softmax& st, const char* vt, int tr_lane_off, const typename Elem<T>::x8 (&pf)[2]) {
+    using X8 = typename Elem<T>::x8;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const char* base = vt + (16 * s2) * 128 + ((tr_lane_off & 0x7f) ^ (dt * 64)) + (tr_lane_off & ~0x7f);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + 8 * 128));
+            s16x8 both;
+            both.s0 = lo.x; both.s1 = lo.y; both.s2 = lo.z; both.s3 = lo.w;
+            both.s4 = hi.x; both.s5 = hi.y; both.s6 = hi.z; both.s7 = hi.w;
+            st.o[dt] = Elem<T>::mfma32(__builtin_bit_cast(X8, both), pf[s2], st.o[dt]);
+        }
+    }
+}
+
+// this lane's address inside a 4-key x 16-dh transposed-read block (without the dh-tile term):
+// row (4*hh + q), byte column (16*(G&1) + 4p)*2, halves swapped when the row's bit 1 is set (row = 4*hh' + q, q>>1)
+__device__ __forceinline__ int tr_lane_offset(int lane) {
+    const int i16 = lane & 15, hh = lane >> 5;
+    const int q = i16 >> 2, p = i16 & 3;
+    const int col = ((16 * ((lane >> 4) & 1) + 4 * p) * 2) ^ ((q >> 1) << 6);
+    return (4 * hh + q) * 128 + col;
+}
 
 template <typename T>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
+__device__ __forceinline__ void store_out(const Softmax& st, T* op /* row base + h*64 + 4*hh */) {
+    const float inv = 1.0f / st.l_run;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            u32x2 p;
+            p.x = pack2<T>(st.o[dt][qd * 4 + 0] * inv, st.o[dt][qd * 4 + 1] * inv);
+            p.y = pack2<T>(st.o[dt][qd * 4 + 2] * inv, st.o[dt][qd * 4 + 3] * inv);
+            *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * qd) = p;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(512) void attn_shared_kernel(const AttnArgs a, int lk_pad) {
+    using X8 = typename Elem<T>::x8;
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    char* Ks = dyn;
+    char* Vs = dyn + lk_pad * 128;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    int64_t t = blockIdx.x;
+    const int h = (int)(t % a.H);
+    t /= a.H;
+    const int b0 = (int)(t % a.B0);
+    const int64_t b1 = t / a.B0;
+    const T* kb = reinterpret_cast<const T*>(a.k) + b1 * a.k_s1 + b0 * a.k_s0 + h * 64;
+    const T* vb = reinterpret_cast<const T*>(a.v) + b1 * a.v_s1 + b0 * a.v_s0 + h * 64;
+    const float* mp = a.mask ? a.mask + b1 * a.m_s1 + b0 * a.m_s0 : nullptr;
+
+    // ---- stage K (chunk ^ ((row>>1)&7): conflict-free 32x32x16 A-operand reads) and V (halves swapped on bit 1) ----
+    for (int c = threadIdx.x; c < lk_pad * 8; c += blockDim.x) {
+        const int row = c >> 3, ch = c & 7;
+        X8 kv, vv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { kv[j] = static_cast<T>(0.f); vv[j] = static_cast<T>(0.f); }
+        if (row < a.Lk) {
+            kv = *reinterpret_cast<const X8*>(kb + (int64_t)row * a.k_rs + ch * 8);
+            vv = *reinterpret_cast<const X8*>(vb + (int64_t)row * a.v_rs + ch * 8);
+        }
+        *reinterpret_cast<X8*>(Ks + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = kv;
+        *reinterpret_cast<X8*>(Vs + row * 128 + ((ch * 16) ^ (((row >> 1) & 1) << 6))) = vv;
+    }
+    __syncthreads();
+
+    const int r = lane & 31, hh = lane >> 5;
+    const int tr_off = tr_lane_offset(lane);
+    const float sl = a.scale * kLog2e;
+    const int nkt = (a.Lk + 31) >> 5;
+    for (int qt = wave; qt < a.nqt; qt += nwaves) {
+        const int q0 = qt * 32;
+        const int qrow = min(q0 + r, a.Lq - 1);
+        const T* qp = reinterpret_cast<const T*>(a.q) + b1 * a.q_s1 + b0 * a.q_s0 + (int64_t)qrow * a.q_rs + h * 64 + 8 * hh;
+        X8 qf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const X8*>(qp + 16 * s);
+        Softmax st;
+        st.init();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int key0 = kt * 32;
+            const int row = key0 + r;
+            const char* krow = Ks + row * 128;
+            const int ksw = (row >> 1) & 7;
+            f32x16 s;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx) {
+                const X8 kf = *reinterpret_cast<const X8*>(krow + (((2 * sx + hh) ^ ksw) << 4));
+                s = Elem<T>::mfma32(kf, qf[sx], s);
+            }
+            X8 pf[2];
+            softmax_tile<T>(st, s, sl, mp, key0, hh, a.Lk, pf);
+            pv_tile<T>(st, Vs + key0 * 128, tr_off, pf);
+        }
+        if (q0 + r < a.Lq) {
+            T* op = reinterpret_cast<T*>(a.out) + b1 * a.o_s1 + b0 * a.o_s0 + (int64_t)(q0 + r) * a.o_rs + h * 64 + 4 * hh;
+            store_out<T>(st, op);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_stream_kernel(const AttnArgs a) {
     using X8 = typename Elem<T>::x8;
     __shared__ __attribute__((aligned(16))) char smem[4 * 4096];  // one 32-key x 64-dh V tile per wave
 
@@ -50,9 +237,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
     const int r = lane & 31, hh = lane >> 5;
     const int q0 = qt * 32;
     const int qrow = min(q0 + r, a.Lq - 1);
-
     const T* qp = reinterpret_cast<const T*>(a.q) + b1 * a.q_s1 + b0 * a.q_s0 + (int64_t)qrow * a.q_rs + h * 64 + 8 * hh;
-    const T* kb = reinterpret_cast<const T*>(a.k) + b1 * a.k_s1 + b0 * a.k_s0 + h * 64;
+    const T* kb = reinterpret_cast<const T*>(a.k) + b1 * a.k_s1 + b0 * a.k_s0 + h * 64 + 8 * hh;
     const T* vb = reinterpret_cast<const T*>(a.v) + b1 * a.v_s1 + b0 * a.v_s0 + h * 64;
     const float* mp = a.mask ? a.mask + b1 * a.m_s1 + b0 * a.m_s0 : nullptr;
 
@@ -60,106 +246,53 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const X8*>(qp + 16 * s);
 
-    constexpr float kLog2e = 1.4426950408889634f;
-    float m_run = -INFINITY, l_run = 0.f;
-    f32x16 o[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
-
     char* vl = smem + wave * 4096;
-    const int i16 = lane & 15;
-    // transposed-read address of this lane inside a 4-key x 16-dh block: row (i16>>2), 4 columns at (i16&3)*4
-    const int tr_lane_off = (4 * hh + (i16 >> 2)) * 128 + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2;
-
+    const int tr_off = tr_lane_offset(lane);
+    const float sl = a.scale * kLog2e;
     const int nkt = (a.Lk + 31) >> 5;
-    for (int kt = 0; kt < nkt; ++kt) {
+    // V staging: lane covers 16-byte chunks c = lane + 64 i -> row c>>3, chunk c&7 (rows clamped: probability 0 there)
+    const int vrow_l = lane >> 3, vch = lane & 7;
+
+    auto load_tile = [&](int kt, X8 (&kf)[4], X8 (&vr)[4]) {
         const int key0 = kt * 32;
-        const int krow = min(key0 + r, a.Lk - 1);
-        const T* kp = kb + (int64_t)krow * a.k_rs + 8 * hh;
-        X8 kf[4];
+        const T* kp = kb + (int64_t)min(key0 + r, a.Lk - 1) * a.k_rs;
 #pragma unroll
         for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const X8*>(kp + 16 * s);
-        X8 vreg[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int c = lane + 64 * i;
-            const int vrow = min(key0 + (c >> 3), a.Lk - 1);  // clamped rows get probability 0
-            vreg[i] = *reinterpret_cast<const X8*>(vb + (int64_t)vrow * a.v_rs + (c & 7) * 8);
+            const int vrow = min(key0 + vrow_l + 8 * i, a.Lk - 1);
+            vr[i] = *reinterpret_cast<const X8*>(vb + (int64_t)vrow * a.v_rs + vch * 8);
         }
+    };
 
+    Softmax st;
+    st.init();
+    X8 kf[4], vr[4];
+    load_tile(0, kf, vr);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int key0 = kt * 32;
         f32x16 s;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = 0.f;
 #pragma unroll
-        for (int st = 0; st < 4; ++st) s = Elem<T>::mfma32(kf[st], qf[st], s);
-
-        float sv[16];
-        float mx = -INFINITY;
+        for (int sx = 0; sx < 4; ++sx) s = Elem<T>::mfma32(kf[sx], qf[sx], s);
+        // V tile -> this wave's LDS tile (same row / half swizzle as the shared kernel)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            float val = s[i] * a.scale;
-            if (mp) val += mp[min(key, a.Lk - 1)];
-            val = key < a.Lk ? val : -INFINITY;
-            sv[i] = val;
-            mx = fmaxf(mx, val);
+        for (int i = 0; i < 4; ++i) {
+            const int row = vrow_l + 8 * i;
+            *reinterpret_cast<X8*>(vl + row * 128 + ((vch * 16) ^ (((row >> 1) & 1) << 6))) = vr[i];
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);  // finite: every tile holds at least one valid key
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
-        float psum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float p = __builtin_amdgcn_exp2f((sv[i] - m_new) * kLog2e);
-            sv[i] = p;
-            psum += p;
-        }
-        psum += __shfl_xor(psum, 32, 64);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-
+        if (kt + 1 < nkt) load_tile(kt + 1, kf, vr);   // prefetch the next tile under this tile's softmax / PV
         X8 pf[2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pf[s2][j] = static_cast<T>(sv[8 * s2 + j]);
-
-        // stage V row-major in this wave's LDS tile (lane-linear 16-byte writes)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<X8*>(vl + (lane + 64 * i) * 16) = vreg[i];
+        softmax_tile<T>(st, s, sl, mp, key0, hh, a.Lk, pf);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const char* base = vl + tr_lane_off + (16 * s2) * 128 + dt * 64;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + 8 * 128));
-                s16x8 both;
-                both.s0 = lo.x; both.s1 = lo.y; both.s2 = lo.z; both.s3 = lo.w;
-                both.s4 = hi.x; both.s5 = hi.y; both.s6 = hi.z; both.s7 = hi.w;
-                o[dt] = Elem<T>::mfma32(__builtin_bit_cast(X8, both), pf[s2], o[dt]);
-            }
-        }
+        pv_tile<T>(st, vl, tr_off, pf);
         __builtin_amdgcn_wave_barrier();  // keep the next tile's LDS writes behind these reads
     }
-
     if (q0 + r < a.Lq) {
-        const float inv = 1.0f / l_run;
         T* op = reinterpret_cast<T*>(a.out) + b1 * a.o_s1 + b0 * a.o_s0 + (int64_t)(q0 + r) * a.o_rs + h * 64 + 4 * hh;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                u32x2 p;
-                p.x = pack2<T>(o[dt][qd * 4 + 0] * inv, o[dt][qd * 4 + 1] * inv);
-                p.y = pack2<T>(o[dt][qd * 4 + 2] * inv, o[dt][qd * 4 + 3] * inv);
-                *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * qd) = p;
-            }
+        store_out<T>(st, op);
     }
 }
 
@@ -187,11 +320,24 @@ extern "C" int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t 
     a.B0 = B0; a.H = H; a.Lq = Lq; a.Lk = Lk; a.nqt = (Lq + 31) / 32;
     a.total = (int64_t)B1 * B0 * H * a.nqt;
     a.scale = scale;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int lk_pad = (Lk + 31) & ~31;
+    // K/V of a head are shared by its query tiles: stage them once per workgroup when there are several tiles
+    const bool shared = a.nqt >= 2 && lk_pad <= 256;
+    if (shared) {
+        const int64_t nblk = (int64_t)B1 * B0 * H;
+        if (nblk > 0x7fffffff) return CIR_ESHAPE;
+        const int waves = a.nqt < 8 ? a.nqt : 8;
+        dim3 grid((unsigned)nblk), block(waves * 64);
+        const size_t lds = (size_t)lk_pad * 256;
+        if (dtype == CIR_BF16) hipLaunchKernelGGL((attn_shared_kernel<__bf16>), grid, block, lds, s, a, lk_pad);
+        else hipLaunchKernelGGL((attn_shared_kernel<_Float16>), grid, block, lds, s, a, lk_pad);
+        CIR_LAUNCH_RESULT();
+    }
     const int64_t nblk = (a.total + 3) / 4;
     if (nblk > 0x7fffffff) return CIR_ESHAPE;
     dim3 grid((unsigned)nblk), block(256);
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == CIR_BF16) hipLaunchKernelGGL((attn_kernel<__bf16>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((attn_kernel<_Float16>), grid, block, 0, s, a);
+    if (dtype == CIR_BF16) hipLaunchKernelGGL((attn_stream_kernel<__bf16>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((attn_stream_kernel<_Float16>), grid, block, 0, s, a);
     CIR_LAUNCH_RESULT();
 }
