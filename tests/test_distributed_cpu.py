@@ -1,0 +1,73 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard the queries, score their block with a stand-in
+scorer and all-gather; the result must equal the single-process matrix (incl. skip rows and padding)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from candidate_reranking_cir_amd import distributed as D
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _fake_scores(rows, k, active):
+    """Deterministic stand-in for the GPU scorer: depends only on (query, candidate)."""
+    out = torch.full((len(rows), k), D.SKIP_FILL)
+    for i, q in enumerate(rows):
+        if active[q]:
+            out[i] = torch.sin(torch.arange(k, dtype=torch.float32) * 0.37 + q)
+    return out
+
+
+def _worker(rank, world, port, n_q, k, active, use_balance, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        order = D.balanced_order(active) if use_balance else None
+        full = D.sharded_scores(lambda rows: _fake_scores(rows, k, active), n_q, k, torch.device("cpu"), order)
+        ret[rank] = full.numpy()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_q,use_balance", [(7, False), (8, True), (1, False), (13, True)])
+def test_two_rank_gather_equals_single_process(n_q, use_balance):
+    k = 5
+    rng = np.random.RandomState(n_q)
+    active = (rng.rand(n_q) > 0.3).tolist()
+    expect = _fake_scores(list(range(n_q)), k, active).numpy()
+    world = 2
+    ret = mp.Manager().dict()
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_q, k, active, use_balance, ret), nprocs=world, join=True)
+    for r in range(world):
+        np.testing.assert_array_equal(ret[r], expect)
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 8, 4181):
+        for world in (1, 2, 8):
+            seen = []
+            for r in range(world):
+                lo, hi, per = D.shard_bounds(n, r, world)
+                assert hi - lo <= per
+                seen += list(range(lo, hi))
+            assert seen == list(range(n))
+
+
+def test_balanced_order_is_a_permutation_and_balances():
+    rng = np.random.RandomState(0)
+    active = (rng.rand(4181) > 0.17).tolist()
+    order = D.balanced_order(active)
+    assert sorted(order) == list(range(len(active)))
+    per = -(-len(active) // 8)
+    loads = [sum(active[i] for i in order[r * per:(r + 1) * per]) for r in range(8)]
+    assert max(loads) - min(loads) <= 2

@@ -1,0 +1,76 @@
+"""Host-side logic that needs no GPU: metric code against the reference's own metric arithmetic
+(tests/golden/metrics.npz), caption joining, tokenizer double, state-dict layout, config loader."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from candidate_reranking_cir_amd import config, synthetic, weights
+from candidate_reranking_cir_amd import validate_stage2 as V
+from tests import helpers as H
+
+
+def test_recall_metrics_match_reference_arithmetic():
+    m = H.load("metrics.npz")
+    ds = V.RelativeValSet(ref_index=np.zeros(len(m["labels"]), dtype=int), cand_index=np.zeros_like(m["labels"], dtype=int),
+                          labels=m["labels"], group_index=m["group_members"], target_index=m["targets"])
+    logits, glogits = torch.tensor(m["logits"]), torch.tensor(m["group_logits"])
+    np.testing.assert_allclose(V.compute_fiq_val_metrics(logits, ds), m["fiq_metrics"], atol=1e-4)
+    np.testing.assert_allclose(V.compute_cirr_val_metrics(logits, glogits, ds), m["cirr_metrics"], atol=1e-4)
+
+
+def test_fiq_caption_rule():
+    assert V.fiq_caption("is red.", "  has long sleeves?") == "Is red and has long sleeves"
+    z = H.load("tiny_loop.npz")
+    for a, b in z["fiq_caps"]:
+        assert V.fiq_caption(str(a), str(b)) == H.fiq_caption((a, b))
+
+
+def test_hash_tokenizer_padding_and_enc_token():
+    tok = synthetic.HashTokenizer()
+    enc = tok(["a b c", "a"], padding="longest", return_tensors="pt")
+    assert enc.input_ids.shape == (2, 5) and enc.attention_mask.tolist() == [[1, 1, 1, 1, 1], [1, 1, 1, 0, 0]]
+    assert enc.input_ids[0, 0] == 101 and enc.input_ids[0, -1] == 102 and enc.input_ids[1, 3] == 0
+    assert enc.input_ids[0, 1] == enc.input_ids[1, 1]                 # same word -> same id
+    assert tok.enc_token_id == 30523
+
+
+def test_state_dict_layout_matches_reference_counts():
+    g, v = config.BertGeometry(), config.VitGeometry.named("base", 384)
+    s2, s1 = weights.nlvr_param_spec(g, v), weights.retrieval_param_spec(g, v)
+    assert len(s2) == 723 and len(s1) == 472                           # SURVEY.md section 8(b) [probe]
+    n2 = sum(int(np.prod(sh)) for k, (sh, kind) in s2.items() if kind != "position_ids")
+    n1 = sum(int(np.prod(sh)) for k, (sh, kind) in s1.items() if kind != "position_ids")
+    assert abs(n2 / 1e6 - 288.06) < 0.4 and abs(n1 / 1e6 - 223.45) < 0.4
+    assert s2["visual_encoder.pos_embed"][0] == (1, 577, 768)
+    assert "text_encoder.encoder.layer.6.crossattention.output.merge_layer.weight" in s2
+    assert "text_encoder.encoder.layer.5.crossattention.output.merge_layer.weight" not in s2
+
+
+def test_med_config_loader_and_factories(tmp_path):
+    from candidate_reranking_cir_amd.blip_stage2 import load_bert_geometry
+    g = load_bert_geometry("configs/med_config.json")                   # the reference's default path
+    assert (g.hidden_size, g.num_attention_heads, g.num_hidden_layers, g.intermediate_size, g.vocab_size) == (768, 12, 12, 3072, 30524)
+    assert g.layer_norm_eps == 1e-12
+    bad = tmp_path / "bad.json"
+    bad.write_text(json.dumps(dict(hidden_size=768, num_attention_heads=8)))
+    with pytest.raises(ValueError, match="head_dim"):
+        load_bert_geometry(str(bad))
+    with pytest.raises(AssertionError):
+        config.VitGeometry.named("huge", 224)
+
+
+def test_synth_weights_are_deterministic_by_name():
+    a = weights.synth_tensor("cls_head.0.weight", (4, 8), "weight", seed=3)
+    b = weights.synth_tensor("cls_head.0.weight", (4, 8), "weight", seed=3)
+    c = weights.synth_tensor("cls_head.2.weight", (4, 8), "weight", seed=3)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+def test_length_buckets_never_pad():
+    caps = ["a b c", "d e", "f g h", "i"]
+    ds = V.RelativeValSet(ref_index=np.zeros(4, dtype=int), cand_index=np.zeros((4, 2), dtype=int), labels=np.ones((4, 2), dtype=bool), captions=caps)
+    buckets = V._length_buckets(ds, synthetic.HashTokenizer(), range(4))
+    assert buckets == {5: [0, 2], 4: [1], 3: [3]}
