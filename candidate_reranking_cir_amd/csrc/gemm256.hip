@@ -13,11 +13,12 @@
 //     128-255 of the tile) and B0 B1 (weight rows 0-127 / 128-255); 128 KiB in total, one block per CU.
 //   * a K-tile is consumed in four phases, one 64x32 output quadrant per wave and phase (16 MFMAs):
 //       q0 = (A0,B0)  reads B0 then A0 (12 ds_read_b128)      q1 = (A0,B1)  reads B1 (4)
-//       q2 = (A1,B1)  reads A1 (8)                             q3 = (A1,B0)  reads B0 (4)
+//       q2 = (A1,B1)  reads A1 (8)                             q3 = (A1,B0)  reads nothing (B0 fragments kept)
 //   * every phase also issues ONE half-tile refill by LDS-DMA (2 x global_load_lds_dwordx4 per lane),
-//     always into a half-tile whose last read lies two phases back:
+//     always into a half-tile whose last read lies at least two phases back, and at least five phases
+//     (~1.25 K-tiles, ~2 us) ahead of its first use, so an HBM-latency miss is still hidden:
 //       phase:   1        2        3        4        5        6        7        8
-//       refill:  A1>d1    B0>d1    A0>d0    B1>d0    A1>d0    B0>d0    A0>d1    B1>d1
+//       refill:  B1>d1    A1>d1    A0>d0    B0>d0    B1>d0    A1>d0    A0>d1    B0>d1
 //       tile:    t+1      t+1      t+2      t+2      t+2      t+2      t+3      t+3
 //     The only vector-memory waits in the loop are a counted `s_waitcnt vmcnt(4)` in phases 4 and 8
 //     (the two newest half-tiles stay in flight across the K-tile boundary); the buffer they retire is
@@ -35,10 +36,10 @@ constexpr int T256 = 256;
 constexpr int kHalf = 16384;       // one half-tile: 128 rows x 64 k x 2 B
 constexpr int kDbuf = 4 * kHalf;   // A0 A1 B0 B1
 
-template <typename T, bool OUT_F32>
+template <typename T, bool OUT_F32, bool HAS_RES>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     using X8 = typename Elem<T>::x8;
-    __shared__ __attribute__((aligned(16))) char smem[2 * kDbuf];
+    __shared__ __attribute__((aligned(16))) char smem[2 * kDbuf + 8 * 1024];   // two K-tiles + one 1-KiB bias slot per wave
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -83,8 +84,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                 gm = gm < a.M ? gm : a.M - 1;
                 a_off[h][j] = (unsigned)((gm * a.lda + schunk * 8) * 2);
                 // weight rows permuted so that accumulator lane group g owns 8 consecutive features per half
-                const int feat = (lr & ~31) + ((lr & 15) >> 2) * 8 + ((lr >> 4) & 1) * 4 + (lr & 3);
-                int gn = n0 + h * 128 + feat;
+                // half h of the weight tile holds, for each consumer wave wc, features wc*64 + h*32 + [0,32): a wave's
+                // two halves are adjacent, so it owns 64 contiguous features = whole 128-byte lines of 16-bit output
+                const int feat = (lr >> 5) * 64 + h * 32 + ((lr & 15) >> 2) * 8 + ((lr >> 4) & 1) * 4 + (lr & 3);
+                int gn = n0 + feat;
                 gn = gn < a.N ? gn : a.N - 1;
                 w_off[h][j] = (unsigned)(((int64_t)gn * a.ldw + schunk * 8) * 2);
             }
@@ -105,14 +108,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     // first K-tile complete in dbuf 0 plus the first two half-tiles of K-tile 1 (what phases 7, 8 would have issued)
 #define ISSUE_PROLOGUE()                                                \
     ISSUE_A(0, 0, 0) ISSUE_A(1, 0, 0) ISSUE_B(0, 0, 0) ISSUE_B(1, 0, 0) \
-    ISSUE_A(0, 1, 1) ISSUE_B(1, 1, 1)
+    ISSUE_A(0, 1, 1) ISSUE_B(0, 1, 1)
 
     f32x4 acc[2][4][2][2];  // [m-half][m-tile][n-half][n-tile]
     const int swz = r15 & 7;
     const int c0 = ((0 + g) ^ swz) << 4, c1 = ((4 + g) ^ swz) << 4;   // 16-byte chunk offsets of the two k-steps
     const char* const a_rd = smem + (wr * 64 + r15) * 128;
     const char* const b_rd = smem + 2 * kHalf + (wc * 32 + r15) * 128;
-    X8 af[4][2], wf[2][2];
+    X8 af[4][2], wf[2][2][2];   // both weight halves stay in registers for the whole K-tile (B0 is used by q0 and q3)
 
 #define READ_A(H, DB)                                                                                  \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                 \
@@ -121,14 +124,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     }
 #define READ_B(H, DB)                                                                                  \
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                                 \
-        wf[ni][0] = *reinterpret_cast<const X8*>(b_rd + (DB) * kDbuf + (H) * kHalf + ni * 2048 + c0);  \
-        wf[ni][1] = *reinterpret_cast<const X8*>(b_rd + (DB) * kDbuf + (H) * kHalf + ni * 2048 + c1);  \
+        wf[H][ni][0] = *reinterpret_cast<const X8*>(b_rd + (DB) * kDbuf + (H) * kHalf + ni * 2048 + c0);  \
+        wf[H][ni][1] = *reinterpret_cast<const X8*>(b_rd + (DB) * kDbuf + (H) * kHalf + ni * 2048 + c1);  \
     }
 #define MMA(MH, NH)                                                                                    \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                   \
         _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                               \
             _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                           \
-                acc[MH][mi][NH][ni] = Elem<T>::mfma16(wf[ni][ks], af[mi][ks], acc[MH][mi][NH][ni]);
+                acc[MH][mi][NH][ni] = Elem<T>::mfma16(wf[NH][ni][ks], af[mi][ks], acc[MH][mi][NH][ni]);
 #define SYNC()                                   \
     __builtin_amdgcn_sched_barrier(0);           \
     __builtin_amdgcn_s_barrier();                \
@@ -145,32 +148,47 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     if ((NEXT_KT) < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    const bool res_in_acc = a.R != nullptr;   // linear epilogues only (dispatcher): the residual rides in the accumulator
+    constexpr bool res_in_acc = HAS_RES;   // linear epilogues only (dispatcher): the residual rides in the accumulator
+
+    // bias of the tile arrives by LDS-DMA into a private 1-KiB slot per wave (no VGPR-destination loads on the
+    // tile boundary: the compiler would answer those with vmcnt(0), which also waits for the previous tile's stores)
+    char* const bias_slot = smem + 2 * kDbuf + wave * 1024;
+#define ISSUE_BIAS()                                                                                                   \
+    if (a.bias != nullptr) {                                                                                           \
+        int bn = n0 + lane * 4;                                                                                        \
+        bn = bn + 4 <= a.N ? bn : a.N - 4;   /* clamped lanes feed features whose outputs are never stored */          \
+        __builtin_amdgcn_global_load_lds((gptr_t)(a.bias + z * a.sBias + bn), (lptr_t)(bias_slot), 16, 0, 0);         \
+    }
 
     int t = blockIdx.x;
     setup(t);
     ISSUE_PROLOGUE()
+    ISSUE_BIAS()
+    int pending_stores = 0;   // store instructions this wave issued after its newest loads (0 = unknown -> full drain)
 
     for (;;) {
         const int64_t cm0 = m0;
         const int cn0 = n0, cz = z;
+        // ---- operands of the first K-tile(s) and the bias have landed; the previous tile's stores may still fly ------
+        if (res_in_acc || pending_stores == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (pending_stores == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         // ---- accumulators start at bias (+ residual): the epilogue then needs no loads --------------------------
         {
             float bias[2][8];
-            bool n_ok[2];
+            if (a.bias != nullptr) {
+                // LDS reads hidden from the compiler's wait-count pass: it would put vmcnt(0) in front of a ds_read of
+                // DMA-written LDS.  Loads and their lgkmcnt wait live in ONE statement (outputs early-clobber).
+                f32x4 b00, b01, b10, b11;
+                const unsigned baddr = (unsigned)(size_t)(lptr_t)(bias_slot) + (unsigned)((wc * 64 + g * 8) * 4);
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:128\n\t"
+                             "ds_read_b128 %3, %4 offset:144\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(b00), "=&v"(b01), "=&v"(b10), "=&v"(b11) : "v"(baddr) : "memory");
 #pragma unroll
-            for (int nh = 0; nh < 2; ++nh) {
-                const int nb = cn0 + nh * 128 + wc * 32 + g * 8;
-                n_ok[nh] = nb + 8 <= a.N;
-                if (a.bias != nullptr && n_ok[nh]) {
-                    const float4* bp = reinterpret_cast<const float4*>(a.bias + cz * a.sBias + nb);
-                    const float4 b0 = bp[0], b1 = bp[1];
-                    bias[nh][0] = b0.x; bias[nh][1] = b0.y; bias[nh][2] = b0.z; bias[nh][3] = b0.w;
-                    bias[nh][4] = b1.x; bias[nh][5] = b1.y; bias[nh][6] = b1.z; bias[nh][7] = b1.w;
-                } else {
+                for (int q = 0; q < 4; ++q) { bias[0][q] = b00[q]; bias[0][4 + q] = b01[q]; bias[1][q] = b10[q]; bias[1][4 + q] = b11[q]; }
+            } else {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) bias[nh][q] = 0.f;
-                }
+                for (int q = 0; q < 8; ++q) { bias[0][q] = 0.f; bias[1][q] = 0.f; }
             }
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh)
@@ -180,8 +198,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
 #pragma unroll
                     for (int nh = 0; nh < 2; ++nh) {
                         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-                        if (res_in_acc && m < a.M && n_ok[nh]) {
-                            const float4* rp = reinterpret_cast<const float4*>(a.R + cz * a.sR + m * a.ldr + cn0 + nh * 128 + wc * 32 + g * 8);
+                        const int nb = cn0 + wc * 64 + nh * 32 + g * 8;
+                        if constexpr (res_in_acc) if (m < a.M && nb + 8 <= a.N) {
+                            const float4* rp = reinterpret_cast<const float4*>(a.R + cz * a.sR + m * a.ldr + nb);
                             r0 = rp[0];
                             r1 = rp[1];
                         }
@@ -189,8 +208,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                         acc[mh][mi][nh][1] = f32x4{bias[nh][4] + r1.x, bias[nh][5] + r1.y, bias[nh][6] + r1.z, bias[nh][7] + r1.w};
                     }
                 }
-            // materialise every accumulator now, so the compiler's own wait for these loads sits here (once per
-            // tile) and not in front of the first MFMA of each phase inside the K loop
+            // materialise every accumulator now, so the compiler's own wait for the residual loads sits here (once
+            // per tile) and not in front of the first MFMA of each phase inside the K loop
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -200,7 +219,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                         asm volatile("" : "+v"(acc[mh][mi][nh][0]), "+v"(acc[mh][mi][nh][1]));
                     }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // prologue half-tiles landed (and the previous tile's stores)
         SYNC();
         if (wr == 1) { SYNC(); }   // stagger: waves 4-7 run one barrier behind waves 0-3
 
@@ -209,67 +227,115 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
             const int t0 = 2 * it, t1 = t0 + 1;
             const bool odd = t1 < nk;
             // ---- K-tile t0 in dbuf 0 ---------------------------------------------------------------------------
-            READ_B(0, 0) READ_A(0, 0) ISSUE_A(1, 1, t1)                      COMPUTE(true, 0, 0)   // phase 1
-            READ_B(1, 0)              ISSUE_B(0, 1, t1)                      COMPUTE(true, 0, 1)   // phase 2
+            READ_B(0, 0) READ_A(0, 0) ISSUE_B(1, 1, t1)                      COMPUTE(true, 0, 0)   // phase 1
+            READ_B(1, 0)              ISSUE_A(1, 1, t1)                      COMPUTE(true, 0, 1)   // phase 2
             READ_A(1, 0)              ISSUE_A(0, 0, t0 + 2)                  COMPUTE(true, 1, 1)   // phase 3
-            READ_B(0, 0)              ISSUE_B(1, 0, t0 + 2) WAIT_TILE(t0 + 2) COMPUTE(true, 1, 0)  // phase 4
+                                      ISSUE_B(0, 0, t0 + 2) WAIT_TILE(t0 + 2) COMPUTE(true, 1, 0)  // phase 4
             // ---- K-tile t1 in dbuf 1 ---------------------------------------------------------------------------
             if (odd) { READ_B(0, 1) READ_A(0, 1) }
-            ISSUE_A(1, 0, t0 + 2)                                            COMPUTE(odd, 0, 0)    // phase 5
+            ISSUE_B(1, 0, t0 + 2)                                            COMPUTE(odd, 0, 0)    // phase 5
             if (odd) { READ_B(1, 1) }
-            ISSUE_B(0, 0, t0 + 2)                                            COMPUTE(odd, 0, 1)    // phase 6
+            ISSUE_A(1, 0, t0 + 2)                                            COMPUTE(odd, 0, 1)    // phase 6
             if (odd) { READ_A(1, 1) }
             ISSUE_A(0, 1, t1 + 2)                                            COMPUTE(odd, 1, 1)    // phase 7
-            if (odd) { READ_B(0, 1) }
-            ISSUE_B(1, 1, t1 + 2) WAIT_TILE(t1 + 2)                          COMPUTE(odd, 1, 0)    // phase 8
+            ISSUE_B(0, 1, t1 + 2) WAIT_TILE(t1 + 2)                          COMPUTE(odd, 1, 0)    // phase 8
         }
         if (wr == 0) { SYNC(); }   // pair the trailing barrier of the staggered group: all LDS reads of this tile are done
 
-        // ---- request the next tile's first K-tile before this tile's epilogue ----------------------------------------
+        // ---- request the next tile's first K-tile (and bias) before this tile's epilogue ------------------------------
         const int tn = t + (int)gridDim.x;
         const bool more = tn < ntiles;
         if (more) {
             setup(tn);
             ISSUE_PROLOGUE()
+            ISSUE_BIAS()
         }
+        __builtin_amdgcn_sched_barrier(0);
 
-        // ---- epilogue: lane (r15, g) owns rows cm0 + mh*128 + wr*64 + mi*16 + r15, features nb(nh) .. nb+7 -----------
+        // ---- epilogue: activation, pack, then ROW-CONTIGUOUS stores through a private LDS staging tile ---------------
+        // In the accumulator a lane owns 8 features of 16 different rows, so a direct store instruction would touch 16
+        // rows x 64 B (store issue, not HBM, then bounds the tile: ~13 B/clk/CU measured).  Each wave instead transposes
+        // 32 rows x 128 B (16-bit out) or 16 rows x 256 B (fp32 out) at a time through 4 KiB of LDS (the two half-tiles of
+        // dbuf 1 the next tile's prologue does not touch) and stores 1 KiB per instruction as 8 whole 128-byte lines.
+        // The LDS ops are inline asm: the compiler's wait-count pass would drain the prologue DMA in front of them.
+        // Interior tiles issue a FIXED number of store instructions (16 or 32): the next tile waits with a counted vmcnt.
+        const bool full = cm0 + T256 <= a.M && cn0 + T256 <= a.N;
+        {
+            char* const stg = smem + kDbuf + (wave < 4 ? kHalf + wave * 4096 : 3 * kHalf + (wave - 4) * 4096);
+            const unsigned stg_addr = (unsigned)(size_t)(lptr_t)(stg);
+            constexpr int ROWS = OUT_F32 ? 16 : 32;                 // rows per pass
+            constexpr int NPASS = 128 / ROWS;
+            constexpr int ROWB = OUT_F32 ? 256 : 128;               // bytes of this wave's 64 features in one row
 #pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int mh = ps / (NPASS / 2);
+                // ---- registers -> LDS (slot = 16-byte chunk of the row, XOR-swizzled with the row) ----
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int64_t m = cm0 + mh * 128 + wr * 64 + mi * 16 + r15;
-                if (m >= a.M) continue;
+                for (int sub = 0; sub < ROWS / 16; ++sub) {
+                    const int mi = (ps % (NPASS / 2)) * (ROWS / 16) + sub;
+                    const int lrow = sub * 16 + r15;
 #pragma unroll
-                for (int nh = 0; nh < 2; ++nh) {
-                    const int nb = cn0 + nh * 128 + wc * 32 + g * 8;
-                    if (nb + 8 > a.N) continue;
-                    float v[8];
+                    for (int nh = 0; nh < 2; ++nh) {
+                        float v[8];
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
+                        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) v[ni * 4 + jj] = acc[mh][mi][nh][ni][jj];
-                    if (a.act == CIR_ACT_GELU) {
+                            for (int jj = 0; jj < 4; ++jj) v[ni * 4 + jj] = acc[mh][mi][nh][ni][jj];
+                        if (a.act == CIR_ACT_GELU) {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] = gelu_erf(v[q]);
-                    } else if (a.act == CIR_ACT_RELU) {
+                            for (int q = 0; q < 8; ++q) v[q] = gelu_erf(v[q]);
+                        } else if (a.act == CIR_ACT_RELU) {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+                            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+                        }
+                        if constexpr (OUT_F32) {
+                            const int s0 = nh * 8 + g * 2;
+                            const unsigned ad0 = stg_addr + lrow * ROWB + (((s0) ^ (lrow & 7)) << 4);
+                            const unsigned ad1 = stg_addr + lrow * ROWB + (((s0 + 1) ^ (lrow & 7)) << 4);
+                            const f32x4 d0 = {v[0], v[1], v[2], v[3]}, d1 = {v[4], v[5], v[6], v[7]};
+                            asm volatile("ds_write_b128 %0, %1" :: "v"(ad0), "v"(d0) : "memory");
+                            asm volatile("ds_write_b128 %0, %1" :: "v"(ad1), "v"(d1) : "memory");
+                        } else {
+                            u32x4 o;
+                            o.x = pack2<T>(v[0], v[1]); o.y = pack2<T>(v[2], v[3]); o.z = pack2<T>(v[4], v[5]); o.w = pack2<T>(v[6], v[7]);
+                            const unsigned ad = stg_addr + lrow * ROWB + (((nh * 4 + g) ^ (lrow & 7)) << 4);
+                            asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(o) : "memory");
+                        }
                     }
-                    if constexpr (OUT_F32) {
-                        float4* cp = reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + cz * a.sC + m * a.ldc + nb);
-                        cp[0] = make_float4(v[0], v[1], v[2], v[3]);
-                        cp[1] = make_float4(v[4], v[5], v[6], v[7]);
-                    } else {
-                        u32x4 o;
-                        o.x = pack2<T>(v[0], v[1]); o.y = pack2<T>(v[2], v[3]); o.z = pack2<T>(v[4], v[5]); o.w = pack2<T>(v[6], v[7]);
-                        *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.C) + cz * a.sC + m * a.ldc + nb) = o;
+                }
+                // ---- LDS -> registers, lanes along the row: instruction j covers ROWS/4 rows x ROWB bytes = 1 KiB ----
+                constexpr int LPR = ROWB / 16;                      // lanes per row
+                const int rr = lane / LPR, sl = lane % LPR;
+                u32x4 d[4];
+                {
+                    unsigned ra[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int lrow = j * (64 / LPR) + rr;
+                        ra[j] = stg_addr + lrow * ROWB + ((sl ^ (lrow & 7)) << 4);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\t"
+                                 "ds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+                                 : "v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]) : "memory");
+                }
+                const int prow = mh * 128 + wr * 64 + (ps % (NPASS / 2)) * ROWS;   // first row of this pass in the tile
+                const int ncol = cn0 + wc * 64 + sl * (OUT_F32 ? 4 : 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t m = cm0 + prow + j * (64 / LPR) + rr;
+                    if (full || (m < a.M && ncol + (OUT_F32 ? 4 : 8) <= a.N)) {
+                        if constexpr (OUT_F32) *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(a.C) + cz * a.sC + m * a.ldc + ncol) = d[j];
+                        else *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.C) + cz * a.sC + m * a.ldc + ncol) = d[j];
                     }
                 }
             }
+        }
+        pending_stores = full ? (OUT_F32 ? 32 : 16) : 0;
         if (!more) break;
         t = tn;
     }
+#undef ISSUE_BIAS
 #undef ISSUE_A
 #undef ISSUE_B
 #undef ISSUE_PROLOGUE
@@ -305,13 +371,16 @@ void launch_gemm256(const GemmArgs& a_in, int in_dtype, bool f32out, hipStream_t
     a.group_w = gw;
     const int64_t g = persistent_grid();
     dim3 grid((unsigned)(ntiles < g ? ntiles : g)), block(512);
+    const bool res = a.R != nullptr;
+#define CIR_LAUNCH256(TT, F32, RES) hipLaunchKernelGGL((gemm256_kernel<TT, F32, RES>), grid, block, 0, s, a)
     if (in_dtype == CIR_BF16) {
-        if (f32out) hipLaunchKernelGGL((gemm256_kernel<__bf16, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm256_kernel<__bf16, false>), grid, block, 0, s, a);
+        if (f32out) { if (res) CIR_LAUNCH256(__bf16, true, true); else CIR_LAUNCH256(__bf16, true, false); }
+        else { if (res) CIR_LAUNCH256(__bf16, false, true); else CIR_LAUNCH256(__bf16, false, false); }
     } else {
-        if (f32out) hipLaunchKernelGGL((gemm256_kernel<_Float16, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm256_kernel<_Float16, false>), grid, block, 0, s, a);
+        if (f32out) { if (res) CIR_LAUNCH256(_Float16, true, true); else CIR_LAUNCH256(_Float16, true, false); }
+        else { if (res) CIR_LAUNCH256(_Float16, false, true); else CIR_LAUNCH256(_Float16, false, false); }
     }
+#undef CIR_LAUNCH256
 }
 
 }  // namespace cir

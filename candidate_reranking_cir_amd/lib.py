@@ -10,7 +10,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcirrank.so")
+LIB_PATH = os.environ.get("CIR_LIB", os.path.join(_HERE, "libcirrank.so"))   # CIR_LIB: A/B a second build
 
 CIR_BF16, CIR_F16, CIR_F32 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2

@@ -27,7 +27,8 @@ if len(sys.argv) >= 4:
     act = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     out32 = bool(int(sys.argv[5])) if len(sys.argv) > 5 else False
     reps = int(sys.argv[6]) if len(sys.argv) > 6 else 20
-    run(m, n, k, act, out32, reps, res=out32)
+    res = bool(int(sys.argv[7])) if len(sys.argv) > 7 else out32
+    run(m, n, k, act, out32, reps, res=res)
 else:
     for shape in [(157600, 3072, 768, 0, False, False), (159176, 2304, 768, 0, False, False), (159176, 3072, 768, 1, False, False),
                   (159176, 768, 3072, 0, True, True), (159176, 768, 768, 0, True, True), (51200, 3072, 768, 1, False, False),
