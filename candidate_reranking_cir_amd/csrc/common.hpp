@@ -92,6 +92,29 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// two GELUs at once on packed fp32 (v_pk_mul / v_pk_fma / v_pk_add): the epilogue has no MFMAs to disturb
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    f32x2 xc;
+    xc.x = __builtin_amdgcn_fmed3f(x.x, -5.5f, 5.5f);
+    xc.y = __builtin_amdgcn_fmed3f(x.y, -5.5f, 5.5f);
+    const f32x2 x2 = xc * xc;
+    const f32x2 c3 = {-2.48362952e-05f, -2.48362952e-05f}, c2 = {-7.36062896e-04f, -7.36062896e-04f};
+    const f32x2 c1 = {1.05982735e-01f, 1.05982735e-01f}, c0 = {2.30164715e+00f, 2.30164715e+00f};
+    f32x2 p = __builtin_elementwise_fma(x2, c3, c2);
+    p = __builtin_elementwise_fma(x2, p, c1);
+    p = __builtin_elementwise_fma(x2, p, c0);
+    const f32x2 q = xc * p;
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(-q.x);
+    e.y = __builtin_amdgcn_exp2f(-q.y);
+    const f32x2 d = e + 1.0f;
+    f32x2 r;
+    r.x = __builtin_amdgcn_rcpf(d.x);
+    r.y = __builtin_amdgcn_rcpf(d.y);
+    return x * r;
+}
+
 // bijective XCD remap: consecutive "logical" ids land on one XCD (blocks b and b+8 share an XCD)
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int q = nblk >> 3, r = nblk & 7, x = bid & 7;

@@ -32,6 +32,20 @@
 
 namespace cir {
 
+#ifdef CIR_GEMM_STAMPS
+// Diagnostic build only: s_memtime stamps of workgroup 0 / wave 0 (and wave 4) at tile-phase boundaries, written to a
+// buffer of their own that no other code reads (MI355X guide: in-kernel stamps).  Never part of the shipped library.
+__device__ unsigned long long g_stamps[2][64][8];
+#define STAMP(SLOT)                                                                                         \
+    if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0 && tile_no < 64) {                        \
+        unsigned long long t_;                                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                    \
+        g_stamps[wave >> 2][tile_no][SLOT] = t_;                                                            \
+    }
+#else
+#define STAMP(SLOT)
+#endif
+
 constexpr int T256 = 256;
 constexpr int kHalf = 16384;       // one half-tile: 128 rows x 64 k x 2 B
 constexpr int kDbuf = 4 * kHalf;   // A0 A1 B0 B1
@@ -54,11 +68,35 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     char* const stage_base = smem + wave * 2048;
 
     // ---- per-tile state ----------------------------------------------------------------------------------------
+    // Operand addresses = wave-uniform tile base (SGPR pair) + 32-bit per-lane byte offset RELATIVE to the tile.  For
+    // interior tiles the lane offsets are tile-invariant (computed once); only tiles on the ragged M / N edge recompute
+    // them with clamped rows.  setup() is then scalar work for almost every tile.
     int64_t m0 = 0;
     int n0 = 0, z = 0;
-    const char* A_z = nullptr;   // wave-uniform bases (SGPRs) + 32-bit per-lane byte offsets: 8 VGPRs of addressing
+    const char* A_z = nullptr;
     const char* W_z = nullptr;
     unsigned a_off[2][2], w_off[2][2];
+    bool rel_interior = false;
+    auto lane_offsets = [&](bool interior) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int lr = (wave * 2 + j) * 8 + srow;             // LDS row inside the half-tile
+                // half h of the weight tile holds, for each consumer wave wc, features wc*64 + h*32 + [0,32): a wave's
+                // two halves are adjacent, so it owns 64 contiguous features = whole 128-byte lines of 16-bit output;
+                // within a half, rows are permuted so that accumulator lane group g owns 8 consecutive features
+                const int feat = (lr >> 5) * 64 + h * 32 + ((lr & 15) >> 2) * 8 + ((lr >> 4) & 1) * 4 + (lr & 3);
+                int64_t rm = h * 128 + lr;
+                int rn = feat;
+                if (!interior) {
+                    rm = (m0 + rm < a.M ? m0 + rm : a.M - 1) - m0;    // clamp the ragged edges (stores are predicated)
+                    rn = (n0 + rn < a.N ? n0 + rn : a.N - 1) - n0;
+                }
+                a_off[h][j] = (unsigned)((rm * a.lda + schunk * 8) * 2);
+                w_off[h][j] = (unsigned)(((int64_t)rn * a.ldw + schunk * 8) * 2);
+            }
+    };
     auto setup = [&](int t) {
         int id = xcd_remap(t, ntiles);
         z = id / per_batch;
@@ -72,25 +110,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         const int tile_m = rem / gw, tile_n = first_n + (rem - tile_m * gw);
         m0 = (int64_t)tile_m * T256;
         n0 = tile_n * T256;
-        A_z = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.A) + z * a.sA);
-        W_z = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.W) + z * a.sW);
-        // staging sources: every half-tile is 16 wave-instructions of 8 rows; wave w issues pieces 2w, 2w+1
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int lr = (wave * 2 + j) * 8 + srow;             // LDS row inside the half-tile
-                int64_t gm = m0 + h * 128 + lr;
-                gm = gm < a.M ? gm : a.M - 1;
-                a_off[h][j] = (unsigned)((gm * a.lda + schunk * 8) * 2);
-                // weight rows permuted so that accumulator lane group g owns 8 consecutive features per half
-                // half h of the weight tile holds, for each consumer wave wc, features wc*64 + h*32 + [0,32): a wave's
-                // two halves are adjacent, so it owns 64 contiguous features = whole 128-byte lines of 16-bit output
-                const int feat = (lr >> 5) * 64 + h * 32 + ((lr & 15) >> 2) * 8 + ((lr >> 4) & 1) * 4 + (lr & 3);
-                int gn = n0 + feat;
-                gn = gn < a.N ? gn : a.N - 1;
-                w_off[h][j] = (unsigned)(((int64_t)gn * a.ldw + schunk * 8) * 2);
-            }
+        A_z = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.A) + z * a.sA + m0 * a.lda);
+        W_z = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.W) + z * a.sW + (int64_t)n0 * a.ldw);
+        const bool interior = m0 + T256 <= a.M && n0 + T256 <= a.N;
+        if (!interior || !rel_interior) lane_offsets(interior);
+        rel_interior = interior;
     };
 
 #define ISSUE_A(H, DB, KT)                                                                                              \
@@ -165,14 +189,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     ISSUE_PROLOGUE()
     ISSUE_BIAS()
     int pending_stores = 0;   // store instructions this wave issued after its newest loads (0 = unknown -> full drain)
+    int tile_no = 0;
 
     for (;;) {
         const int64_t cm0 = m0;
         const int cn0 = n0, cz = z;
+        STAMP(0)
         // ---- operands of the first K-tile(s) and the bias have landed; the previous tile's stores may still fly ------
         if (res_in_acc || pending_stores == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (pending_stores == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        STAMP(1)
         // ---- accumulators start at bias (+ residual): the epilogue then needs no loads --------------------------
         {
             float bias[2][8];
@@ -219,8 +246,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                         asm volatile("" : "+v"(acc[mh][mi][nh][0]), "+v"(acc[mh][mi][nh][1]));
                     }
         }
+        STAMP(2)
         SYNC();
         if (wr == 1) { SYNC(); }   // stagger: waves 4-7 run one barrier behind waves 0-3
+        STAMP(3)
 
         const int niter = (nk + 1) >> 1;
         for (int it = 0; it < niter; ++it) {
@@ -240,7 +269,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
             ISSUE_A(0, 1, t1 + 2)                                            COMPUTE(odd, 1, 1)    // phase 7
             ISSUE_B(0, 1, t1 + 2) WAIT_TILE(t1 + 2)                          COMPUTE(odd, 1, 0)    // phase 8
         }
+        STAMP(4)
         if (wr == 0) { SYNC(); }   // pair the trailing barrier of the staggered group: all LDS reads of this tile are done
+        STAMP(5)
 
         // ---- request the next tile's first K-tile (and bias) before this tile's epilogue ------------------------------
         const int tn = t + (int)gridDim.x;
@@ -251,6 +282,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
             ISSUE_BIAS()
         }
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(6)
 
         // ---- epilogue: activation, pack, then ROW-CONTIGUOUS stores through a private LDS staging tile ---------------
         // In the accumulator a lane owns 8 features of 16 different rows, so a direct store instruction would touch 16
@@ -266,47 +298,50 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
             constexpr int ROWS = OUT_F32 ? 16 : 32;                 // rows per pass
             constexpr int NPASS = 128 / ROWS;
             constexpr int ROWB = OUT_F32 ? 256 : 128;               // bytes of this wave's 64 features in one row
+            constexpr int LPR = ROWB / 16;                          // lanes per row when reading back
+            const int rr = lane / LPR, sl = lane % LPR;
+            const int ncol = cn0 + wc * 64 + sl * (OUT_F32 ? 4 : 8);
+            u32x4 wd[4];                                            // one pass of packed outputs: [sub][nh] (16-bit) / [nh][half] (fp32)
+            // activation + pack of pass `ps` into wd (pure VALU: overlaps the LDS round trip of the previous pass)
+#define PRODUCE(PS)                                                                                                          \
+            _Pragma("unroll") for (int sub = 0; sub < ROWS / 16; ++sub) {                                                    \
+                const int mi = ((PS) % (NPASS / 2)) * (ROWS / 16) + sub;                                                     \
+                _Pragma("unroll") for (int nh = 0; nh < 2; ++nh) {                                                           \
+                    float v[8];                                                                                              \
+                    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                         \
+                        _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) v[ni * 4 + jj] = acc[(PS) / (NPASS / 2)][mi][nh][ni][jj]; \
+                    if (a.act == CIR_ACT_GELU) {                                                                             \
+                        _Pragma("unroll") for (int q = 0; q < 8; q += 2) {                                                   \
+                            const f32x2 y = gelu_erf2(f32x2{v[q], v[q + 1]});                                                \
+                            v[q] = y.x; v[q + 1] = y.y;                                                                      \
+                        }                                                                                                    \
+                    } else if (a.act == CIR_ACT_RELU) {                                                                      \
+                        _Pragma("unroll") for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);                               \
+                    }                                                                                                        \
+                    if constexpr (OUT_F32) {                                                                                 \
+                        wd[nh * 2 + 0] = __builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]});                           \
+                        wd[nh * 2 + 1] = __builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]});                           \
+                    } else {                                                                                                 \
+                        u32x4 o;                                                                                             \
+                        o.x = pack2<T>(v[0], v[1]); o.y = pack2<T>(v[2], v[3]); o.z = pack2<T>(v[4], v[5]); o.w = pack2<T>(v[6], v[7]); \
+                        wd[sub * 2 + nh] = o;                                                                                \
+                    }                                                                                                        \
+                }                                                                                                            \
+            }
+            // registers -> LDS staging tile: slot = 16-byte chunk of the row, XOR-swizzled with the row
+#define WRITE_STAGE()                                                                                                        \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                  \
+                const int lrow = OUT_F32 ? r15 : (i >> 1) * 16 + r15;                                                        \
+                const int slot = OUT_F32 ? ((i >> 1) * 8 + g * 2 + (i & 1)) : ((i & 1) * 4 + g);                             \
+                const unsigned ad = stg_addr + lrow * ROWB + ((slot ^ (lrow & 7)) << 4);                                     \
+                asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(wd[i]) : "memory");                                      \
+            }
+            PRODUCE(0)
+            WRITE_STAGE()
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
-                const int mh = ps / (NPASS / 2);
-                // ---- registers -> LDS (slot = 16-byte chunk of the row, XOR-swizzled with the row) ----
-#pragma unroll
-                for (int sub = 0; sub < ROWS / 16; ++sub) {
-                    const int mi = (ps % (NPASS / 2)) * (ROWS / 16) + sub;
-                    const int lrow = sub * 16 + r15;
-#pragma unroll
-                    for (int nh = 0; nh < 2; ++nh) {
-                        float v[8];
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                            for (int jj = 0; jj < 4; ++jj) v[ni * 4 + jj] = acc[mh][mi][nh][ni][jj];
-                        if (a.act == CIR_ACT_GELU) {
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) v[q] = gelu_erf(v[q]);
-                        } else if (a.act == CIR_ACT_RELU) {
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
-                        }
-                        if constexpr (OUT_F32) {
-                            const int s0 = nh * 8 + g * 2;
-                            const unsigned ad0 = stg_addr + lrow * ROWB + (((s0) ^ (lrow & 7)) << 4);
-                            const unsigned ad1 = stg_addr + lrow * ROWB + (((s0 + 1) ^ (lrow & 7)) << 4);
-                            const f32x4 d0 = {v[0], v[1], v[2], v[3]}, d1 = {v[4], v[5], v[6], v[7]};
-                            asm volatile("ds_write_b128 %0, %1" :: "v"(ad0), "v"(d0) : "memory");
-                            asm volatile("ds_write_b128 %0, %1" :: "v"(ad1), "v"(d1) : "memory");
-                        } else {
-                            u32x4 o;
-                            o.x = pack2<T>(v[0], v[1]); o.y = pack2<T>(v[2], v[3]); o.z = pack2<T>(v[4], v[5]); o.w = pack2<T>(v[6], v[7]);
-                            const unsigned ad = stg_addr + lrow * ROWB + (((nh * 4 + g) ^ (lrow & 7)) << 4);
-                            asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(o) : "memory");
-                        }
-                    }
-                }
-                // ---- LDS -> registers, lanes along the row: instruction j covers ROWS/4 rows x ROWB bytes = 1 KiB ----
-                constexpr int LPR = ROWB / 16;                      // lanes per row
-                const int rr = lane / LPR, sl = lane % LPR;
-                u32x4 d[4];
+                // LDS -> registers, lanes along the row: instruction j covers 64/LPR rows x ROWB bytes = 1 KiB
+                u32x4 d0, d1, d2, d3;
                 {
                     unsigned ra[4];
 #pragma unroll
@@ -314,24 +349,30 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                         const int lrow = j * (64 / LPR) + rr;
                         ra[j] = stg_addr + lrow * ROWB + ((sl ^ (lrow & 7)) << 4);
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\t"
-                                 "ds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7"
+                                 : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
                                  : "v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]) : "memory");
                 }
-                const int prow = mh * 128 + wr * 64 + (ps % (NPASS / 2)) * ROWS;   // first row of this pass in the tile
-                const int ncol = cn0 + wc * 64 + sl * (OUT_F32 ? 4 : 8);
+                if (ps + 1 < NPASS) { PRODUCE(ps + 1) }             // next pass's VALU work under the LDS latency
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) :: "memory");
+                const int prow = (ps / (NPASS / 2)) * 128 + wr * 64 + (ps % (NPASS / 2)) * ROWS;   // first row of this pass in the tile
+                const u32x4 dd[4] = {d0, d1, d2, d3};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int64_t m = cm0 + prow + j * (64 / LPR) + rr;
                     if (full || (m < a.M && ncol + (OUT_F32 ? 4 : 8) <= a.N)) {
-                        if constexpr (OUT_F32) *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(a.C) + cz * a.sC + m * a.ldc + ncol) = d[j];
-                        else *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.C) + cz * a.sC + m * a.ldc + ncol) = d[j];
+                        if constexpr (OUT_F32) *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(a.C) + cz * a.sC + m * a.ldc + ncol) = dd[j];
+                        else *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.C) + cz * a.sC + m * a.ldc + ncol) = dd[j];
                     }
                 }
+                if (ps + 1 < NPASS) { WRITE_STAGE() }               // the reads of this pass have retired
             }
+#undef PRODUCE
+#undef WRITE_STAGE
         }
         pending_stores = full ? (OUT_F32 ? 32 : 16) : 0;
+        STAMP(7)
+        ++tile_no;
         if (!more) break;
         t = tn;
     }
@@ -346,6 +387,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
 #undef COMPUTE
 #undef WAIT_TILE
 }
+
+#ifdef CIR_GEMM_STAMPS
+}  // namespace cir
+extern "C" int cir_debug_read_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cir::g_stamps), sizeof(cir::g_stamps));
+}
+namespace cir {
+#endif
 
 static int persistent_grid() {
     static int cus = 0;   // lazily read device constant (number of CUs); the only state this library keeps
