@@ -97,10 +97,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                 w_off[h][j] = (unsigned)(((int64_t)rn * a.ldw + schunk * 8) * 2);
             }
     };
-    auto setup = [&](int t) {
+    struct Coords { int64_t m0; int n0, z; const char* A; const char* W; bool interior; };
+    auto coords = [&](int t) -> Coords {
+        Coords c;
         int id = xcd_remap(t, ntiles);
-        z = id / per_batch;
-        id -= z * per_batch;
+        c.z = id / per_batch;
+        id -= c.z * per_batch;
         // column groups of `group_w` weight panels: an XCD's 32 concurrent tiles then share few weight panels
         // (resident in its 4 MiB L2) and stream the activation panels, each used by group_w tiles at once
         const int gsz = a.tiles_m * a.group_w;
@@ -108,24 +110,34 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         const int first_n = grp * a.group_w;
         const int gw = min(a.group_w, a.tiles_n - first_n);
         const int tile_m = rem / gw, tile_n = first_n + (rem - tile_m * gw);
-        m0 = (int64_t)tile_m * T256;
-        n0 = tile_n * T256;
-        A_z = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.A) + z * a.sA + m0 * a.lda);
-        W_z = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.W) + z * a.sW + (int64_t)n0 * a.ldw);
-        const bool interior = m0 + T256 <= a.M && n0 + T256 <= a.N;
-        if (!interior || !rel_interior) lane_offsets(interior);
-        rel_interior = interior;
+        c.m0 = (int64_t)tile_m * T256;
+        c.n0 = tile_n * T256;
+        c.A = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.A) + c.z * a.sA + c.m0 * a.lda);
+        c.W = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.W) + c.z * a.sW + (int64_t)c.n0 * a.ldw);
+        c.interior = c.m0 + T256 <= a.M && c.n0 + T256 <= a.N;
+        return c;
     };
+    auto adopt = [&](const Coords& c) {   // make `c` the current tile (refreshes lane offsets only on / after edge tiles)
+        m0 = c.m0; n0 = c.n0; z = c.z; A_z = c.A; W_z = c.W;
+        if (!c.interior || !rel_interior) lane_offsets(c.interior);
+        rel_interior = c.interior;
+    };
+    // Operand stream across tile seams: when this and the next tile are interior (same lane offsets) and K holds an
+    // even number of K-tiles, the refill slots of the LAST iteration - idle otherwise - fetch the next tile's first
+    // K-tile(s), exactly the set a prologue would request, several phases before this tile even ends.
+    const char* A_nx = nullptr;
+    const char* W_nx = nullptr;
+    bool stream = false;
 
 #define ISSUE_A(H, DB, KT)                                                                                              \
-    if ((KT) < nk) {                                                                                                    \
-        const char* kb_ = A_z + (KT) * 128;                                                                            \
+    if ((KT) < nk || stream) {                                                                                          \
+        const char* kb_ = (KT) < nk ? A_z + (KT) * 128 : A_nx + ((KT) - nk) * 128;                                      \
         __builtin_amdgcn_global_load_lds((gptr_t)(kb_ + a_off[H][0]), (lptr_t)(stage_base + (DB) * kDbuf + (H) * kHalf), 16, 0, 0);        \
         __builtin_amdgcn_global_load_lds((gptr_t)(kb_ + a_off[H][1]), (lptr_t)(stage_base + (DB) * kDbuf + (H) * kHalf + 1024), 16, 0, 0); \
     }
 #define ISSUE_B(H, DB, KT)                                                                                              \
-    if ((KT) < nk) {                                                                                                    \
-        const char* kb_ = W_z + (KT) * 128;                                                                            \
+    if ((KT) < nk || stream) {                                                                                          \
+        const char* kb_ = (KT) < nk ? W_z + (KT) * 128 : W_nx + ((KT) - nk) * 128;                                      \
         __builtin_amdgcn_global_load_lds((gptr_t)(kb_ + w_off[H][0]), (lptr_t)(stage_base + (DB) * kDbuf + (2 + (H)) * kHalf), 16, 0, 0);        \
         __builtin_amdgcn_global_load_lds((gptr_t)(kb_ + w_off[H][1]), (lptr_t)(stage_base + (DB) * kDbuf + (2 + (H)) * kHalf + 1024), 16, 0, 0); \
     }
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     }                                            \
     SYNC();
 #define WAIT_TILE(NEXT_KT)                                                        \
-    if ((NEXT_KT) < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          \
+    if ((NEXT_KT) < nk || stream) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     constexpr bool res_in_acc = HAS_RES;   // linear epilogues only (dispatcher): the residual rides in the accumulator
@@ -185,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     }
 
     int t = blockIdx.x;
-    setup(t);
+    adopt(coords(t));
     ISSUE_PROLOGUE()
     ISSUE_BIAS()
     int pending_stores = 0;   // store instructions this wave issued after its newest loads (0 = unknown -> full drain)
@@ -194,6 +206,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     for (;;) {
         const int64_t cm0 = m0;
         const int cn0 = n0, cz = z;
+        const int tn = t + (int)gridDim.x;
+        const bool more = tn < ntiles;
+        Coords nx = coords(more ? tn : t);
+        A_nx = nx.A; W_nx = nx.W;
+        stream = false;   // the prologue of THIS tile must not be mistaken for a streamed one while waiting below
         STAMP(0)
         // ---- operands of the first K-tile(s) and the bias have landed; the previous tile's stores may still fly ------
         if (res_in_acc || pending_stores == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -249,6 +266,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         STAMP(2)
         SYNC();
         if (wr == 1) { SYNC(); }   // stagger: waves 4-7 run one barrier behind waves 0-3
+        stream = more && nx.interior && rel_interior && nk >= 2 && (nk & 1) == 0;
         STAMP(3)
 
         const int niter = (nk + 1) >> 1;
@@ -274,11 +292,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         STAMP(5)
 
         // ---- request the next tile's first K-tile (and bias) before this tile's epilogue ------------------------------
-        const int tn = t + (int)gridDim.x;
-        const bool more = tn < ntiles;
         if (more) {
-            setup(tn);
-            ISSUE_PROLOGUE()
+            const bool streamed = stream;
+            stream = false;
+            adopt(nx);
+            if (!streamed) { ISSUE_PROLOGUE() }   // otherwise already in flight since the last iteration
             ISSUE_BIAS()
         }
         __builtin_amdgcn_sched_barrier(0);
