@@ -26,6 +26,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL / multi-process)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -14,15 +14,15 @@
 //   * a K-tile is consumed in four phases, one 64x32 output quadrant per wave and phase (16 MFMAs):
 //       q0 = (A0,B0)  reads B0 then A0 (12 ds_read_b128)      q1 = (A0,B1)  reads B1 (4)
 //       q2 = (A1,B1)  reads A1 (8)                             q3 = (A1,B0)  reads nothing (B0 fragments kept)
-//   * every phase also issues ONE half-tile refill by LDS-DMA (2 x global_load_lds_dwordx4 per lane),
-//     always into a half-tile whose last read lies at least two phases back, and at least five phases
-//     (~1.25 K-tiles, ~2 us) ahead of its first use, so an HBM-latency miss is still hidden:
-//       phase:   1        2        3        4        5        6        7        8
-//       refill:  B1>d1    A1>d1    A0>d0    B0>d0    B1>d0    A1>d0    A0>d1    B0>d1
-//       tile:    t+1      t+1      t+2      t+2      t+2      t+2      t+3      t+3
-//     The only vector-memory waits in the loop are a counted `s_waitcnt vmcnt(4)` in phases 4 and 8
-//     (the two newest half-tiles stay in flight across the K-tile boundary); the buffer they retire is
-//     first read one phase later, behind a barrier.
+//   * refills go by LDS-DMA (2 x global_load_lds_dwordx4 per lane and half-tile), always into a half-tile whose last
+//     read lies at least two phases back (the staggered group reads one slot later), as early as that allows:
+//       phase:   1        2     3            4        5        6     7            8
+//       refill:  A1>d1    -     A0,B0>d0     B1>d0    A1>d0    -     A0,B0>d1     B1>d1
+//       tile:    t+1            t+2          t+2      t+2            t+3          t+3
+//     The only vector-memory waits in the loop are a counted `s_waitcnt vmcnt(6)` in phases 4 and 8: THREE half-tiles
+//     stay in flight across the K-tile boundary and every refill has >= 3 phases to land.  (The loop is bound by
+//     operand delivery, not by the MFMA pipe: with the MFMAs compiled out it takes the same time; bytes in flight /
+//     latency is what sets the rate.)  The buffer a wait retires is first read one phase later, behind a barrier.
 //   * the two wave groups (waves 0-3 / 4-7 = the two waves of each SIMD) run staggered by one barrier,
 //     so one group's MFMA segment overlaps the other group's LDS-read / DMA-issue segment.
 // Operand layout, swizzle and the swapped MFMA orientation are those of gemm.hip.
@@ -53,7 +53,7 @@ constexpr int kDbuf = 4 * kHalf;   // A0 A1 B0 B1
 template <typename T, bool OUT_F32, bool HAS_RES>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     using X8 = typename Elem<T>::x8;
-    __shared__ __attribute__((aligned(16))) char smem[2 * kDbuf + 8 * 1024];   // two K-tiles + one 1-KiB bias slot per wave
+    __shared__ __attribute__((aligned(16))) char smem[2 * kDbuf + 8 * 1024 + 4 * 4096];   // two K-tiles + a 1-KiB bias slot per wave + epilogue staging for waves 4-7
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     // first K-tile complete in dbuf 0 plus the first two half-tiles of K-tile 1 (what phases 7, 8 would have issued)
 #define ISSUE_PROLOGUE()                                                \
     ISSUE_A(0, 0, 0) ISSUE_A(1, 0, 0) ISSUE_B(0, 0, 0) ISSUE_B(1, 0, 0) \
-    ISSUE_A(0, 1, 1) ISSUE_B(0, 1, 1)
+    ISSUE_A(0, 1, 1) ISSUE_B(0, 1, 1) ISSUE_B(1, 1, 1)
 
     f32x4 acc[2][4][2][2];  // [m-half][m-tile][n-half][n-tile]
     const int swz = r15 & 7;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     }                                            \
     SYNC();
 #define WAIT_TILE(NEXT_KT)                                                        \
-    if ((NEXT_KT) < nk || stream) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); \
+    if ((NEXT_KT) < nk || stream) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     constexpr bool res_in_acc = HAS_RES;   // linear epilogues only (dispatcher): the residual rides in the accumulator
@@ -274,18 +274,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
             const int t0 = 2 * it, t1 = t0 + 1;
             const bool odd = t1 < nk;
             // ---- K-tile t0 in dbuf 0 ---------------------------------------------------------------------------
-            READ_B(0, 0) READ_A(0, 0) ISSUE_B(1, 1, t1)                      COMPUTE(true, 0, 0)   // phase 1
-            READ_B(1, 0)              ISSUE_A(1, 1, t1)                      COMPUTE(true, 0, 1)   // phase 2
-            READ_A(1, 0)              ISSUE_A(0, 0, t0 + 2)                  COMPUTE(true, 1, 1)   // phase 3
-                                      ISSUE_B(0, 0, t0 + 2) WAIT_TILE(t0 + 2) COMPUTE(true, 1, 0)  // phase 4
+            READ_B(0, 0) READ_A(0, 0) ISSUE_A(1, 1, t1)                                      COMPUTE(true, 0, 0)   // phase 1
+            READ_B(1, 0)                                                                     COMPUTE(true, 0, 1)   // phase 2
+            READ_A(1, 0)              ISSUE_A(0, 0, t0 + 2) ISSUE_B(0, 0, t0 + 2)            COMPUTE(true, 1, 1)   // phase 3
+                                      ISSUE_B(1, 0, t0 + 2) WAIT_TILE(t0 + 2)                COMPUTE(true, 1, 0)   // phase 4
             // ---- K-tile t1 in dbuf 1 ---------------------------------------------------------------------------
             if (odd) { READ_B(0, 1) READ_A(0, 1) }
-            ISSUE_B(1, 0, t0 + 2)                                            COMPUTE(odd, 0, 0)    // phase 5
+            ISSUE_A(1, 0, t0 + 2)                                                            COMPUTE(odd, 0, 0)    // phase 5
             if (odd) { READ_B(1, 1) }
-            ISSUE_A(1, 0, t0 + 2)                                            COMPUTE(odd, 0, 1)    // phase 6
+                                                                                             COMPUTE(odd, 0, 1)    // phase 6
             if (odd) { READ_A(1, 1) }
-            ISSUE_A(0, 1, t1 + 2)                                            COMPUTE(odd, 1, 1)    // phase 7
-            ISSUE_B(0, 1, t1 + 2) WAIT_TILE(t1 + 2)                          COMPUTE(odd, 1, 0)    // phase 8
+            ISSUE_A(0, 1, t1 + 2) ISSUE_B(0, 1, t1 + 2)                                      COMPUTE(odd, 1, 1)    // phase 7
+            ISSUE_B(1, 1, t1 + 2) WAIT_TILE(t1 + 2)                                          COMPUTE(odd, 1, 0)    // phase 8
         }
         STAMP(4)
         if (wr == 0) { SYNC(); }   // pair the trailing barrier of the staggered group: all LDS reads of this tile are done
@@ -305,13 +305,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         // ---- epilogue: activation, pack, then ROW-CONTIGUOUS stores through a private LDS staging tile ---------------
         // In the accumulator a lane owns 8 features of 16 different rows, so a direct store instruction would touch 16
         // rows x 64 B (store issue, not HBM, then bounds the tile: ~13 B/clk/CU measured).  Each wave instead transposes
-        // 32 rows x 128 B (16-bit out) or 16 rows x 256 B (fp32 out) at a time through 4 KiB of LDS (the two half-tiles of
-        // dbuf 1 the next tile's prologue does not touch) and stores 1 KiB per instruction as 8 whole 128-byte lines.
+        // 32 rows x 128 B (16-bit out) or 16 rows x 256 B (fp32 out) at a time through 4 KiB of LDS (half-tile A1 of dbuf 1,
+        // which the next tile's prologue does not touch, and 16 KiB of spare LDS) and stores 1 KiB per instruction as 8 whole 128-byte lines.
         // The LDS ops are inline asm: the compiler's wait-count pass would drain the prologue DMA in front of them.
         // Interior tiles issue a FIXED number of store instructions (16 or 32): the next tile waits with a counted vmcnt.
         const bool full = cm0 + T256 <= a.M && cn0 + T256 <= a.N;
         {
-            char* const stg = smem + kDbuf + (wave < 4 ? kHalf + wave * 4096 : 3 * kHalf + (wave - 4) * 4096);
+            char* const stg = wave < 4 ? smem + kDbuf + kHalf + wave * 4096 : smem + 2 * kDbuf + 8 * 1024 + (wave - 4) * 4096;
             const unsigned stg_addr = (unsigned)(size_t)(lptr_t)(stg);
             constexpr int ROWS = OUT_F32 ? 16 : 32;                 // rows per pass
             constexpr int NPASS = 128 / ROWS;

@@ -2,7 +2,7 @@
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["CIR_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "candidate_reranking_cir_amd", "libcirrank_stamp.so")
+os.environ.setdefault("CIR_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "candidate_reranking_cir_amd", "libcirrank_stamp.so"))
 from candidate_reranking_cir_amd import ops, lib
 m, n, k = (int(x) for x in sys.argv[1:4])
 act = int(sys.argv[4]) if len(sys.argv) > 4 else 0
