@@ -19,7 +19,9 @@
 //       phase:   1        2     3            4        5        6     7            8
 //       refill:  A1>d1    -     A0,B0>d0     B1>d0    A1>d0    -     A0,B0>d1     B1>d1
 //       tile:    t+1            t+2          t+2      t+2            t+3          t+3
-//     The only vector-memory waits in the loop are a counted `s_waitcnt vmcnt(6)` in phases 4 and 8: THREE half-tiles
+//     Each half-tile is two 1-KiB pieces per wave: piece 0 is issued in the read segment, piece 1 between the two
+//     k-steps of the same phase's MFMA segment.  The only vector-memory waits in the loop are a counted
+//     `s_waitcnt vmcnt(5)` in phases 4 and 8: two and a half half-tiles
 //     stay in flight across the K-tile boundary and every refill has >= 3 phases to land.  (The loop is bound by
 //     operand delivery, not by the MFMA pipe: with the MFMAs compiled out it takes the same time; bytes in flight /
 //     latency is what sets the rate.)  The buffer a wait retires is first read one phase later, behind a barrier.
@@ -129,18 +131,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     const char* W_nx = nullptr;
     bool stream = false;
 
-#define ISSUE_A(H, DB, KT)                                                                                              \
+// One half-tile = two 1-KiB pieces per wave.  P selects the piece: the K loop issues piece 0 in the LDS-read segment and
+// piece 1 in the middle of the same phase's MFMA segment (an LDS-DMA issue costs the wave ~60 cycles among MFMAs but
+// ~170 in a segment of its own; the K loop is bound by that issue cost, not by the matrix pipe).
+#define ISSUE_A1(H, DB, KT, P)                                                                                          \
     if ((KT) < nk || stream) {                                                                                          \
         const char* kb_ = (KT) < nk ? A_z + (KT) * 128 : A_nx + ((KT) - nk) * 128;                                      \
-        __builtin_amdgcn_global_load_lds((gptr_t)(kb_ + a_off[H][0]), (lptr_t)(stage_base + (DB) * kDbuf + (H) * kHalf), 16, 0, 0);        \
-        __builtin_amdgcn_global_load_lds((gptr_t)(kb_ + a_off[H][1]), (lptr_t)(stage_base + (DB) * kDbuf + (H) * kHalf + 1024), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((gptr_t)(kb_ + a_off[H][P]), (lptr_t)(stage_base + (DB) * kDbuf + (H) * kHalf + (P) * 1024), 16, 0, 0); \
     }
-#define ISSUE_B(H, DB, KT)                                                                                              \
+#define ISSUE_B1(H, DB, KT, P)                                                                                          \
     if ((KT) < nk || stream) {                                                                                          \
         const char* kb_ = (KT) < nk ? W_z + (KT) * 128 : W_nx + ((KT) - nk) * 128;                                      \
-        __builtin_amdgcn_global_load_lds((gptr_t)(kb_ + w_off[H][0]), (lptr_t)(stage_base + (DB) * kDbuf + (2 + (H)) * kHalf), 16, 0, 0);        \
-        __builtin_amdgcn_global_load_lds((gptr_t)(kb_ + w_off[H][1]), (lptr_t)(stage_base + (DB) * kDbuf + (2 + (H)) * kHalf + 1024), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((gptr_t)(kb_ + w_off[H][P]), (lptr_t)(stage_base + (DB) * kDbuf + (2 + (H)) * kHalf + (P) * 1024), 16, 0, 0); \
     }
+#define ISSUE_A(H, DB, KT) ISSUE_A1(H, DB, KT, 0) ISSUE_A1(H, DB, KT, 1)
+#define ISSUE_B(H, DB, KT) ISSUE_B1(H, DB, KT, 0) ISSUE_B1(H, DB, KT, 1)
     // first K-tile complete in dbuf 0 plus the first two half-tiles of K-tile 1 (what phases 7, 8 would have issued)
 #define ISSUE_PROLOGUE()                                                \
     ISSUE_A(0, 0, 0) ISSUE_A(1, 0, 0) ISSUE_B(0, 0, 0) ISSUE_B(1, 0, 0) \
@@ -163,25 +168,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         wf[H][ni][0] = *reinterpret_cast<const X8*>(b_rd + (DB) * kDbuf + (H) * kHalf + ni * 2048 + c0);  \
         wf[H][ni][1] = *reinterpret_cast<const X8*>(b_rd + (DB) * kDbuf + (H) * kHalf + ni * 2048 + c1);  \
     }
-#define MMA(MH, NH)                                                                                    \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                   \
-        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                               \
-            _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                           \
-                acc[MH][mi][NH][ni] = Elem<T>::mfma16(wf[NH][ni][ks], af[mi][ks], acc[MH][mi][NH][ni]);
+#define MMA_K(MH, NH, KS)                                                                              \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                   \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                               \
+            acc[MH][mi][NH][ni] = Elem<T>::mfma16(wf[NH][ni][KS], af[mi][KS], acc[MH][mi][NH][ni]);
 #define SYNC()                                   \
     __builtin_amdgcn_sched_barrier(0);           \
     __builtin_amdgcn_s_barrier();                \
     __builtin_amdgcn_sched_barrier(0);
-#define COMPUTE(ON, MH, NH)                      \
+#define COMPUTE(ON, MH, NH, MID)                 \
     SYNC();                                      \
-    if (ON) {                                    \
-        __builtin_amdgcn_s_setprio(1);           \
-        MMA(MH, NH);                             \
-        __builtin_amdgcn_s_setprio(0);           \
-    }                                            \
+    __builtin_amdgcn_s_setprio(1);               \
+    if (ON) { MMA_K(MH, NH, 0) }                 \
+    __builtin_amdgcn_sched_barrier(0);           \
+    MID                                          \
+    __builtin_amdgcn_sched_barrier(0);           \
+    if (ON) { MMA_K(MH, NH, 1) }                 \
+    __builtin_amdgcn_s_setprio(0);               \
     SYNC();
 #define WAIT_TILE(NEXT_KT)                                                        \
-    if ((NEXT_KT) < nk || stream) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
+    if ((NEXT_KT) < nk || stream) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     constexpr bool res_in_acc = HAS_RES;   // linear epilogues only (dispatcher): the residual rides in the accumulator
@@ -273,19 +279,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         for (int it = 0; it < niter; ++it) {
             const int t0 = 2 * it, t1 = t0 + 1;
             const bool odd = t1 < nk;
-            // ---- K-tile t0 in dbuf 0 ---------------------------------------------------------------------------
-            READ_B(0, 0) READ_A(0, 0) ISSUE_A(1, 1, t1)                                      COMPUTE(true, 0, 0)   // phase 1
-            READ_B(1, 0)                                                                     COMPUTE(true, 0, 1)   // phase 2
-            READ_A(1, 0)              ISSUE_A(0, 0, t0 + 2) ISSUE_B(0, 0, t0 + 2)            COMPUTE(true, 1, 1)   // phase 3
-                                      ISSUE_B(1, 0, t0 + 2) WAIT_TILE(t0 + 2)                COMPUTE(true, 1, 0)   // phase 4
+            // ---- K-tile t0 in dbuf 0 (L segment: reads + piece 0;  MFMA segment: piece 1 between the k-steps) ------
+            READ_B(0, 0) READ_A(0, 0) ISSUE_A1(1, 1, t1, 0)
+                COMPUTE(true, 0, 0, ISSUE_A1(1, 1, t1, 1))                                                       // phase 1
+            READ_B(1, 0)
+                COMPUTE(true, 0, 1, )                                                                            // phase 2
+            READ_A(1, 0) ISSUE_A1(0, 0, t0 + 2, 0) ISSUE_B1(0, 0, t0 + 2, 0)
+                COMPUTE(true, 1, 1, ISSUE_A1(0, 0, t0 + 2, 1) ISSUE_B1(0, 0, t0 + 2, 1))                         // phase 3
+            ISSUE_B1(1, 0, t0 + 2, 0) WAIT_TILE(t0 + 2)
+                COMPUTE(true, 1, 0, ISSUE_B1(1, 0, t0 + 2, 1))                                                   // phase 4
             // ---- K-tile t1 in dbuf 1 ---------------------------------------------------------------------------
             if (odd) { READ_B(0, 1) READ_A(0, 1) }
-            ISSUE_A(1, 0, t0 + 2)                                                            COMPUTE(odd, 0, 0)    // phase 5
+            ISSUE_A1(1, 0, t0 + 2, 0)
+                COMPUTE(odd, 0, 0, ISSUE_A1(1, 0, t0 + 2, 1))                                                    // phase 5
             if (odd) { READ_B(1, 1) }
-                                                                                             COMPUTE(odd, 0, 1)    // phase 6
+                COMPUTE(odd, 0, 1, )                                                                             // phase 6
             if (odd) { READ_A(1, 1) }
-            ISSUE_A(0, 1, t1 + 2) ISSUE_B(0, 1, t1 + 2)                                      COMPUTE(odd, 1, 1)    // phase 7
-            ISSUE_B(1, 1, t1 + 2) WAIT_TILE(t1 + 2)                                          COMPUTE(odd, 1, 0)    // phase 8
+            ISSUE_A1(0, 1, t1 + 2, 0) ISSUE_B1(0, 1, t1 + 2, 0)
+                COMPUTE(odd, 1, 1, ISSUE_A1(0, 1, t1 + 2, 1) ISSUE_B1(0, 1, t1 + 2, 1))                          // phase 7
+            ISSUE_B1(1, 1, t1 + 2, 0) WAIT_TILE(t1 + 2)
+                COMPUTE(odd, 1, 0, ISSUE_B1(1, 1, t1 + 2, 1))                                                    // phase 8
         }
         STAMP(4)
         if (wr == 0) { SYNC(); }   // pair the trailing barrier of the staggered group: all LDS reads of this tile are done
@@ -397,10 +410,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
 #undef ISSUE_BIAS
 #undef ISSUE_A
 #undef ISSUE_B
+#undef ISSUE_A1
+#undef ISSUE_B1
 #undef ISSUE_PROLOGUE
 #undef READ_A
 #undef READ_B
-#undef MMA
+#undef MMA_K
 #undef SYNC
 #undef COMPUTE
 #undef WAIT_TILE
