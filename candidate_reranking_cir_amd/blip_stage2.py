@@ -128,13 +128,21 @@ class BLIP_NLVR(_EngineHost):
         return ops.gather_rows(t if t.dtype == torch.float32 else t.float(), None, self.compute_dtype)
 
     @torch.no_grad()
-    def score(self, z_t: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor, cand: torch.Tensor,
-              qidx: torch.Tensor, taps: Optional[list] = None) -> torch.Tensor:
+    def score(self, z_t: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor, cand: Optional[torch.Tensor],
+              qidx: torch.Tensor, taps: Optional[list] = None, kv_bank: Optional[list] = None,
+              cand_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Batched scoring: z_t (Q,L,D), ids/mask (Q,L) with [ENC] already set, cand (T,N,D),
-        qidx (T,) -> (T,) fp32 logits (column 0 of cls_head)."""
-        out = self.engines()[1].forward(input_ids, attention_mask, z_t.to(self.device), self._cand16(cand),
-                                        qidx.to(self.device), taps=taps)
+        qidx (T,) -> (T,) fp32 logits (column 0 of cls_head).  `kv_bank` + `cand_rows` score candidates
+        straight out of a per-image cross-attention K/V bank (`build_kv_bank`)."""
+        out = self.engines()[1].forward(input_ids, attention_mask, z_t.to(self.device),
+                                        self._cand16(cand) if kv_bank is None else None, qidx.to(self.device), taps=taps,
+                                        kv_bank=kv_bank, cand_rows=None if cand_rows is None else cand_rows.to(self.device))
         return out[:, 0]
+
+    @torch.no_grad()
+    def build_kv_bank(self, bank: torch.Tensor) -> list:
+        """Per-image, per-layer cross-attention K|V of an index-feature bank (n_index, N, D)."""
+        return self.engines()[1].build_kv_bank(self._cand16(bank))
 
     @torch.no_grad()
     def img_txt_fusion_val(self, r_image_embeds, t_image_embeds, text):

@@ -30,6 +30,7 @@ struct AttnArgs {
     const void* k; int64_t k_s1, k_s0, k_rs;
     const void* v; int64_t v_s1, v_s0, v_rs;
     const float* mask; int64_t m_s1, m_s0;
+    const int64_t* kv_index;   // optional: item b1 reads K/V of bank row kv_index[b1] (cross-query K/V cache)
     void* out; int64_t o_s1, o_s0, o_rs;
     int B0, H, Lq, Lk, nqt;
     int64_t total;
@@ -160,8 +161,9 @@ __global__ __launch_bounds__(512) void attn_shared_kernel(const AttnArgs a, int 
     t /= a.H;
     const int b0 = (int)(t % a.B0);
     const int64_t b1 = t / a.B0;
-    const T* kb = reinterpret_cast<const T*>(a.k) + b1 * a.k_s1 + b0 * a.k_s0 + h * 64;
-    const T* vb = reinterpret_cast<const T*>(a.v) + b1 * a.v_s1 + b0 * a.v_s0 + h * 64;
+    const int64_t kb1 = a.kv_index ? a.kv_index[b1] : b1;
+    const T* kb = reinterpret_cast<const T*>(a.k) + kb1 * a.k_s1 + b0 * a.k_s0 + h * 64;
+    const T* vb = reinterpret_cast<const T*>(a.v) + kb1 * a.v_s1 + b0 * a.v_s0 + h * 64;
     const float* mp = a.mask ? a.mask + b1 * a.m_s1 + b0 * a.m_s0 : nullptr;
 
     // ---- stage K (chunk ^ ((row>>1)&7): conflict-free 32x32x16 A-operand reads) and V (halves swapped on bit 1) ----
@@ -238,8 +240,9 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const AttnArgs a) {
     const int q0 = qt * 32;
     const int qrow = min(q0 + r, a.Lq - 1);
     const T* qp = reinterpret_cast<const T*>(a.q) + b1 * a.q_s1 + b0 * a.q_s0 + (int64_t)qrow * a.q_rs + h * 64 + 8 * hh;
-    const T* kb = reinterpret_cast<const T*>(a.k) + b1 * a.k_s1 + b0 * a.k_s0 + h * 64 + 8 * hh;
-    const T* vb = reinterpret_cast<const T*>(a.v) + b1 * a.v_s1 + b0 * a.v_s0 + h * 64;
+    const int64_t kb1 = a.kv_index ? a.kv_index[b1] : b1;
+    const T* kb = reinterpret_cast<const T*>(a.k) + kb1 * a.k_s1 + b0 * a.k_s0 + h * 64 + 8 * hh;
+    const T* vb = reinterpret_cast<const T*>(a.v) + kb1 * a.v_s1 + b0 * a.v_s0 + h * 64;
     const float* mp = a.mask ? a.mask + b1 * a.m_s1 + b0 * a.m_s0 : nullptr;
 
     X8 qf[4];
@@ -300,8 +303,8 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const AttnArgs a) {
 
 extern "C" int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t q_rs, const void* k, int64_t k_s1,
                              int64_t k_s0, int64_t k_rs, const void* v, int64_t v_s1, int64_t v_s0, int64_t v_rs,
-                             const float* mask, int64_t m_s1, int64_t m_s0, void* out, int64_t o_s1, int64_t o_s0,
-                             int64_t o_rs, int B1, int B0, int H, int Lq, int Lk, float scale, int dtype, void* stream) {
+                             const float* mask, int64_t m_s1, int64_t m_s0, const int64_t* kv_index, void* out, int64_t o_s1,
+                             int64_t o_s0, int64_t o_rs, int B1, int B0, int H, int Lq, int Lk, float scale, int dtype, void* stream) {
     using namespace cir;
     CIR_CHECK_PTR(q); CIR_CHECK_PTR(k); CIR_CHECK_PTR(v); CIR_CHECK_PTR(out);
     if (B1 <= 0 || B0 <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return CIR_EINVAL;
@@ -316,6 +319,7 @@ extern "C" int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t 
     a.k = k; a.k_s1 = k_s1; a.k_s0 = k_s0; a.k_rs = k_rs;
     a.v = v; a.v_s1 = v_s1; a.v_s0 = v_s0; a.v_rs = v_rs;
     a.mask = mask; a.m_s1 = m_s1; a.m_s0 = m_s0;
+    a.kv_index = kv_index;
     a.out = out; a.o_s1 = o_s1; a.o_s0 = o_s0; a.o_rs = o_rs;
     a.B0 = B0; a.H = H; a.Lq = Lq; a.Lk = Lk; a.nqt = (Lq + 31) / 32;
     a.total = (int64_t)B1 * B0 * H * a.nqt;

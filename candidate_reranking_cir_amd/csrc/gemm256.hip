@@ -207,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     ISSUE_PROLOGUE()
     ISSUE_BIAS()
     int pending_stores = 0;   // store instructions this wave issued after its newest loads (0 = unknown -> full drain)
-    int tile_no = 0;
+    [[maybe_unused]] int tile_no = 0;
 
     for (;;) {
         const int64_t cm0 = m0;

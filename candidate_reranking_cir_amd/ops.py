@@ -105,13 +105,18 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, scale: float,
-              mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+              mask: Optional[torch.Tensor] = None, kv_index: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q/out: (B1, B0, Lq, H*64) views, k/v: (B1, B0, Lk, H*64) views (any strides, unit last stride);
-    mask: additive fp32 (B1, B0, Lk) view or None.  Writes `out` and returns it."""
-    _need_cuda(q, k, v, out, mask)
+    mask: additive fp32 (B1, B0, Lk) view or None.  With `kv_index` (B1,) int64, k/v are banks
+    (rows, B0, Lk, H*64) and item b1 attends to bank row kv_index[b1].  Writes `out` and returns it."""
+    _need_cuda(q, k, v, out, mask, kv_index)
     b1, b0, lq, d = q.shape
     lk = k.shape[2]
-    assert d % 64 == 0 and k.shape == (b1, b0, lk, d) and v.shape == k.shape and out.shape == q.shape
+    if kv_index is None:
+        assert k.shape == (b1, b0, lk, d)
+    else:
+        assert kv_index.dtype == torch.int64 and kv_index.shape == (b1,) and kv_index.is_contiguous() and k.shape[1:] == (b0, lk, d)
+    assert d % 64 == 0 and v.shape == k.shape and out.shape == q.shape
     assert q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1 and out.stride(3) == 1
     assert q.dtype == k.dtype == v.dtype == out.dtype
     ms1 = ms0 = 0
@@ -120,7 +125,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
         ms1, ms0 = mask.stride(0), mask.stride(1)
     code = _lib.load().cir_attention(
         q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), k.data_ptr(), k.stride(0), k.stride(1), k.stride(2),
-        v.data_ptr(), v.stride(0), v.stride(1), v.stride(2), _ptr(mask), ms1, ms0,
+        v.data_ptr(), v.stride(0), v.stride(1), v.stride(2), _ptr(mask), ms1, ms0, _ptr(kv_index),
         out.data_ptr(), out.stride(0), out.stride(1), out.stride(2), b1, b0, d // 64, lq, lk, float(scale), _DT[q.dtype], _stream())
     _lib.check(code, "cir_attention")
     return out

@@ -88,9 +88,10 @@ def _length_buckets(ds: RelativeValSet, tokenizer, rows: Sequence[int]):
 
 @torch.no_grad()
 def generate_val_predictions(blip_model, model_stage1, ds: RelativeValSet, index_features: torch.Tensor,
-                             query_batch: int = 8, rows: Optional[Sequence[int]] = None):
+                             query_batch: int = 8, rows: Optional[Sequence[int]] = None, kv_bank: Optional[list] = None):
     """Logits (len(rows), K) [and (len(rows), 5) subset logits when `ds.group_index` is set].
-    `rows` selects a shard of the queries (default: all)."""
+    `rows` selects a shard of the queries (default: all).  `kv_bank` (blip_model.build_kv_bank(index_features))
+    re-uses the per-image cross-attention K/V across all queries instead of re-projecting every candidate."""
     dev = blip_model.device
     rows = list(range(len(ds))) if rows is None else list(rows)
     pos = {r: i for i, r in enumerate(rows)}
@@ -113,8 +114,13 @@ def generate_val_predictions(blip_model, model_stage1, ds: RelativeValSet, index
                 if ds.group_index is not None:
                     g = ds.group_index[q]
                     cand_rows.append(g); qidx += [j] * len(g); slots.append((pos[q], 1, len(g)))
-            cand = ops.gather_rows(index_features, torch.as_tensor(np.concatenate(cand_rows), device=dev))
-            out = blip_model.score(z.last_hidden_state, ids, mask, cand, torch.as_tensor(qidx, device=dev))
+            bank_rows = torch.as_tensor(np.concatenate(cand_rows), device=dev)
+            if kv_bank is None:
+                out = blip_model.score(z.last_hidden_state, ids, mask, ops.gather_rows(index_features, bank_rows),
+                                       torch.as_tensor(qidx, device=dev))
+            else:
+                out = blip_model.score(z.last_hidden_state, ids, mask, None, torch.as_tensor(qidx, device=dev),
+                                       kv_bank=kv_bank, cand_rows=bank_rows)
             o = 0
             for row, which, n in slots:
                 (glogits if which else logits)[row] = out[o:o + n]

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CIR_ABI_VERSION 1
+#define CIR_ABI_VERSION 2
 
 enum { CIR_BF16 = 0, CIR_F16 = 1, CIR_F32 = 2 };
 enum { CIR_ACT_NONE = 0, CIR_ACT_GELU = 1, CIR_ACT_RELU = 2 };
@@ -78,15 +78,17 @@ int cir_layernorm(const float* x, int64_t strideX, const float* residual, int64_
  * out = softmax(q k^T * scale + mask) v per (batch item, head), head_dim fixed at 64.
  *   Batch items are indexed (b1, b0), b1 < B1, b0 < B0; element (b1,b0,row,h,d) of q lives at
  *   q + b1*q_s1 + b0*q_s0 + row*q_rs + h*64 + d (same scheme for k, v, out); mask is an additive
- *   fp32 key mask (Lk) per item at mask + b1*m_s1 + b0*m_s0, or NULL.  16-bit in/out, fp32
- *   softmax.  Replaces BertSelfAttention.forward (nlvr_encoder.py:140-222, med.py:158-240: the
+ *   fp32 key mask (Lk) per item at mask + b1*m_s1 + b0*m_s0, or NULL.  kv_index (B1 int64, or NULL):
+ *   item b1 reads its K/V from row kv_index[b1] of k / v instead of row b1 - the candidates of a
+ *   query are then attended straight out of a per-image K/V bank (the cross-query reuse of
+ *   SURVEY section 8(f)-1) with no gather copy.  16-bit in/out, fp32 softmax.  Replaces BertSelfAttention.forward (nlvr_encoder.py:140-222, med.py:158-240: the
  *   transpose_for_scores / matmul / scale / mask / softmax / matmul / merge-heads sequence) and
  *   Attention.forward's core (vit.py:73-83).
  */
 int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t q_rs,
                   const void* k, int64_t k_s1, int64_t k_s0, int64_t k_rs,
                   const void* v, int64_t v_s1, int64_t v_s0, int64_t v_rs,
-                  const float* mask, int64_t m_s1, int64_t m_s0,
+                  const float* mask, int64_t m_s1, int64_t m_s0, const int64_t* kv_index,
                   void* out, int64_t o_s1, int64_t o_s0, int64_t o_rs,
                   int B1, int B0, int H, int Lq, int Lk, float scale, int dtype, void* stream);
 

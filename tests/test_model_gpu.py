@@ -138,6 +138,21 @@ def test_batch_invariance_and_api(tiny):
     assert bb.shape == (2, 2) and torch.allclose(bb[0], full[:2], atol=1e-6) and torch.allclose(bb[1], full[:2], atol=1e-6)
 
 
+def test_kv_bank_reuse_is_bit_identical(tiny):
+    """Cross-query reuse: scoring out of the per-image K/V bank gives exactly the logits of the
+    per-candidate projection (same kernel, same rows), including skip rows and the CIRR subset."""
+    from candidate_reranking_cir_amd import validate_stage2 as V
+    z, g, v, m2, m1, dt = tiny
+    bank = V.extract_index_features(synthetic.images(range(14), v.image_size), m2)
+    ds = V.RelativeValSet(ref_index=z["refs"], cand_index=z["cand_idx"], labels=z["labels"], captions=[str(c) for c in z["cirr_caps"]],
+                          group_index=z["groups"], target_index=z["targets"])
+    plain = V.generate_val_predictions(m2, m1, ds, bank, query_batch=3)
+    kvb = m2.build_kv_bank(bank)
+    assert len(kvb) == g.num_hidden_layers and kvb[0].shape == (14, v.num_tokens, 4 * g.hidden_size)
+    reuse = V.generate_val_predictions(m2, m1, ds, bank, query_batch=3, kv_bank=kvb)
+    assert torch.equal(plain[0], reuse[0]) and torch.equal(plain[1], reuse[1])
+
+
 def test_unfolded_merge_matches_folded(cuda):
     z = H.load("tiny_loop.npz")
     g, v = H.geometry(json.loads(str(z["bert_cfg"])), json.loads(str(z["vit_cfg"])))

@@ -267,3 +267,19 @@ def test_gather_rows(ops, src, dst):
     torch.cuda.synchronize()
     assert torch.equal(out, bank[idx].to(dst))
     assert torch.equal(ops.gather_rows(bank, None, dst), bank.to(dst))
+
+
+def test_attention_kv_bank_index(ops):
+    """kv_index: items attend to rows of a K/V bank (cross-query K/V cache) - equals gathering first."""
+    t, l, nk, h, rows = 6, 9, 37, 2, 4
+    d = h * 64
+    q = _rand((t, 2, l, d), torch.bfloat16, seed=1)
+    bank = _rand((rows, nk, 4, d), torch.bfloat16, seed=2)
+    idx = torch.tensor([3, 0, 0, 2, 1, 3], device="cuda")
+    k4, v4 = bank[:, :, 0::2].permute(0, 2, 1, 3), bank[:, :, 1::2].permute(0, 2, 1, 3)
+    out_a, out_b = torch.empty_like(q), torch.empty_like(q)
+    ops.attention(q, k4, v4, out_a, 0.125, kv_index=idx)
+    g = bank[idx]
+    ops.attention(q, g[:, :, 0::2].permute(0, 2, 1, 3), g[:, :, 1::2].permute(0, 2, 1, 3), out_b, 0.125)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b)
