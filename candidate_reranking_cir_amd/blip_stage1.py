@@ -1,9 +1,9 @@
 """Stage-I model surface used by the stage-II scoring loop: `BLIP_Retrieval.img_txt_fusion(...,
 train=False, return_raw=True)` produces z_t (reference: blip_stage1.py:67-92; called at
 validate_stage2.py:106, 244, 264).  State-dict layout = the reference's `["BLIP_Retrieval"]` entry
-(472 keys).  Only the text encoder runs here: the stage-II scripts feed it image tokens from the
-stage-II ViT (validate_stage2.py:139, 293); stage-I retrieval itself (validate.py) is SURVEY
-section 8(f) row 2 and not built yet.
+(472 keys).  The stage-II scripts feed the text encoder image tokens from the stage-II ViT
+(validate_stage2.py:139, 293); stage-I retrieval (validate.py) additionally
+uses this model's own ViT and the 256-d `vision_proj` / `text_proj` heads (blip_stage1.py:48-65, 83).
 """
 from __future__ import annotations
 
@@ -46,8 +46,24 @@ class BLIP_Retrieval(_EngineHost):
             dev = self.device
             if dev.type != "cuda":
                 raise RuntimeError("BLIP_Retrieval runs on an MI355X only: move the model to 'cuda' (no CPU path)")
-            self._engines = (MedEngine(self.state_dict(), self.bert_geometry, self.compute_dtype, dev),)
+            sd = self.state_dict()
+            f32 = lambda k: sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()
+            self._engines = (MedEngine(sd, self.bert_geometry, self.compute_dtype, dev),
+                             VitEngine(sd, self.vit_geometry, self.compute_dtype, dev),
+                             dict(vw=f32("vision_proj.weight"), vb=f32("vision_proj.bias"), tw=f32("text_proj.weight"), tb=f32("text_proj.bias")))
         return self._engines
+
+    @torch.no_grad()
+    def img_embed(self, image, atts=False, return_pool_and_normalized=False):
+        """blip_stage1.py:48-65: ViT tokens (B, N, D) fp32 [, normalised 256-d pooled features][, ones mask]."""
+        _, vit, heads = self.engines()
+        y32, _ = vit.forward(image.to(self.device), want32=True)
+        out = (y32,)
+        if return_pool_and_normalized:
+            out += (ops.l2_normalize(ops.linear_f32(y32[:, 0, :], heads["vw"], heads["vb"])),)
+        if atts:
+            out += (torch.ones(y32.shape[:-1], dtype=torch.long, device=y32.device),)
+        return out[0] if len(out) == 1 else out
 
     @torch.no_grad()
     def z_t(self, ref_tokens: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> EncoderOutput:
@@ -60,10 +76,16 @@ class BLIP_Retrieval(_EngineHost):
 
     @torch.no_grad()
     def img_txt_fusion(self, r_image_embeds, t_image_embeds, text, train=True, return_raw=False):
-        if train or not return_raw:
-            raise NotImplementedError("only img_txt_fusion(..., train=False, return_raw=True) is on the stage-II path")
+        """blip_stage1.py:67-92 in eval mode: `return_raw` -> z_t object (stage-II input); otherwise the normalised
+        256-d query feature `F.normalize(text_proj(z_t[:, 0]))` used by stage-I retrieval."""
+        if train:
+            raise NotImplementedError("forward only: the contrastive training branch (blip_stage1.py:88-92) is out of scope")
         ids, mask = encode_text(self.tokenizer, text, self.device)          # blip_stage1.py:72-73
-        return self.z_t(r_image_embeds, ids, mask)
+        z = self.z_t(r_image_embeds, ids, mask)
+        if return_raw:
+            return z
+        heads = self.engines()[2]
+        return ops.l2_normalize(ops.linear_f32(z.last_hidden_state[:, 0, :], heads["tw"], heads["tb"]))
 
 
 def blip_stage1(pretrained: str = "", **kwargs) -> BLIP_Retrieval:

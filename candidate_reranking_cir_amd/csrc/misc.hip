@@ -106,6 +106,65 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const TI* src, const i
     }
 }
 
+
+// ---- y = x W^T + bias (mode 0), 1 - x W^T (mode 1) or x W^T - 1 (mode 2 = the exact negative of mode 1), all fp32: the 256-d retrieval heads and the cosine-distance
+// matrix of stage I (validate.py:57, 202; blip_stage1.py:83).  A few GFLOP per split: a plain LDS-tiled FMA kernel. ----
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* x, int64_t ldx, const float* W, const float* bias, float* y,
+                                                        int64_t M, int N, int K, int mode) {
+    __shared__ float As[16][65], Ws[16][65];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int64_t row0 = (int64_t)blockIdx.y * 64;
+    const int col0 = blockIdx.x * 64;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + i * 256, r = e >> 4, kk = e & 15;
+            As[kk][r] = (row0 + r < M && k0 + kk < K) ? x[(row0 + r) * ldx + k0 + kk] : 0.f;
+            Ws[kk][r] = (col0 + r < N && k0 + kk < K) ? W[(int64_t)(col0 + r) * K + k0 + kk] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float av[4], wv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { av[i] = As[kk][ty * 4 + i]; wv[i] = Ws[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], wv[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = row0 + ty * 4 + i;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = col0 + tx * 4 + j;
+            if (n >= N) continue;
+            const float v = acc[i][j] + (bias ? bias[n] : 0.f);
+            y[m * N + n] = mode == 1 ? 1.0f - v : (mode == 2 ? v - 1.0f : v);
+        }
+    }
+}
+
+// ---- y = x / max(||x||_2, 1e-12) per row (F.normalize, blip_stage1.py:58, 83), one wave per row ----
+__global__ __launch_bounds__(256) void l2_normalize_kernel(const float* x, float* y, int64_t rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) { const float v = x[row * cols + c]; s = fmaf(v, v, s); }
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    for (int c = lane; c < cols; c += 64) y[row * cols + c] = x[row * cols + c] * inv;
+}
+
 // ---- descending argsort of one row per workgroup: bitonic network on (value, index) in LDS ------------------
 __global__ __launch_bounds__(256) void topk_desc_kernel(const float* logits, int64_t* idx, int K, int n_pow2) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
@@ -204,7 +263,7 @@ extern "C" int cir_small_linear(const void* x, int64_t ldx, const void* W, const
 extern "C" int cir_topk_desc(const float* logits, int64_t* idx, int Q, int K, void* stream) {
     CIR_CHECK_PTR(logits); CIR_CHECK_PTR(idx);
     if (Q <= 0 || K <= 0) return CIR_EINVAL;
-    if (K > 2048) return CIR_ESHAPE;
+    if (K > 8192) return CIR_ESHAPE;   // 8192 (value, index) pairs = 64 KiB of LDS: every index of the reference's datasets fits
     int n = 2;
     while (n < K) n <<= 1;
     dim3 grid((unsigned)Q), block(256);
@@ -240,4 +299,23 @@ extern "C" int cir_gather_rows(const void* src, int src_dtype, const int64_t* in
     CIR_G(CIR_F16, CIR_F32, _Float16, float)
 #undef CIR_G
     return CIR_EDTYPE;
+}
+
+extern "C" int cir_linear_f32(const float* x, int64_t ldx, const float* W, const float* bias, float* y, int64_t M, int N, int K,
+                              int mode, void* stream) {
+    CIR_CHECK_PTR(x); CIR_CHECK_PTR(W); CIR_CHECK_PTR(y);
+    if (M <= 0 || N <= 0 || K <= 0) return CIR_EINVAL;
+    if (mode < 0 || mode > 2) return CIR_EINVAL;
+    dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), block(256);
+    if (grid.y > 65535u * 16u) return CIR_ESHAPE;
+    hipLaunchKernelGGL(cir::linear_f32_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), x, ldx, W, bias, y, M, N, K, mode);
+    CIR_LAUNCH_RESULT();
+}
+
+extern "C" int cir_l2_normalize(const float* x, float* y, int64_t rows, int cols, void* stream) {
+    CIR_CHECK_PTR(x); CIR_CHECK_PTR(y);
+    if (rows <= 0 || cols <= 0) return CIR_EINVAL;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipLaunchKernelGGL(cir::l2_normalize_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), x, y, rows, cols);
+    CIR_LAUNCH_RESULT();
 }

@@ -35,6 +35,8 @@ SIGNATURES = {
     "cir_small_linear": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "cir_gather_rows": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p]),
     "cir_topk_desc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "cir_linear_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "cir_l2_normalize": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
 }
 
 _lib = None

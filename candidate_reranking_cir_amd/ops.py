@@ -206,3 +206,25 @@ def gather_rows(src: torch.Tensor, index: Optional[torch.Tensor], dtype: Optiona
                                        src.shape[0], _stream())
     _lib.check(code, "cir_gather_rows")
     return dst
+
+
+def linear_f32(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, mode: int = 0) -> torch.Tensor:
+    """fp32 y = x @ w.T + bias (mode 0), 1 - x @ w.T (mode 1: cosine distance) or x @ w.T - 1 (mode 2: its exact
+    negative); x rows may be strided."""
+    _need_cuda(x, w, bias)
+    assert x.dtype == torch.float32 and w.dtype == torch.float32 and x.stride(1) == 1 and w.is_contiguous()
+    m, k = x.shape
+    n = w.shape[0]
+    y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    code = _lib.load().cir_linear_f32(x.data_ptr(), x.stride(0), w.data_ptr(), _ptr(bias), y.data_ptr(), m, n, k, mode, _stream())
+    _lib.check(code, "cir_linear_f32")
+    return y
+
+
+def l2_normalize(x: torch.Tensor) -> torch.Tensor:
+    _need_cuda(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    code = _lib.load().cir_l2_normalize(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], _stream())
+    _lib.check(code, "cir_l2_normalize")
+    return y

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CIR_ABI_VERSION 2
+#define CIR_ABI_VERSION 3
 
 enum { CIR_BF16 = 0, CIR_F16 = 1, CIR_F32 = 2 };
 enum { CIR_ACT_NONE = 0, CIR_ACT_GELU = 1, CIR_ACT_RELU = 2 };
@@ -134,9 +134,22 @@ int cir_gather_rows(const void* src, int src_dtype, const int64_t* index, void* 
 
 /*
  * Per-row descending argsort (validate_stage2.py:53,174,188: torch.argsort(..., descending=True)):
- *   idx[q][j] = index of the j-th largest logit of row q, ties broken by lower index.  K <= 2048.
+ *   idx[q][j] = index of the j-th largest logit of row q, ties broken by lower index.  K <= 8192
+ *   (also ranks a whole index for stage I: validate.py:58, 203 sort ascending distances = descending -distance).
  */
 int cir_topk_desc(const float* logits, int64_t* idx, int Q, int K, void* stream);
+
+/*
+ * fp32 y (M,N) = x (M,K) W(N,K)^T + bias (mode 0), 1 - x W^T (mode 1) or x W^T - 1 (mode 2, the exact
+ * negative of mode 1, so that cir_topk_desc ranks by ascending distance): stage I's 256-d heads
+ * vision_proj / text_proj (blip_stage1.py:42-43, 58, 83) and its distance matrix
+ * `1 - predicted_features @ index_features.T` (validate.py:57, 202).  x rows at stride ldx.
+ */
+int cir_linear_f32(const float* x, int64_t ldx, const float* W, const float* bias, float* y,
+                   int64_t M, int N, int K, int mode, void* stream);
+
+/* y = x / max(||x||_2, 1e-12) row-wise, fp32 (F.normalize at blip_stage1.py:58, 83). */
+int cir_l2_normalize(const float* x, float* y, int64_t rows, int cols, void* stream);
 
 #ifdef __cplusplus
 }

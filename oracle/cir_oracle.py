@@ -278,3 +278,42 @@ def group_recall_at(group_logits: torch.Tensor, group_members: np.ndarray, targe
     names = np.take_along_axis(group_members, order, axis=1)
     lab = torch.tensor(names == np.repeat(np.asarray(targets), group_members.shape[1]).reshape(len(targets), -1))
     return [(torch.sum(lab[:, :k]) / len(lab)).item() * 100 for k in ks]
+
+
+# ----------------------------------------------------------------------------------------------
+# stage-I retrieval + top-K (validate.py) and CIRR test dicts (cirr_test_submission_stage2.py)
+# ----------------------------------------------------------------------------------------------
+def stage1_img_embed(w1: Weights, image: torch.Tensor):
+    """BLIP_Retrieval.img_embed(..., return_pool_and_normalized=True), blip_stage1.py:48-65."""
+    tokens = vit_forward(w1, image)
+    pooled = F.normalize(F.linear(tokens[:, 0, :], w1["vision_proj.weight"], w1["vision_proj.bias"]), dim=-1)
+    return tokens, pooled
+
+
+def stage1_query_features(w1: Weights, ref_tokens: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor):
+    """BLIP_Retrieval.img_txt_fusion(..., train=False), blip_stage1.py:67-88: normalised text_proj of z_t's CLS row."""
+    z = stage1_z_t(w1, ref_tokens, input_ids, attention_mask)
+    return F.normalize(F.linear(z[:, 0, :], w1["text_proj.weight"], w1["text_proj.bias"]), dim=-1)
+
+
+def rank_index(predicted: torch.Tensor, index_pooled: torch.Tensor) -> np.ndarray:
+    """validate.py:57-58 / 202-203: argsort of `1 - predicted @ index.T` (ascending)."""
+    distances = 1 - predicted @ index_pooled.float().T
+    return torch.argsort(distances, dim=-1).cpu().numpy()
+
+
+def cirr_drop_reference(sorted_rows: np.ndarray, ref_index: np.ndarray) -> np.ndarray:
+    """validate.py:206-210: remove the reference image from every ranking."""
+    keep = sorted_rows != np.asarray(ref_index)[:, None]
+    return sorted_rows[keep].reshape(sorted_rows.shape[0], sorted_rows.shape[1] - 1)
+
+
+def cirr_test_dicts(logits: torch.Tensor, group_logits: torch.Tensor, cand_names: np.ndarray, group_names: np.ndarray, pair_ids):
+    """cirr_test_submission_stage2.py:92-108: top-50 names by descending logit, top-3 subset names."""
+    order = torch.argsort(logits, dim=-1, descending=True).cpu().numpy()
+    names = np.take_along_axis(cand_names, order, axis=1)
+    gorder = torch.argsort(group_logits, dim=-1, descending=True).cpu().numpy()
+    gnames = np.take_along_axis(group_names, gorder, axis=1)
+    rec = {str(int(p)): row[:50].tolist() for p, row in zip(pair_ids, names)}
+    sub = {str(int(p)): row[:3].tolist() for p, row in zip(pair_ids, gnames)}
+    return rec, sub

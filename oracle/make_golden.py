@@ -18,6 +18,8 @@ and `.weights`, so fixtures hold only seeds, small input checksums and the refer
                   (utils.py:25-55, hard-coded 577 tokens) + `compute_cirr_val_metrics`.
   metrics.npz     `compute_fiq_val_metrics` / `compute_cirr_val_metrics` arithmetic on large
                   synthetic (Q,K) logit/label matrices (prediction generators stubbed out).
+  stage1_tiny.npz stage-I retrieval (validate.py) incl. the top-K files the reference writes itself, and the
+                  CIRR test-split prediction dicts of cirr_test_submission_stage2.py (`make_golden.py stage1`).
 """
 from __future__ import annotations
 
@@ -162,8 +164,123 @@ def loop_case(n_index, n_q, k, seed, n_words):
                 cirr_caps=cirr_caps, fiq_caps=fiq_caps)
 
 
+class FakeStage1FIQ:
+    """FashionIQDataset('val', [t], 'relative') in stage-I mode: item layout of data_utils.py:210-213."""
+
+    def __init__(self, names, refs, targets, captions):
+        self.names, self.refs, self.targets, self.captions = names, refs, targets, captions
+        self.dress_types = ["dress"]
+        self.split = "val"
+
+    def __len__(self):
+        return len(self.refs)
+
+    def __getitem__(self, i):
+        return self.names[self.refs[i]], self.names[self.targets[i]], self.captions[i]
+
+
+class FakeStage1CIRR(FakeStage1FIQ):
+    """CIRRDataset('val', 'relative') in stage-I mode: item layout of data_utils.py:337-340 (6 group members)."""
+
+    def __init__(self, names, refs, targets, captions, groups):
+        super().__init__(names, refs, targets, captions)
+        self.groups = groups
+
+    def __getitem__(self, i):
+        members = [self.names[self.refs[i]]] + [self.names[j] for j in self.groups[i]]
+        return self.names[self.refs[i]], self.names[self.targets[i]], self.captions[i], members
+
+
+class FakeCIRRTest:
+    """CIRRDataset('test1', 'relative', load_topk=..., K=...): item layout of data_utils.py:342-346."""
+
+    def __init__(self, names, pair_ids, refs, captions, groups, cand_idx):
+        self.names, self.pair_ids, self.refs, self.captions, self.groups = names, pair_ids, refs, captions, groups
+        self.K_sorted_index_names = np.array(names)[cand_idx]
+        self.K = cand_idx.shape[1]
+        self.split = "test1"
+
+    def __len__(self):
+        return len(self.refs)
+
+    def __getitem__(self, i):
+        members = [self.names[self.refs[i]]] + [self.names[j] for j in self.groups[i]]
+        return self.pair_ids[i], self.names[self.refs[i]], self.captions[i], members, self.K_sorted_index_names[i].tolist()
+
+
+def stage1_goldens(R):
+    """tests/golden/stage1_tiny.npz: the reference's stage-I retrieval (validate.py) incl. the top-K FILES it writes
+    itself (SAVE_TOPK branch with the manual `breakpoint()` gate stubbed), and its CIRR test-split prediction dicts
+    (cirr_test_submission_stage2.py:74-108)."""
+    import builtins
+    cwd = os.getcwd()
+    os.chdir(ref_shim.REFERENCE_ROOT)
+    import validate as ref_v1                       # reference src/validate.py
+    import cirr_test_submission_stage2 as ref_sub   # reference src/cirr_test_submission_stage2.py
+    os.chdir(cwd)
+    m2, m1, g, v = build_reference_models(R, TINY_BERT, TINY_VIT, seed=11, profile="test")
+    n_index, n_q, k = 14, 8, 6
+    case = loop_case(n_index=n_index, n_q=n_q, k=k, seed=5, n_words=6)
+    rng = np.random.RandomState(17)
+    caps_cirr = [synthetic.caption_text(400 + q, int(rng.randint(3, 9))) for q in range(n_q)]      # ragged -> padded batches
+    caps_fiq = [(synthetic.caption_text(500 + q, 3) + ".", " " + synthetic.caption_text(600 + q, int(rng.randint(2, 6))) + "?") for q in range(n_q)]
+    targets = np.array([(r + 1 + int(rng.randint(n_index - 1))) % n_index for r in case["refs"]])
+    targets = np.where(targets == case["refs"], (targets + 1) % n_index, targets)
+    groups = []
+    for q in range(n_q):
+        others = [j for j in rng.permutation(n_index) if j != case["refs"][q] and j != targets[q]][:4]
+        groups.append(np.array([targets[q]] + others)[rng.permutation(5)])
+    groups = np.stack(groups)
+    imgs = synthetic.images(range(n_index), v.image_size)
+    with torch.no_grad():
+        feats1, pooled = m1.img_embed(imgs, return_pool_and_normalized=True)
+    tmp = tempfile.mkdtemp()
+    ref_v1.SAVE_TOPK, ref_v1.K_VALUE, ref_v1.STAGE1_PATH = True, k, os.path.join(tmp, "a", "b", "ckpt.pt")
+    os.makedirs(os.path.join(tmp, "a"), exist_ok=True)
+    saved_bp = builtins.breakpoint
+    builtins.breakpoint = lambda *a, **kw: None
+    try:
+        fiq_ds = FakeStage1FIQ(case["names"], case["refs"], targets, caps_fiq)
+        fiq_metrics = ref_v1.compute_fiq_val_metrics(fiq_ds, m1, feats1, pooled, case["names"])
+        fiq_pred, _ = ref_v1.generate_fiq_val_predictions(m1, fiq_ds, case["names"], feats1)
+        cirr_ds = FakeStage1CIRR(case["names"], case["refs"], targets, caps_cirr, groups)
+        cirr_metrics = ref_v1.compute_cirr_val_metrics(cirr_ds, m1, feats1, pooled, case["names"])
+        cirr_pred, *_ = ref_v1.generate_cirr_val_predictions(m1, cirr_ds, case["names"], feats1)
+    finally:
+        builtins.breakpoint = saved_bp
+    fiq_file = torch.load(os.path.join(tmp, "a", f"fiq_top_{k}_val_dress.pt"), weights_only=False)
+    cirr_file = torch.load(os.path.join(tmp, "a", f"cirr_top_{k}_val.pt"), weights_only=False)
+    # CIRR test-split dicts through stage II, candidates = the stage-I top-K of the reference
+    with torch.no_grad():
+        feats2 = m2.img_embed(imgs)
+    row_of = {n: i for i, n in enumerate(case["names"])}
+    cand_idx = np.vectorize(row_of.__getitem__)(cirr_file["sorted_index_names"])
+    pair_ids = np.arange(1000, 1000 + n_q)
+    test_ds = FakeCIRRTest(case["names"], pair_ids, case["refs"], caps_cirr, groups, cand_idx)
+    d_rec, d_sub = ref_sub.generate_cirr_test_dicts(test_ds, m2, m1, feats2, case["names"])
+    np.savez_compressed(
+        os.path.join(OUT, "stage1_tiny.npz"), bert_cfg=json.dumps(TINY_BERT), vit_cfg=json.dumps(TINY_VIT), seed=11, profile="test", k=k,
+        refs=case["refs"], targets=targets, groups=groups, cirr_caps=np.array(caps_cirr), fiq_caps=np.array(caps_fiq),
+        pooled=pooled.numpy(), tokens_slice=feats1[:, :3, :8].numpy(), fiq_pred=fiq_pred.numpy(), cirr_pred=cirr_pred.numpy(),
+        fiq_metrics=np.array(fiq_metrics), cirr_metrics=np.array(cirr_metrics),
+        fiq_file_names=np.asarray(fiq_file["sorted_index_names"]), fiq_file_labels=np.asarray(fiq_file["labels"]),
+        fiq_file_targets=np.array(fiq_file["target_names"]), fiq_file_split=str(fiq_file["split"]), fiq_file_dress=str(fiq_file["dress_types"]),
+        cirr_file_names=np.asarray(cirr_file["sorted_index_names"]), cirr_file_labels=np.asarray(cirr_file["labels"]),
+        cirr_file_group_labels=np.asarray(cirr_file["group_labels"]), cirr_file_split=str(cirr_file["split"]),
+        index_names=np.array(case["names"]), pair_ids=pair_ids,
+        test_recall_json=json.dumps(d_rec, sort_keys=True), test_subset_json=json.dumps(d_sub, sort_keys=True))
+    print("stage1_tiny: fiq", fiq_metrics, "cirr", cirr_metrics)
+    print("   test dicts", list(d_rec.items())[:2], list(d_sub.items())[:2])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "stage1":   # only the stage-I / submission fixtures
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        R = ref_shim.load_reference_modules()
+        _install_torchvision_stub()
+        return stage1_goldens(R)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     R = ref_shim.load_reference_modules()
@@ -276,6 +393,7 @@ def main():
             print("full384 logits", c_logits.numpy().round(4))
             del m2b, m1b
         del m2, m1
+    stage1_goldens(R)
 
 
 if __name__ == "__main__":
