@@ -11,6 +11,7 @@ nlvr_encoder.py:414-476 / 777-908, blip_stage2.py:101-136.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -174,6 +175,7 @@ class NlvrEngine:
     def __init__(self, sd: SD, geo: BertGeometry, dtype: torch.dtype, device, prefix: str = "text_encoder.", fold_merge: bool = True):
         geo.validate()
         self.geo, self.dtype, self.device, self.fold_merge = geo, dtype, device, fold_merge
+        self.kv_chunk = int(os.environ.get("CIR_KV_CHUNK", "0"))   # candidates per K|V + cross-attention chunk (0 = all at once)
         e = prefix + "embeddings."
         self.word, self.posemb = _f32(sd[e + "word_embeddings.weight"], device), _f32(sd[e + "position_embeddings.weight"], device)
         self.ge, self.be = _f32(sd[e + "LayerNorm.weight"], device), _f32(sd[e + "LayerNorm.bias"], device)
@@ -291,13 +293,18 @@ class NlvrEngine:
                 a32, a16 = self._self_block(ly, h32, h16, t_n, l, smask)
             qc = ops.gemm(a16, ly["wq"], ly["bq"]).view(2, t_n, l, d).permute(1, 0, 2, 3)               # (T, 2, L, D) view
             if kv_bank is None:
-                kv = ops.gemm(cand2, ly["wkv"], ly["bkv"]).view(t_n, n, 4, d)                             # [K0 V0 K1 V1]
-                kidx = None
+                # K|V projection + cross-attention in candidate chunks: the chunk's K|V (chunk * N * 4D * 2 B) is consumed
+                # by the attention right after it is produced, while it still sits in the 256 MiB Infinity Cache
+                step_c = self.kv_chunk if self.kv_chunk > 0 else t_n
+                for c0 in range(0, t_n, step_c):
+                    c1 = min(c0 + step_c, t_n)
+                    kv = ops.gemm(cand2[c0 * n:c1 * n], ly["wkv"], ly["bkv"]).view(c1 - c0, n, 4, d)     # [K0 V0 K1 V1]
+                    ops.attention(qc[c0:c1], kv[:, :, 0::2].permute(0, 2, 1, 3), kv[:, :, 1::2].permute(0, 2, 1, 3),
+                                  cc[c0:c1].permute(0, 2, 1, 3), scale, None if emask is None else emask[c0:c1])   # nlvr_encoder.py:321-344
             else:
                 kv = kv_bank[i].view(-1, n, 4, d)                                                         # (n_index, N, 4, D) bank
-                kidx = cand_rows
-            ops.attention(qc, kv[:, :, 0::2].permute(0, 2, 1, 3), kv[:, :, 1::2].permute(0, 2, 1, 3),
-                          cc.permute(0, 2, 1, 3), scale, emask, kv_index=kidx)                            # nlvr_encoder.py:321-344
+                ops.attention(qc, kv[:, :, 0::2].permute(0, 2, 1, 3), kv[:, :, 1::2].permute(0, 2, 1, 3),
+                              cc.permute(0, 2, 1, 3), scale, emask, kv_index=cand_rows)
             if "wd" in ly:                                                                                # unfolded merge_layer
                 dd = torch.empty((r, 2, d), dtype=dt, device=cc.device)
                 ops.gemm(cc.view(r, 2, d).permute(1, 0, 2), ly["wd"], ly["bd"], out=dd.permute(1, 0, 2))

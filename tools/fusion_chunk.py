@@ -1,0 +1,25 @@
+"""A/B of the K|V + cross-attention chunk size inside the fusion (GPU box only)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from candidate_reranking_cir_amd import config, synthetic
+from candidate_reranking_cir_amd.blip_stage1 import BLIP_Retrieval
+from candidate_reranking_cir_amd.blip_stage2 import BLIP_NLVR
+dev = torch.device("cuda")
+g, v = config.BertGeometry(), config.VitGeometry(image_size=224)
+m2 = BLIP_NLVR(med_config=g, vit_geometry=v).to(dev).eval()
+m1 = BLIP_Retrieval(med_config=g, vit_geometry=v).to(dev).eval()
+q_n, k = 16, 100
+toks = torch.randn((q_n + q_n * k, 197, 768), device=dev).bfloat16()
+ids = torch.stack([synthetic.caption_ids(q, 32) for q in range(q_n)]).to(dev); mask = torch.ones_like(ids)
+qidx = torch.arange(q_n, device=dev).repeat_interleave(k)
+z = m1.z_t(toks[:q_n], ids, mask)
+eng = m2.engines()[1]
+for rep in range(2):
+    for chunk in (0, 800, 400, 256, 128, 64):
+        eng.kv_chunk = chunk
+        for _ in range(2): m2.score(z.last_hidden_state, ids, mask, toks[q_n:], qidx)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(4): m2.score(z.last_hidden_state, ids, mask, toks[q_n:], qidx)
+        torch.cuda.synchronize()
+        print(f"kv_chunk={chunk:4d}: fusion {(time.perf_counter()-t0)/4*1e3:7.2f} ms", flush=True)
