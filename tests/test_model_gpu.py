@@ -153,6 +153,24 @@ def test_kv_bank_reuse_is_bit_identical(tiny):
     assert torch.equal(plain[0], reuse[0]) and torch.equal(plain[1], reuse[1])
 
 
+def test_last_layer_cls_trimming_is_equivalent(tiny):
+    """The last layer's per-token work on CLS rows only gives the logits of the untrimmed schedule (same rows, same
+    kernels up to the tile variant; bias enters the accumulator first or last)."""
+    z, g, v, m2, m1, dt = tiny
+    feats = m2.img_embed(synthetic.images(range(9), v.image_size).cuda())
+    cap = [str(z["cirr_caps"][3])]
+    zt = m1.img_txt_fusion(feats[:1], None, cap, train=False, return_raw=True)
+    eng = m2.engines()[1]
+    assert eng.trim_last
+    a = m2.img_txt_fusion_val(zt, feats[1:], cap)
+    eng.trim_last = False
+    try:
+        b = m2.img_txt_fusion_val(zt, feats[1:], cap)
+    finally:
+        eng.trim_last = True
+    assert torch.allclose(a, b, atol=2e-5, rtol=0)
+
+
 def test_unfolded_merge_matches_folded(cuda):
     z = H.load("tiny_loop.npz")
     g, v = H.geometry(json.loads(str(z["bert_cfg"])), json.loads(str(z["vit_cfg"])))
