@@ -24,16 +24,19 @@ from .param_tree import ParamNode, populate
 from .synthetic import HashTokenizer
 from .weights import nlvr_param_spec
 
-_PKG_CONFIG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "med_config.json")
-
-
 def load_bert_geometry(med_config) -> BertGeometry:
+    """`med_config` is a path to a JSON file with the reference's keys (blip_stage2.py:46-47 reads
+    configs/med_config.json: hidden_size, num_attention_heads, num_hidden_layers, intermediate_size, layer_norm_eps,
+    vocab_size, max_position_embeddings), a dict, or a BertGeometry.  When the reference's default relative path is
+    given but no such file exists in the working directory, the built-in BERT-base/BLIP geometry is used."""
     if isinstance(med_config, BertGeometry):
         return med_config
     if isinstance(med_config, dict):
         return BertGeometry.from_dict(med_config)
     if not os.path.isfile(med_config) and med_config == "configs/med_config.json":
-        med_config = _PKG_CONFIG  # same default path as the reference, resolved next to the package
+        g = BertGeometry()   # defaults = the reference's med_config.json values
+        g.validate()
+        return g
     return BertGeometry.from_json_file(med_config)
 
 
