@@ -1,7 +1,7 @@
 """Shared helpers with the reference's names (src/blip.py): `init_tokenizer` and `create_vit`.
 
 `init_tokenizer` (blip.py:186-191) needs the `bert-base-uncased` WordPiece vocabulary, which cannot be downloaded in an
-offline build: pass a local `vocab.txt` (or rely on a populated HuggingFace cache); without either the deterministic
+offline build: pass a local directory holding `vocab.txt` (or rely on a populated HuggingFace cache); without either the deterministic
 `synthetic.HashTokenizer` double is returned when `allow_fallback=True` (what tests and the benchmark use).
 """
 from __future__ import annotations
@@ -17,7 +17,7 @@ def init_tokenizer(vocab_file: Optional[str] = None, allow_fallback: bool = Fals
     """BertTokenizer + '[DEC]' (bos) + '[ENC]' with `.enc_token_id`, exactly as blip.py:186-191."""
     try:
         from transformers import BertTokenizer
-        tok = BertTokenizer(vocab_file=vocab_file) if vocab_file else BertTokenizer.from_pretrained("bert-base-uncased", local_files_only=True)
+        tok = BertTokenizer.from_pretrained(vocab_file or "bert-base-uncased", local_files_only=True)   # directory / cache with vocab.txt
     except Exception as exc:  # no vocabulary available offline
         if allow_fallback:
             return HashTokenizer()
