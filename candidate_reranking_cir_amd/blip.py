@@ -18,6 +18,8 @@ def init_tokenizer(vocab_file: Optional[str] = None, allow_fallback: bool = Fals
     try:
         from transformers import BertTokenizer
         tok = BertTokenizer.from_pretrained(vocab_file or "bert-base-uncased", local_files_only=True)   # directory / cache with vocab.txt
+        if tok.vocab_size < 30000:   # transformers >= 5 builds an EMPTY tokenizer instead of failing when nothing is cached
+            raise FileNotFoundError("bert-base-uncased vocabulary (30522 entries) not found")
     except Exception as exc:  # no vocabulary available offline
         if allow_fallback:
             return HashTokenizer()
