@@ -65,7 +65,7 @@ class VitEngine:
                 w2=_w16(sd[b + "mlp.fc2.weight"], dtype, device), c2=_f32(sd[b + "mlp.fc2.bias"], device)))
         self.gf, self.bf = _f32(sd[p + "norm.weight"], device), _f32(sd[p + "norm.bias"], device)
 
-    def forward(self, image: torch.Tensor, want32: bool = False, chunk: int = 1024):
+    def forward(self, image: torch.Tensor, want32: bool = False, chunk: int = 2048):
         """(B,3,H,W) fp32/16-bit -> tokens (B, N, D): 16-bit always, fp32 too if `want32`."""
         if image.shape[0] > chunk:
             n_parts = -(-image.shape[0] // chunk)

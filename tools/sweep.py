@@ -1,4 +1,4 @@
-"""Throughput sweep over queries-per-step and ViT chunk size (GPU box only)."""
+"""Throughput sweep over queries-per-step and ViT chunk size on one box (GPU box only)."""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,24 +11,21 @@ g, v = config.BertGeometry(), config.VitGeometry(image_size=224)
 m2 = BLIP_NLVR(med_config=g, vit_geometry=v).to(dev).eval()
 m1 = BLIP_Retrieval(med_config=g, vit_geometry=v).to(dev).eval()
 k = 100
-for q_n, chunk in [(8, 101), (8, 202), (8, 404), (8, 808), (16, 404), (16, 808), (16, 1616), (32, 808)]:
-    images = torch.randn((q_n + q_n * k, 3, 224, 224), device=dev).bfloat16()
-    ids = torch.stack([synthetic.caption_ids(q, 32) for q in range(q_n)]).to(dev)
-    mask = torch.ones_like(ids)
-    qidx = torch.arange(q_n, device=dev).repeat_interleave(k)
-    def step():
-        toks = m2.engines()[0].forward(images, want32=False, chunk=chunk)[1]
-        z = m1.z_t(toks[:q_n], ids, mask)
-        return m2.score(z.last_hidden_state, ids, mask, toks[q_n:], qidx)
-    step(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3): step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 3
-    # split: vit only
-    t0 = time.perf_counter()
-    for _ in range(3): m2.engines()[0].forward(images, want32=False, chunk=chunk)
-    torch.cuda.synchronize()
-    dv = (time.perf_counter() - t0) / 3
-    print(f"Q={q_n:3d} chunk={chunk:5d}: {dt*1e3:8.2f} ms/step  {q_n*k/dt:9.1f} triplets/s   vit {dv*1e3:7.2f} ms ({(q_n+q_n*k)/dv:8.1f} img/s)  rest {(dt-dv)*1e3:7.2f} ms", flush=True)
-    del images
+cases = [(16, 1024), (16, 332), (16, 664), (16, 1616), (13, 664), (20, 1024), (20, 674), (24, 1024), (24, 808), (32, 1024)]
+for rep in range(2):
+    for q_n, chunk in cases:
+        images = torch.randn((q_n + q_n * k, 3, 224, 224), device=dev).bfloat16()
+        ids = torch.stack([synthetic.caption_ids(q, 32) for q in range(q_n)]).to(dev)
+        mask = torch.ones_like(ids)
+        qidx = torch.arange(q_n, device=dev).repeat_interleave(k)
+        def step():
+            toks = m2.engines()[0].forward(images, want32=False, chunk=chunk)[1]
+            z = m1.z_t(toks[:q_n], ids, mask)
+            return m2.score(z.last_hidden_state, ids, mask, toks[q_n:], qidx)
+        step(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3): step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        print(f"Q={q_n:3d} chunk={chunk:5d}: {dt*1e3:8.2f} ms/step  {q_n*k/dt:9.1f} triplets/s", flush=True)
+        del images
