@@ -4,8 +4,9 @@
 // (K = 768 -> 12 K-tiles), so the per-tile fixed cost matters as much as the main loop:
 //   * the next tile's first K-tile is requested (LDS-DMA) BEFORE the current tile's epilogue, so its
 //     HBM/L2 latency hides behind the epilogue's VALU work and store issue;
-//   * bias (and, for linear epilogues, the fp32 residual) initialise the accumulators, so the epilogue
-//     itself issues no loads: activation, 16-bit pack, 16-byte stores that drain during the next main loop.
+//   * the bias initialises the accumulators; the epilogue is activation, pack, an LDS transposition to whole output
+//     rows, the fp32 residual (fetched row-contiguously two passes ahead) and 16-byte stores that drain during the
+//     next main loop.
 //
 // Main-loop schedule (after the 8-phase structure of the CDNA4 programming guide, re-derived with
 // conservative hazards; see DESIGN.md "GEMM"):
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     if ((NEXT_KT) < nk || stream) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    constexpr bool res_in_acc = HAS_RES;   // linear epilogues only (dispatcher): the residual rides in the accumulator
+    static_assert(!HAS_RES || OUT_F32, "the residual is added in the fp32 row layout of the epilogue");
 
     // bias of the tile arrives by LDS-DMA into a private 1-KiB slot per wave (no VGPR-destination loads on the
     // tile boundary: the compiler would answer those with vmcnt(0), which also waits for the previous tile's stores)
@@ -219,11 +220,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         stream = false;   // the prologue of THIS tile must not be mistaken for a streamed one while waiting below
         STAMP(0)
         // ---- operands of the first K-tile(s) and the bias have landed; the previous tile's stores may still fly ------
-        if (res_in_acc || pending_stores == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (pending_stores == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (pending_stores == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         STAMP(1)
-        // ---- accumulators start at bias (+ residual): the epilogue then needs no loads --------------------------
+        // ---- accumulators start at the bias ----------------------------------------------------------------------------
         {
             float bias[2][8];
             if (a.bias != nullptr) {
@@ -243,23 +244,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) {
-                    const int64_t m = cm0 + mh * 128 + wr * 64 + mi * 16 + r15;
+                for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                     for (int nh = 0; nh < 2; ++nh) {
-                        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-                        const int nb = cn0 + wc * 64 + nh * 32 + g * 8;
-                        if constexpr (res_in_acc) if (m < a.M && nb + 8 <= a.N) {
-                            const float4* rp = reinterpret_cast<const float4*>(a.R + cz * a.sR + m * a.ldr + nb);
-                            r0 = rp[0];
-                            r1 = rp[1];
-                        }
-                        acc[mh][mi][nh][0] = f32x4{bias[nh][0] + r0.x, bias[nh][1] + r0.y, bias[nh][2] + r0.z, bias[nh][3] + r0.w};
-                        acc[mh][mi][nh][1] = f32x4{bias[nh][4] + r1.x, bias[nh][5] + r1.y, bias[nh][6] + r1.z, bias[nh][7] + r1.w};
+                        acc[mh][mi][nh][0] = f32x4{bias[nh][0], bias[nh][1], bias[nh][2], bias[nh][3]};
+                        acc[mh][mi][nh][1] = f32x4{bias[nh][4], bias[nh][5], bias[nh][6], bias[nh][7]};
                     }
-                }
-            // materialise every accumulator now, so the compiler's own wait for the residual loads sits here (once
-            // per tile) and not in front of the first MFMA of each phase inside the K loop
+            // materialise every accumulator now (nothing of the initialisation may sink into the K loop)
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -304,6 +295,32 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         if (wr == 0) { SYNC(); }   // pair the trailing barrier of the staggered group: all LDS reads of this tile are done
         STAMP(5)
 
+        // ---- epilogue geometry; the first residual passes are requested BEFORE the next tile's operands (vector memory
+        //      returns in order: a residual load queued behind the prologue would wait for all of it) ------------------
+        const bool full = cm0 + T256 <= a.M && cn0 + T256 <= a.N;
+        constexpr int ROWS = OUT_F32 ? 16 : 32;                 // rows per pass
+        constexpr int NPASS = 128 / ROWS;
+        constexpr int ROWB = OUT_F32 ? 256 : 128;               // bytes of this wave's 64 features in one row
+        constexpr int LPR = ROWB / 16;                          // lanes per row when reading back
+        const int rr = lane / LPR, sl = lane % LPR;
+        const int ncol = cn0 + wc * 64 + sl * (OUT_F32 ? 4 : 8);
+        // fp32 residual, fetched in the SAME row-contiguous layout the stores use (1 KiB = 4 rows x 256 B per
+        // instruction, whole lines) RD passes ahead; loading it in the accumulator layout (16 rows x 32-byte pieces
+        // per instruction) costs ~8 us of address processing per tile.
+        constexpr int RD = 2;                                   // residual passes in flight
+        [[maybe_unused]] float4 rres[RD][4];
+#define LOAD_RES(PS)                                                                                                         \
+        if constexpr (HAS_RES) {                                                                                             \
+            const int prow_ = ((PS) / (NPASS / 2)) * 128 + wr * 64 + ((PS) % (NPASS / 2)) * ROWS;                            \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                  \
+                const int64_t m = cm0 + prow_ + j * (64 / LPR) + rr;                                                         \
+                rres[(PS) % RD][j] = (full || (m < a.M && ncol + 4 <= a.N))                                                  \
+                    ? *reinterpret_cast<const float4*>(a.R + cz * a.sR + m * a.ldr + ncol) : make_float4(0.f, 0.f, 0.f, 0.f); \
+            }                                                                                                                \
+        }
+        _Pragma("unroll") for (int p = 0; p < RD; ++p) { LOAD_RES(p) }
+        __builtin_amdgcn_sched_barrier(0);
+
         // ---- request the next tile's first K-tile (and bias) before this tile's epilogue ------------------------------
         if (more) {
             const bool streamed = stream;
@@ -322,16 +339,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         // which the next tile's prologue does not touch, and 16 KiB of spare LDS) and stores 1 KiB per instruction as 8 whole 128-byte lines.
         // The LDS ops are inline asm: the compiler's wait-count pass would drain the prologue DMA in front of them.
         // Interior tiles issue a FIXED number of store instructions (16 or 32): the next tile waits with a counted vmcnt.
-        const bool full = cm0 + T256 <= a.M && cn0 + T256 <= a.N;
         {
             char* const stg = wave < 4 ? smem + kDbuf + kHalf + wave * 4096 : smem + 2 * kDbuf + 8 * 1024 + (wave - 4) * 4096;
             const unsigned stg_addr = (unsigned)(size_t)(lptr_t)(stg);
-            constexpr int ROWS = OUT_F32 ? 16 : 32;                 // rows per pass
-            constexpr int NPASS = 128 / ROWS;
-            constexpr int ROWB = OUT_F32 ? 256 : 128;               // bytes of this wave's 64 features in one row
-            constexpr int LPR = ROWB / 16;                          // lanes per row when reading back
-            const int rr = lane / LPR, sl = lane % LPR;
-            const int ncol = cn0 + wc * 64 + sl * (OUT_F32 ? 4 : 8);
             u32x4 wd[4];                                            // one pass of packed outputs: [sub][nh] (16-bit) / [nh][half] (fp32)
             // activation + pack of pass `ps` into wd (pure VALU: overlaps the LDS round trip of the previous pass)
 #define PRODUCE(PS)                                                                                                          \
@@ -387,7 +397,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                 if (ps + 1 < NPASS) { PRODUCE(ps + 1) }             // next pass's VALU work under the LDS latency
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) :: "memory");
                 const int prow = (ps / (NPASS / 2)) * 128 + wr * 64 + (ps % (NPASS / 2)) * ROWS;   // first row of this pass in the tile
-                const u32x4 dd[4] = {d0, d1, d2, d3};
+                u32x4 dd[4] = {d0, d1, d2, d3};
+                if constexpr (HAS_RES) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 o = __builtin_bit_cast(f32x4, dd[j]);
+                        const float4 r = rres[ps % RD][j];
+                        o += f32x4{r.x, r.y, r.z, r.w};
+                        dd[j] = __builtin_bit_cast(u32x4, o);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int64_t m = cm0 + prow + j * (64 / LPR) + rr;
@@ -396,12 +415,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                         else *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.C) + cz * a.sC + m * a.ldc + ncol) = dd[j];
                     }
                 }
+                if (ps + RD < NPASS) { LOAD_RES(ps + RD) }
                 if (ps + 1 < NPASS) { WRITE_STAGE() }               // the reads of this pass have retired
             }
 #undef PRODUCE
+#undef LOAD_RES
 #undef WRITE_STAGE
         }
-        pending_stores = full ? (OUT_F32 ? 32 : 16) : 0;
+        pending_stores = full ? (OUT_F32 ? 32 : 16) : 0;   // (residual loads also follow the prologue: waiting for fewer is safe)
         STAMP(7)
         ++tile_no;
         if (!more) break;
@@ -457,10 +478,10 @@ void launch_gemm256(const GemmArgs& a_in, int in_dtype, bool f32out, hipStream_t
 #define CIR_LAUNCH256(TT, F32, RES) hipLaunchKernelGGL((gemm256_kernel<TT, F32, RES>), grid, block, 0, s, a)
     if (in_dtype == CIR_BF16) {
         if (f32out) { if (res) CIR_LAUNCH256(__bf16, true, true); else CIR_LAUNCH256(__bf16, true, false); }
-        else { if (res) CIR_LAUNCH256(__bf16, false, true); else CIR_LAUNCH256(__bf16, false, false); }
+        else CIR_LAUNCH256(__bf16, false, false);
     } else {
         if (f32out) { if (res) CIR_LAUNCH256(_Float16, true, true); else CIR_LAUNCH256(_Float16, true, false); }
-        else { if (res) CIR_LAUNCH256(_Float16, false, true); else CIR_LAUNCH256(_Float16, false, false); }
+        else CIR_LAUNCH256(_Float16, false, false);
     }
 #undef CIR_LAUNCH256
 }
