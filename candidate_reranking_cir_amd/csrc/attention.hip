@@ -13,14 +13,17 @@
 // of V through ds_read_b64_tr_b16 (hardware transpose).
 //
 // Two kernels share that tile update:
-//   * attn_shared_kernel - one workgroup per (item, head); the head's whole K and V (Lk <= 256 keys, 64 KiB)
+//   * attn_shared_kernel - one workgroup per (item, head); the head's whole K and V (Lk <= 608 keys, 152 KiB)
 //     are staged ONCE into LDS (bank-swizzled) and every 32-query wave of the workgroup reads them from
-//     there: the ViT case (197 x 197), where 7 query tiles would otherwise each re-read K/V from L2.
+//     there: the ViT cases (197 x 197: 7 query tiles, 2 workgroups per CU; 577 x 577: 19 tiles on 10 waves, one
+//     workgroup per CU), where every query tile would otherwise re-read K/V from L2.
 //   * attn_stream_kernel - one wave per (item, head, 32 queries), K straight from global memory into
 //     MFMA fragments, V through a private 4-KiB LDS tile, next tile prefetched into registers while the
 //     current one is processed: the text-side cases (32 x 32 self-attention, 32 x 197 / 32 x 577
-//     cross-attention) where nothing is shared between waves, and any Lk > 256.
+//     cross-attention) where nothing is shared between waves, and any Lk > 608.
 // Ragged extents: rows beyond Lq / Lk are clamped or zero-filled on load; scores of keys >= Lk are -inf.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace cir {
@@ -147,7 +150,7 @@ __device__ __forceinline__ void store_out(const Softmax& st, T* op /* row base +
 
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(512) void attn_shared_kernel(const AttnArgs a, int lk_pad) {
+__global__ __launch_bounds__(1024) void attn_shared_kernel(const AttnArgs a, int lk_pad) {
     using X8 = typename Elem<T>::x8;
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     char* Ks = dyn;
@@ -327,13 +330,23 @@ extern "C" int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int lk_pad = (Lk + 31) & ~31;
     // K/V of a head are shared by its query tiles: stage them once per workgroup when there are several tiles
-    const bool shared = a.nqt >= 2 && lk_pad <= 256;
+    // (up to 608 keys = 152 KiB of LDS: the 577-token ViT of the reference's 384-px scripts still fits one CU)
+    bool shared = a.nqt >= 2 && lk_pad <= 608;
+    if (const char* e = getenv("CIR_ATTN_SHARED_MAX")) shared = a.nqt >= 2 && lk_pad <= atoi(e);   // tests, A/B
     if (shared) {
         const int64_t nblk = (int64_t)B1 * B0 * H;
         if (nblk > 0x7fffffff) return CIR_ESHAPE;
-        const int waves = a.nqt < 8 ? a.nqt : 8;
+        // query tiles are dealt round-robin to the waves: as few rounds as 16 waves allow, then as few waves as that needs
+        const int rounds = (a.nqt + 15) / 16;
+        const int waves = (a.nqt + rounds - 1) / rounds;
         dim3 grid((unsigned)nblk), block(waves * 64);
         const size_t lds = (size_t)lk_pad * 256;
+        const void* fn = dtype == CIR_BF16 ? reinterpret_cast<const void*>(&attn_shared_kernel<__bf16>)
+                                           : reinterpret_cast<const void*>(&attn_shared_kernel<_Float16>);
+        if (lds > 64 * 1024) {   // opt in to more than 64 KiB of dynamic LDS (idempotent, per function)
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
         if (dtype == CIR_BF16) hipLaunchKernelGGL((attn_shared_kernel<__bf16>), grid, block, lds, s, a, lk_pad);
         else hipLaunchKernelGGL((attn_shared_kernel<_Float16>), grid, block, lds, s, a, lk_pad);
         CIR_LAUNCH_RESULT();

@@ -149,7 +149,8 @@ def _attn_ref(q, k, v, scale, mask):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("lq,lk", [(1, 1), (5, 7), (32, 32), (33, 64), (32, 197), (197, 197), (11, 577), (64, 40)])
+@pytest.mark.parametrize("lq,lk", [(1, 1), (5, 7), (32, 32), (33, 64), (32, 197), (197, 197), (11, 577), (64, 40),
+                                   (577, 577), (300, 608), (70, 640), (520, 300)])
 def test_attention_shapes(ops, dtype, lq, lk):
     b1, b0, h = 3, 2, 2
     q, k, v = _rand((b1, b0, lq, h * 64), dtype, seed=1), _rand((b1, b0, lk, h * 64), dtype, seed=2), _rand((b1, b0, lk, h * 64), dtype, seed=3)

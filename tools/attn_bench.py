@@ -15,12 +15,15 @@ def timeit(fn, reps=20):
 
 d = 768
 # ViT: B images, N=197, packed qkv
-for B, N in [(808, 197), (202, 197), (64, 577)]:
+for B, N in [(808, 197), (202, 197), (64, 577), (404, 577)]:
     qkv = torch.randn((B, N, 3, d), device="cuda").bfloat16()
     out = torch.empty((B, N, d), device="cuda", dtype=torch.bfloat16)
-    us = timeit(lambda: ops.attention(qkv[:, :, 0].unsqueeze(1), qkv[:, :, 1].unsqueeze(1), qkv[:, :, 2].unsqueeze(1), out.unsqueeze(1), 0.125))
-    fl = 4.0 * B * 12 * N * N * 64
-    print(f"vit    B={B:4d} N={N}: {us:8.1f} us  {fl/us/1e6:7.1f} TF/s")
+    for cap in ("608", "256"):       # K/V of a head shared through LDS up to this many keys (256 = streamed for N=577)
+        os.environ["CIR_ATTN_SHARED_MAX"] = cap
+        us = timeit(lambda: ops.attention(qkv[:, :, 0].unsqueeze(1), qkv[:, :, 1].unsqueeze(1), qkv[:, :, 2].unsqueeze(1), out.unsqueeze(1), 0.125))
+        fl = 4.0 * B * 12 * N * N * 64
+        print(f"vit    B={B:4d} N={N} shared<={cap}: {us:8.1f} us  {fl/us/1e6:7.1f} TF/s")
+os.environ.pop("CIR_ATTN_SHARED_MAX")
 T, L, N = 1600, 32, 197
 qb = torch.randn((2, T, L, d), device="cuda").bfloat16()
 kv = torch.randn((T, N, 4, d), device="cuda").bfloat16()
