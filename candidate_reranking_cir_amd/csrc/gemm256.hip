@@ -470,6 +470,11 @@ void launch_gemm256(const GemmArgs& a_in, int in_dtype, bool f32out, hipStream_t
     int gw = 1;
     for (int d = 1; d <= a.tiles_n; ++d)
         if (a.tiles_n % d == 0 && d * panel <= (2LL << 20)) gw = d;
+    // deep K: whole panels no longer fit, but the CUs of an XCD sweep K together, so a 2-D block of concurrent tiles
+    // still shares the current K-slices through L2 (8192^3: 1223 -> 1283 TF/s with 4 columns instead of 1)
+    if (gw == 1)
+        for (int d = 2; d <= 4; ++d)
+            if (a.tiles_n % d == 0) gw = d;
     if (const char* e = getenv("CIR_GEMM_GW")) { const int v = atoi(e); if (v > 0) gw = v < a.tiles_n ? v : a.tiles_n; }
     a.group_w = gw;
     const int64_t g = persistent_grid();
