@@ -465,16 +465,17 @@ void launch_gemm256(const GemmArgs& a_in, int in_dtype, bool f32out, hipStream_t
     a.tiles_m = (int)((a.M + T256 - 1) / T256);
     a.tiles_n = (a.N + T256 - 1) / T256;
     const int64_t ntiles = (int64_t)a.tiles_m * a.tiles_n * a.batch;
-    // widest divisor of tiles_n whose weight panels (256 x K 16-bit each) fit in ~2 MiB of an XCD's L2
-    const int64_t panel = 256LL * a.K * 2;
+    // Raster: an XCD's 32 CUs sweep K together on 32 tiles laid out as gw columns x 32/gw rows, so per K-step its L2
+    // pulls gw weight slices + 32/gw activation slices from the fabric for 32 x 2 delivered: pick the gw that minimises
+    // gw + 32/gw (~6), preferring a divisor of tiles_n (ragged last groups cost more than they save).  Measured with the
+    // operand stream alone (tools/dma_probe.hip, 318464 x 3072 x 768): 50 / 55 / 68 / 61 GB/s per CU at gw 1 / 4 / 6 / 12;
+    // in the GEMM: 1022 -> 1080 TF/s from gw 4 to 6.
     int gw = 1;
-    for (int d = 1; d <= a.tiles_n; ++d)
-        if (a.tiles_n % d == 0 && d * panel <= (2LL << 20)) gw = d;
-    // deep K: whole panels no longer fit, but the CUs of an XCD sweep K together, so a 2-D block of concurrent tiles
-    // still shares the current K-slices through L2 (8192^3: 1223 -> 1283 TF/s with 4 columns instead of 1)
-    if (gw == 1)
-        for (int d = 2; d <= 4; ++d)
-            if (a.tiles_n % d == 0) gw = d;
+    float best = 1e30f;
+    for (int d = 1; d <= a.tiles_n && d <= 12; ++d) {
+        const float cost = d + 32.0f / d + (a.tiles_n % d ? 1.5f : 0.f);
+        if (cost < best) { best = cost; gw = d; }
+    }
     if (const char* e = getenv("CIR_GEMM_GW")) { const int v = atoi(e); if (v > 0) gw = v < a.tiles_n ? v : a.tiles_n; }
     a.group_w = gw;
     const int64_t g = persistent_grid();
