@@ -31,6 +31,11 @@ template <> struct Elem<__bf16> {
     static __device__ __forceinline__ f32x16 mfma32(x8 a, x8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
+    // c += a * b IN PLACE, at this exact spot of the instruction stream (hand-scheduled loops: the builtin lets the
+    // register allocator rename accumulators, which costs registers the 256-VGPR kernels do not have)
+    static __device__ __forceinline__ void mfma16_acc(f32x4& c, x8 a, x8 b) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    }
 };
 template <> struct Elem<_Float16> {
     using x8 = f16x8;
@@ -40,6 +45,9 @@ template <> struct Elem<_Float16> {
     }
     static __device__ __forceinline__ f32x16 mfma32(x8 a, x8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mfma16_acc(f32x4& c, x8 a, x8 b) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
     }
 };
 

@@ -211,7 +211,7 @@ extern "C" int cir_gemm_bias_act(const void* A, int64_t lda, int64_t strideA, co
     const int64_t nblk256 = ((M + 255) / 256) * ((N + 255) / 256) * batch;
     // (the 256 kernel adds the residual in its fp32 row layout: linear fp32-out epilogues only; 32-bit operand offsets)
     bool use256 = N >= 256 && nblk256 >= 192;
-    const bool can256 = !(residual && (act != CIR_ACT_NONE || !f32out)) && lda < (1 << 21) && ldw < (1 << 21);   // tile-relative 32-bit offsets
+    const bool can256 = !(residual && (act != CIR_ACT_NONE || !f32out)) && K % 128 == 0 && lda < (1 << 21) && ldw < (1 << 21);   // K-tile pairs; tile-relative 32-bit offsets
     if (const char* force = getenv("CIR_GEMM_TILE")) {
         if (force[0] == '1') use256 = false;
         else if (force[0] == '2') use256 = true;

@@ -20,10 +20,11 @@
 //       phase:   1        2     3            4        5        6     7            8
 //       refill:  A1>d1    -     A0,B0>d0     B1>d0    A1>d0    -     A0,B0>d1     B1>d1
 //       tile:    t+1            t+2          t+2      t+2            t+3          t+3
-//     Each half-tile is two 1-KiB pieces per wave: piece 0 is issued in the read segment, piece 1 between the two
-//     k-steps of the same phase's MFMA segment.  The only vector-memory waits in the loop are a counted
-//     `s_waitcnt vmcnt(5)` in phases 4 and 8: two and a half half-tiles
-//     stay in flight across the K-tile boundary and every refill has >= 3 phases to land.  (The loop is bound by
+//     Each half-tile is two 1-KiB pieces per wave, issued BETWEEN the MFMAs of the phase's MFMA segment (one
+//     scheduling region, sched_group_barrier): the ~100 wave-cycles of an LDS-DMA issue then hide in the issue gaps
+//     behind the MFMAs instead of idling the matrix pipe.  The only vector-memory waits in the loop are a counted
+//     `s_waitcnt vmcnt(4)` in the read segments of phases 4 and 8: two half-tiles
+//     stay in flight across the K-tile boundary and every refill has >= 2.5 phases to land.  (The loop is bound by
 //     operand delivery, not by the MFMA pipe: with the MFMAs compiled out it takes the same time; bytes in flight /
 //     latency is what sets the rate.)  The buffer a wait retires is first read one phase later, behind a barrier.
 //   * the two wave groups (waves 0-3 / 4-7 = the two waves of each SIMD) run staggered by one barrier,
@@ -132,19 +133,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     const char* W_nx = nullptr;
     bool stream = false;
 
-// One half-tile = two 1-KiB pieces per wave.  P selects the piece: the K loop issues piece 0 in the LDS-read segment and
-// piece 1 in the middle of the same phase's MFMA segment (an LDS-DMA issue costs the wave ~60 cycles among MFMAs but
-// ~170 in a segment of its own; the K loop is bound by that issue cost, not by the matrix pipe).
-#define ISSUE_A1(H, DB, KT, P)                                                                                          \
-    if ((KT) < nk || stream) {                                                                                          \
-        const char* kb_ = (KT) < nk ? A_z + (KT) * 128 : A_nx + ((KT) - nk) * 128;                                      \
-        __builtin_amdgcn_global_load_lds((gptr_t)(kb_ + a_off[H][P]), (lptr_t)(stage_base + (DB) * kDbuf + (H) * kHalf + (P) * 1024), 16, 0, 0); \
-    }
-#define ISSUE_B1(H, DB, KT, P)                                                                                          \
-    if ((KT) < nk || stream) {                                                                                          \
-        const char* kb_ = (KT) < nk ? W_z + (KT) * 128 : W_nx + ((KT) - nk) * 128;                                      \
-        __builtin_amdgcn_global_load_lds((gptr_t)(kb_ + w_off[H][P]), (lptr_t)(stage_base + (DB) * kDbuf + (2 + (H)) * kHalf + (P) * 1024), 16, 0, 0); \
-    }
+// One half-tile = two 1-KiB pieces per wave (P selects the piece).  Refills are UNCONDITIONAL and branch-free: past the
+// end of the tile they fetch the next tile's first K-tiles when the seam streams, and otherwise re-fetch this tile's last
+// K-tile into a slot nobody reads again (a later prologue of the same wave overwrites it in order).  Every K-tile
+// therefore issues the same pieces, the counted waits need no cases, and - the point - a phase's MFMA segment stays ONE
+// scheduling region in which the pieces are interleaved between MFMAs (sched_group_barrier below).
+#define KBASE(KT, CUR, NXT) ((KT) < nk ? (CUR) + (KT) * 128 : (stream ? (NXT) + ((KT) - nk) * 128 : (CUR) + (nk - 1) * 128))
+// piece P of half-tile H from the K-tile whose (wave-uniform) base pointer is KB
+#define PIECE_A(H, DB, KB, P) __builtin_amdgcn_global_load_lds((gptr_t)((KB) + a_off[H][P]), (lptr_t)(stage_base + (DB) * kDbuf + (H) * kHalf + (P) * 1024), 16, 0, 0);
+#define PIECE_B(H, DB, KB, P) __builtin_amdgcn_global_load_lds((gptr_t)((KB) + w_off[H][P]), (lptr_t)(stage_base + (DB) * kDbuf + (2 + (H)) * kHalf + (P) * 1024), 16, 0, 0);
+#define ISSUE_A1(H, DB, KT, P) { const char* kb_ = KBASE(KT, A_z, A_nx); PIECE_A(H, DB, kb_, P) }
+#define ISSUE_B1(H, DB, KT, P) { const char* kb_ = KBASE(KT, W_z, W_nx); PIECE_B(H, DB, kb_, P) }
 #define ISSUE_A(H, DB, KT) ISSUE_A1(H, DB, KT, 0) ISSUE_A1(H, DB, KT, 1)
 #define ISSUE_B(H, DB, KT) ISSUE_B1(H, DB, KT, 0) ISSUE_B1(H, DB, KT, 1)
     // first K-tile complete in dbuf 0 plus the first two half-tiles of K-tile 1 (what phases 7, 8 would have issued)
@@ -177,19 +176,32 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);           \
     __builtin_amdgcn_s_barrier();                \
     __builtin_amdgcn_sched_barrier(0);
-#define COMPUTE(ON, MH, NH, MID)                 \
+// MFMA segment of one phase: 16 in-place MFMAs (two k-steps of one 64 x 32 quadrant) in SOURCE order, with the phase's
+// refill pieces placed between them.  An LDS-DMA issue (M0, address add, the VMEM issue itself) costs the wave some tens
+// of cycles; as a block between the k-steps - with its address selects - it idled the matrix pipe for ~100 cycles in
+// every phase (measured: MFMA segments of 350-400 cycles for 256 cycles of MFMA work); behind an MFMA, whose issue
+// leaves the wave 12 idle cycles, it is nearly free.
+#define MM(MH, NH, I) Elem<T>::mfma16_acc(acc[MH][((I) & 7) >> 1][NH][(I) & 1], wf[NH][(I) & 1][(I) >> 3], af[((I) & 7) >> 1][(I) >> 3]);
+#define PLACE(X) __builtin_amdgcn_sched_barrier(0); X __builtin_amdgcn_sched_barrier(0);
+#define MFMAS_0(MH, NH, P0, P1, P2, P3)                                                                                   \
+    MM(MH, NH, 0) MM(MH, NH, 1) MM(MH, NH, 2) MM(MH, NH, 3) MM(MH, NH, 4) MM(MH, NH, 5) MM(MH, NH, 6) MM(MH, NH, 7)       \
+    MM(MH, NH, 8) MM(MH, NH, 9) MM(MH, NH, 10) MM(MH, NH, 11) MM(MH, NH, 12) MM(MH, NH, 13) MM(MH, NH, 14) MM(MH, NH, 15)
+#define MFMAS_2(MH, NH, P0, P1, P2, P3)                                                                                   \
+    MM(MH, NH, 0) MM(MH, NH, 1) MM(MH, NH, 2) PLACE(P0) MM(MH, NH, 3) MM(MH, NH, 4) MM(MH, NH, 5) MM(MH, NH, 6)           \
+    MM(MH, NH, 7) MM(MH, NH, 8) PLACE(P1) MM(MH, NH, 9) MM(MH, NH, 10) MM(MH, NH, 11) MM(MH, NH, 12) MM(MH, NH, 13)       \
+    MM(MH, NH, 14) MM(MH, NH, 15)
+#define MFMAS_4(MH, NH, P0, P1, P2, P3)                                                                                   \
+    MM(MH, NH, 0) MM(MH, NH, 1) PLACE(P0) MM(MH, NH, 2) MM(MH, NH, 3) MM(MH, NH, 4) MM(MH, NH, 5) PLACE(P1)               \
+    MM(MH, NH, 6) MM(MH, NH, 7) MM(MH, NH, 8) MM(MH, NH, 9) PLACE(P2) MM(MH, NH, 10) MM(MH, NH, 11) MM(MH, NH, 12)        \
+    MM(MH, NH, 13) PLACE(P3) MM(MH, NH, 14) MM(MH, NH, 15)
+#define COMPUTE(MH, NH, NDMA, P0, P1, P2, P3)    \
     SYNC();                                      \
     __builtin_amdgcn_s_setprio(1);               \
-    if (ON) { MMA_K(MH, NH, 0) }                 \
-    __builtin_amdgcn_sched_barrier(0);           \
-    MID                                          \
-    __builtin_amdgcn_sched_barrier(0);           \
-    if (ON) { MMA_K(MH, NH, 1) }                 \
+    MFMAS_##NDMA(MH, NH, P0, P1, P2, P3)         \
     __builtin_amdgcn_s_setprio(0);               \
     SYNC();
-#define WAIT_TILE(NEXT_KT)                                                        \
-    if ((NEXT_KT) < nk || stream) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+// the other buffer's K-tile is complete (4 newer pieces - one phase's refills - may stay in flight)
+#define WAIT_TILE() asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 
     static_assert(!HAS_RES || OUT_F32, "the residual is added in the fp32 row layout of the epilogue");
 
@@ -263,33 +275,47 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         STAMP(2)
         SYNC();
         if (wr == 1) { SYNC(); }   // stagger: waves 4-7 run one barrier behind waves 0-3
-        stream = more && nx.interior && rel_interior && nk >= 2 && (nk & 1) == 0;
+        stream = more && nx.interior && rel_interior;
         STAMP(3)
 
-        const int niter = (nk + 1) >> 1;
-        for (int it = 0; it < niter; ++it) {
-            const int t0 = 2 * it, t1 = t0 + 1;
-            const bool odd = t1 < nk;
-            // ---- K-tile t0 in dbuf 0 (L segment: reads + piece 0;  MFMA segment: piece 1 between the k-steps) ------
-            READ_B(0, 0) READ_A(0, 0) ISSUE_A1(1, 1, t1, 0)
-                COMPUTE(true, 0, 0, ISSUE_A1(1, 1, t1, 1))                                                       // phase 1
-            READ_B(1, 0)
-                COMPUTE(true, 0, 1, )                                                                            // phase 2
-            READ_A(1, 0) ISSUE_A1(0, 0, t0 + 2, 0) ISSUE_B1(0, 0, t0 + 2, 0)
-                COMPUTE(true, 1, 1, ISSUE_A1(0, 0, t0 + 2, 1) ISSUE_B1(0, 0, t0 + 2, 1))                         // phase 3
-            ISSUE_B1(1, 0, t0 + 2, 0) WAIT_TILE(t0 + 2)
-                COMPUTE(true, 1, 0, ISSUE_B1(1, 0, t0 + 2, 1))                                                   // phase 4
-            // ---- K-tile t1 in dbuf 1 ---------------------------------------------------------------------------
-            if (odd) { READ_B(0, 1) READ_A(0, 1) }
-            ISSUE_A1(1, 0, t0 + 2, 0)
-                COMPUTE(odd, 0, 0, ISSUE_A1(1, 0, t0 + 2, 1))                                                    // phase 5
-            if (odd) { READ_B(1, 1) }
-                COMPUTE(odd, 0, 1, )                                                                             // phase 6
-            if (odd) { READ_A(1, 1) }
-            ISSUE_A1(0, 1, t1 + 2, 0) ISSUE_B1(0, 1, t1 + 2, 0)
-                COMPUTE(odd, 1, 1, ISSUE_A1(0, 1, t1 + 2, 1) ISSUE_B1(0, 1, t1 + 2, 1))                          // phase 7
-            ISSUE_B1(1, 1, t1 + 2, 0) WAIT_TILE(t1 + 2)
-                COMPUTE(odd, 1, 0, ISSUE_B1(1, 1, t1 + 2, 1))                                                    // phase 8
+        // K-tile T0 from dbuf 0 (phases 1-4) / T1 = T0+1 from dbuf 1 (phases 5-8); refills: see the schedule at the top.
+        // PA1 / PA2,PW2 / PA3,PW3: wave-uniform base pointers of K-tiles T0+1, T0+2, T0+3 (computed outside: no
+        // selects or branches between the MFMAs).
+#define KTILE_D0(PA1, PA2, PW2)                                                                                         \
+        READ_B(0, 0) READ_A(0, 0)                                                                                       \
+            COMPUTE(0, 0, 2, PIECE_A(1, 1, PA1, 0), PIECE_A(1, 1, PA1, 1), , )                             /* phase 1 */ \
+        READ_B(1, 0)                                                                                                    \
+            COMPUTE(0, 1, 0, , , , )                                                                       /* phase 2 */ \
+        READ_A(1, 0)                                                                                                    \
+            COMPUTE(1, 1, 4, PIECE_A(0, 0, PA2, 0), PIECE_B(0, 0, PW2, 0), PIECE_A(0, 0, PA2, 1), PIECE_B(0, 0, PW2, 1)) /* phase 3 */ \
+        WAIT_TILE()                                                                                                     \
+            COMPUTE(1, 0, 2, PIECE_B(1, 0, PW2, 0), PIECE_B(1, 0, PW2, 1), , )                             /* phase 4 */
+#define KTILE_D1(PA2, PA3, PW3)                                                                                         \
+        READ_B(0, 1) READ_A(0, 1)                                                                                       \
+            COMPUTE(0, 0, 2, PIECE_A(1, 0, PA2, 0), PIECE_A(1, 0, PA2, 1), , )                             /* phase 5 */ \
+        READ_B(1, 1)                                                                                                    \
+            COMPUTE(0, 1, 0, , , , )                                                                       /* phase 6 */ \
+        READ_A(1, 1)                                                                                                    \
+            COMPUTE(1, 1, 4, PIECE_A(0, 1, PA3, 0), PIECE_B(0, 1, PW3, 0), PIECE_A(0, 1, PA3, 1), PIECE_B(0, 1, PW3, 1)) /* phase 7 */ \
+        WAIT_TILE()                                                                                                     \
+            COMPUTE(1, 0, 2, PIECE_B(1, 1, PW3, 0), PIECE_B(1, 1, PW3, 1), , )                             /* phase 8 */
+        // K-tiles past the end of this tile: the next tile's first two when the seam streams, else this tile's last one
+        const char* const A_e0 = stream ? A_nx : A_z + (nk - 1) * 128;
+        const char* const A_e1 = stream ? A_nx + 128 : A_e0;
+        const char* const W_e0 = stream ? W_nx : W_z + (nk - 1) * 128;
+        const char* const W_e1 = stream ? W_nx + 128 : W_e0;
+        {
+            const char* pa = A_z;
+            const char* pw = W_z;
+            for (int it = 1; it < (nk >> 1); ++it) {     // all K-tile pairs but the last: refills stay inside the tile
+                KTILE_D0(pa + 128, pa + 256, pw + 256)
+                KTILE_D1(pa + 256, pa + 384, pw + 384)
+                pa += 256;
+                pw += 256;
+            }
+            // last pair (the dispatcher sends only K % 128 == 0 here): its refills are the K-tiles past the end
+            KTILE_D0(pa + 128, A_e0, W_e0)
+            KTILE_D1(A_e0, A_e1, W_e1)
         }
         STAMP(4)
         if (wr == 0) { SYNC(); }   // pair the trailing barrier of the staggered group: all LDS reads of this tile are done
@@ -437,6 +463,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
 #undef READ_A
 #undef READ_B
 #undef MMA_K
+#undef MM
+#undef PLACE
 #undef SYNC
 #undef COMPUTE
 #undef WAIT_TILE
