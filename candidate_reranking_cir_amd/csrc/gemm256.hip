@@ -22,9 +22,10 @@
 //       tile:    t+1            t+2          t+2      t+2            t+3          t+3
 //     Each half-tile is two 1-KiB pieces per wave, issued BETWEEN the MFMAs of the phase's MFMA segment (one
 //     scheduling region, sched_group_barrier): the ~100 wave-cycles of an LDS-DMA issue then hide in the issue gaps
-//     behind the MFMAs instead of idling the matrix pipe.  The only vector-memory waits in the loop are a counted
-//     `s_waitcnt vmcnt(4)` in the read segments of phases 4 and 8: two half-tiles
-//     stay in flight across the K-tile boundary and every refill has >= 2.5 phases to land.  (The loop is bound by
+//     behind the MFMAs instead of idling the matrix pipe.  The only vector-memory waits in the loop are counted:
+//     `vmcnt(6)` in the read segments of phases 4 / 8 (A0, B0, B1 of the other buffer) and `vmcnt(8)` in those of
+//     phases 2 / 6 (the A1 half-tile, consumed and refilled last): three to four half-tiles stay in flight and every
+//     refill has >= 3.5 phases to land.  (The loop is bound by
 //     operand delivery, not by the MFMA pipe: with the MFMAs compiled out it takes the same time; bytes in flight /
 //     latency is what sets the rate.)  The buffer a wait retires is first read one phase later, behind a barrier.
 //   * the two wave groups (waves 0-3 / 4-7 = the two waves of each SIMD) run staggered by one barrier,
@@ -200,8 +201,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     MFMAS_##NDMA(MH, NH, P0, P1, P2, P3)         \
     __builtin_amdgcn_s_setprio(0);               \
     SYNC();
-// the other buffer's K-tile is complete (4 newer pieces - one phase's refills - may stay in flight)
-#define WAIT_TILE() asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+// Counted waits, one per half of a K-tile, each in the read segment ONE phase before the half is first read (behind a
+// barrier): WAIT_ABB retires the other buffer's A0/B0/B1 (the newest 6 pieces - its own A1 and one phase's refills -
+// may stay in flight), WAIT_A1 retires an A1 half-tile, which is consumed last and refilled last (the newest 8 pieces
+// may stay in flight).  Every half-tile then has >= 3.5 phases to land; A1, issued 2.5 phases before the old single
+// wait, has 5.
+// Vector memory retires in order, and the previous tile's output stores are OLDER than every refill of this tile: a
+// counted wait cannot retire a refill before those stores have drained.  The first two waits of a tile only concern
+// data the prologue delivered (already retired at the head of the tile), so a tile's first K-tile pair skips them
+// (`skip`) instead of stalling on its predecessor's stores 1.5 phases into the tile.
+#define WAIT_N(N) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+#define WAIT_PRO(N) if (!skip) { WAIT_N(N) }
+#define WAIT_ABB() WAIT_N(6)
+#define WAIT_A1() WAIT_N(8)
 
     static_assert(!HAS_RES || OUT_F32, "the residual is added in the fp32 row layout of the epilogue");
 
@@ -284,20 +296,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
 #define KTILE_D0(PA1, PA2, PW2)                                                                                         \
         READ_B(0, 0) READ_A(0, 0)                                                                                       \
             COMPUTE(0, 0, 2, PIECE_A(1, 1, PA1, 0), PIECE_A(1, 1, PA1, 1), , )                             /* phase 1 */ \
-        READ_B(1, 0)                                                                                                    \
+        READ_B(1, 0) WAIT_PRO(8)                                                                                        \
             COMPUTE(0, 1, 0, , , , )                                                                       /* phase 2 */ \
         READ_A(1, 0)                                                                                                    \
             COMPUTE(1, 1, 4, PIECE_A(0, 0, PA2, 0), PIECE_B(0, 0, PW2, 0), PIECE_A(0, 0, PA2, 1), PIECE_B(0, 0, PW2, 1)) /* phase 3 */ \
-        WAIT_TILE()                                                                                                     \
+        WAIT_PRO(6)                                                                                                     \
             COMPUTE(1, 0, 2, PIECE_B(1, 0, PW2, 0), PIECE_B(1, 0, PW2, 1), , )                             /* phase 4 */
 #define KTILE_D1(PA2, PA3, PW3)                                                                                         \
         READ_B(0, 1) READ_A(0, 1)                                                                                       \
             COMPUTE(0, 0, 2, PIECE_A(1, 0, PA2, 0), PIECE_A(1, 0, PA2, 1), , )                             /* phase 5 */ \
-        READ_B(1, 1)                                                                                                    \
+        READ_B(1, 1) WAIT_A1()                                                                                          \
             COMPUTE(0, 1, 0, , , , )                                                                       /* phase 6 */ \
         READ_A(1, 1)                                                                                                    \
             COMPUTE(1, 1, 4, PIECE_A(0, 1, PA3, 0), PIECE_B(0, 1, PW3, 0), PIECE_A(0, 1, PA3, 1), PIECE_B(0, 1, PW3, 1)) /* phase 7 */ \
-        WAIT_TILE()                                                                                                     \
+        WAIT_ABB()                                                                                                      \
             COMPUTE(1, 0, 2, PIECE_B(1, 1, PW3, 0), PIECE_B(1, 1, PW3, 1), , )                             /* phase 8 */
         // K-tiles past the end of this tile: the next tile's first two when the seam streams, else this tile's last one
         const char* const A_e0 = stream ? A_nx : A_z + (nk - 1) * 128;
@@ -307,11 +319,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         {
             const char* pa = A_z;
             const char* pw = W_z;
+            bool skip = true;                            // first K-tile pair of the tile (see WAIT_PRO)
             for (int it = 1; it < (nk >> 1); ++it) {     // all K-tile pairs but the last: refills stay inside the tile
                 KTILE_D0(pa + 128, pa + 256, pw + 256)
                 KTILE_D1(pa + 256, pa + 384, pw + 384)
                 pa += 256;
                 pw += 256;
+                skip = false;
             }
             // last pair (the dispatcher sends only K % 128 == 0 here): its refills are the K-tiles past the end
             KTILE_D0(pa + 128, A_e0, W_e0)
@@ -467,7 +481,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
 #undef PLACE
 #undef SYNC
 #undef COMPUTE
-#undef WAIT_TILE
+#undef WAIT_ABB
+#undef WAIT_A1
+#undef WAIT_N
+#undef WAIT_PRO
 }
 
 #ifdef CIR_GEMM_STAMPS
