@@ -34,7 +34,7 @@ template <> struct Elem<__bf16> {
     // c += a * b IN PLACE, at this exact spot of the instruction stream (hand-scheduled loops: the builtin lets the
     // register allocator rename accumulators, which costs registers the 256-VGPR kernels do not have)
     static __device__ __forceinline__ void mfma16_acc(f32x4& c, x8 a, x8 b) {
-        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+        asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
     }
 };
 template <> struct Elem<_Float16> {
@@ -47,7 +47,7 @@ template <> struct Elem<_Float16> {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ void mfma16_acc(f32x4& c, x8 a, x8 b) {
-        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+        asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
     }
 };
 

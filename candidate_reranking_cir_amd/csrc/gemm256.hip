@@ -141,8 +141,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
 // scheduling region in which the pieces are interleaved between MFMAs (sched_group_barrier below).
 #define KBASE(KT, CUR, NXT) ((KT) < nk ? (CUR) + (KT) * 128 : (stream ? (NXT) + ((KT) - nk) * 128 : (CUR) + (nk - 1) * 128))
 // piece P of half-tile H from the K-tile whose (wave-uniform) base pointer is KB
-#define PIECE_A(H, DB, KB, P) __builtin_amdgcn_global_load_lds((gptr_t)((KB) + a_off[H][P]), (lptr_t)(stage_base + (DB) * kDbuf + (H) * kHalf + (P) * 1024), 16, 0, 0);
-#define PIECE_B(H, DB, KB, P) __builtin_amdgcn_global_load_lds((gptr_t)((KB) + w_off[H][P]), (lptr_t)(stage_base + (DB) * kDbuf + (2 + (H)) * kHalf + (P) * 1024), 16, 0, 0);
+// (inline asm, SADDR form: wave-uniform 64-bit base in an SGPR pair + the lane's 32-bit offset; the builtin takes a
+// 64-bit per-lane address, i.e. two VALU ops per piece and - hoisted out of the loop by the compiler - 32 more VGPRs)
+#define LDS_DMA(SRC_BASE, VOFF, LDS_DST)                                                                                 \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                                       \
+                 :: "s"((unsigned)(size_t)(lptr_t)(LDS_DST)), "v"(VOFF), "s"(SRC_BASE) : "memory");   /* (M0 is reserved: the compiler re-loads it before each of its own uses) */
+#define PIECE_A(H, DB, KB, P) LDS_DMA(KB, a_off[H][P], stage_base + (DB) * kDbuf + (H) * kHalf + (P) * 1024)
+#define PIECE_B(H, DB, KB, P) LDS_DMA(KB, w_off[H][P], stage_base + (DB) * kDbuf + (2 + (H)) * kHalf + (P) * 1024)
 #define ISSUE_A1(H, DB, KT, P) { const char* kb_ = KBASE(KT, A_z, A_nx); PIECE_A(H, DB, kb_, P) }
 #define ISSUE_B1(H, DB, KT, P) { const char* kb_ = KBASE(KT, W_z, W_nx); PIECE_B(H, DB, kb_, P) }
 #define ISSUE_A(H, DB, KT) ISSUE_A1(H, DB, KT, 0) ISSUE_A1(H, DB, KT, 1)
@@ -177,43 +182,40 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     __builtin_amdgcn_sched_barrier(0);           \
     __builtin_amdgcn_s_barrier();                \
     __builtin_amdgcn_sched_barrier(0);
-// MFMA segment of one phase: 16 in-place MFMAs (two k-steps of one 64 x 32 quadrant) in SOURCE order, with the phase's
-// refill pieces placed between them.  An LDS-DMA issue (M0, address add, the VMEM issue itself) costs the wave some tens
-// of cycles; as a block between the k-steps - with its address selects - it idled the matrix pipe for ~100 cycles in
-// every phase (measured: MFMA segments of 350-400 cycles for 256 cycles of MFMA work); behind an MFMA, whose issue
-// leaves the wave 12 idle cycles, it is nearly free.
-#define MM(MH, NH, I) Elem<T>::mfma16_acc(acc[MH][((I) & 7) >> 1][NH][(I) & 1], wf[NH][(I) & 1][(I) >> 3], af[((I) & 7) >> 1][(I) >> 3]);
+// MFMA segment of one phase: the 32 in-place MFMAs of one M-half (64 x 64 outputs per wave, two k-steps, both weight
+// halves) in SOURCE order, with the phase's refill pieces placed between them.  An LDS-DMA issue (M0, address add, the
+// VMEM issue itself) costs the wave some tens of cycles; as a block between the k-steps - with its address selects - it
+// idled the matrix pipe for ~100 cycles per phase (measured: MFMA segments of 350-400 cycles for 256 cycles of MFMA
+// work); behind an MFMA, whose issue leaves the wave 12 idle cycles, it is nearly free.
+#define MM(MH, I) Elem<T>::mfma16_acc(acc[MH][((I) & 7) >> 1][(I) >> 4][(I) & 1], wf[(I) >> 4][(I) & 1][((I) >> 3) & 1], af[((I) & 7) >> 1][((I) >> 3) & 1]);
+#define MM4(MH, I) MM(MH, I) MM(MH, (I) + 1) MM(MH, (I) + 2) MM(MH, (I) + 3)
 #define PLACE(X) __builtin_amdgcn_sched_barrier(0); X __builtin_amdgcn_sched_barrier(0);
-#define MFMAS_0(MH, NH, P0, P1, P2, P3)                                                                                   \
-    MM(MH, NH, 0) MM(MH, NH, 1) MM(MH, NH, 2) MM(MH, NH, 3) MM(MH, NH, 4) MM(MH, NH, 5) MM(MH, NH, 6) MM(MH, NH, 7)       \
-    MM(MH, NH, 8) MM(MH, NH, 9) MM(MH, NH, 10) MM(MH, NH, 11) MM(MH, NH, 12) MM(MH, NH, 13) MM(MH, NH, 14) MM(MH, NH, 15)
-#define MFMAS_2(MH, NH, P0, P1, P2, P3)                                                                                   \
-    MM(MH, NH, 0) MM(MH, NH, 1) MM(MH, NH, 2) PLACE(P0) MM(MH, NH, 3) MM(MH, NH, 4) MM(MH, NH, 5) MM(MH, NH, 6)           \
-    MM(MH, NH, 7) MM(MH, NH, 8) PLACE(P1) MM(MH, NH, 9) MM(MH, NH, 10) MM(MH, NH, 11) MM(MH, NH, 12) MM(MH, NH, 13)       \
-    MM(MH, NH, 14) MM(MH, NH, 15)
-#define MFMAS_4(MH, NH, P0, P1, P2, P3)                                                                                   \
-    MM(MH, NH, 0) MM(MH, NH, 1) PLACE(P0) MM(MH, NH, 2) MM(MH, NH, 3) MM(MH, NH, 4) MM(MH, NH, 5) PLACE(P1)               \
-    MM(MH, NH, 6) MM(MH, NH, 7) MM(MH, NH, 8) MM(MH, NH, 9) PLACE(P2) MM(MH, NH, 10) MM(MH, NH, 11) MM(MH, NH, 12)        \
-    MM(MH, NH, 13) PLACE(P3) MM(MH, NH, 14) MM(MH, NH, 15)
-#define COMPUTE(MH, NH, NDMA, P0, P1, P2, P3)    \
+#define MFMAS_0(MH, P0, P1, P2, P3, P4, P5) MM4(MH, 0) MM4(MH, 4) MM4(MH, 8) MM4(MH, 12) MM4(MH, 16) MM4(MH, 20) MM4(MH, 24) MM4(MH, 28)
+#define MFMAS_2(MH, P0, P1, P2, P3, P4, P5)                                                                              \
+    MM4(MH, 0) MM4(MH, 4) PLACE(P0) MM4(MH, 8) MM4(MH, 12) MM4(MH, 16) PLACE(P1) MM4(MH, 20) MM4(MH, 24) MM4(MH, 28)
+#define MFMAS_6(MH, P0, P1, P2, P3, P4, P5)                                                                              \
+    MM4(MH, 0) PLACE(P0) MM4(MH, 4) MM(MH, 8) PLACE(P1) MM(MH, 9) MM(MH, 10) MM(MH, 11) MM4(MH, 12) PLACE(P2)            \
+    MM4(MH, 16) MM(MH, 20) PLACE(P3) MM(MH, 21) MM(MH, 22) MM(MH, 23) MM(MH, 24) PLACE(P4) MM(MH, 25) MM(MH, 26)         \
+    MM(MH, 27) MM(MH, 28) PLACE(P5) MM(MH, 29) MM(MH, 30) MM(MH, 31)
+#define COMPUTE(MH, NDMA, P0, P1, P2, P3, P4, P5) \
     SYNC();                                      \
     __builtin_amdgcn_s_setprio(1);               \
-    MFMAS_##NDMA(MH, NH, P0, P1, P2, P3)         \
+    MFMAS_##NDMA(MH, P0, P1, P2, P3, P4, P5)     \
     __builtin_amdgcn_s_setprio(0);               \
     SYNC();
 // Counted waits, one per half of a K-tile, each in the read segment ONE phase before the half is first read (behind a
-// barrier): WAIT_ABB retires the other buffer's A0/B0/B1 (the newest 6 pieces - its own A1 and one phase's refills -
-// may stay in flight), WAIT_A1 retires an A1 half-tile, which is consumed last and refilled last (the newest 8 pieces
-// may stay in flight).  Every half-tile then has >= 3.5 phases to land; A1, issued 2.5 phases before the old single
-// wait, has 5.
+// barrier).  Issue order per K-tile pair: M(a0) A1>d1 (2 pieces) | M(b0) A0,B0,B1>d0 (6) | M(a1) A1>d0 (2) |
+// M(b1) A0,B0,B1>d1 (6).  WAIT_ABB retires the other buffer's A0/B0/B1 (only the A1 issued after them may stay in
+// flight: vmcnt(2)); WAIT_A1 retires an A1 half-tile (the 6 pieces issued after it may stay: vmcnt(6)).  Every
+// half-tile has two phases (~2 x 32 MFMAs x 2 groups) to land.
 // Vector memory retires in order, and the previous tile's output stores are OLDER than every refill of this tile: a
 // counted wait cannot retire a refill before those stores have drained.  The first two waits of a tile only concern
 // data the prologue delivered (already retired at the head of the tile), so a tile's first K-tile pair skips them
-// (`skip`) instead of stalling on its predecessor's stores 1.5 phases into the tile.
+// (`skip`) instead of stalling on its predecessor's stores.
 #define WAIT_N(N) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 #define WAIT_PRO(N) if (!skip) { WAIT_N(N) }
-#define WAIT_ABB() WAIT_N(6)
-#define WAIT_A1() WAIT_N(8)
+#define WAIT_ABB() WAIT_N(2)
+#define WAIT_A1() WAIT_N(6)
 
     static_assert(!HAS_RES || OUT_F32, "the residual is added in the fp32 row layout of the epilogue");
 
@@ -294,23 +296,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         // PA1 / PA2,PW2 / PA3,PW3: wave-uniform base pointers of K-tiles T0+1, T0+2, T0+3 (computed outside: no
         // selects or branches between the MFMAs).
 #define KTILE_D0(PA1, PA2, PW2)                                                                                         \
-        READ_B(0, 0) READ_A(0, 0)                                                                                       \
-            COMPUTE(0, 0, 2, PIECE_A(1, 1, PA1, 0), PIECE_A(1, 1, PA1, 1), , )                             /* phase 1 */ \
-        READ_B(1, 0) WAIT_PRO(8)                                                                                        \
-            COMPUTE(0, 1, 0, , , , )                                                                       /* phase 2 */ \
-        READ_A(1, 0)                                                                                                    \
-            COMPUTE(1, 1, 4, PIECE_A(0, 0, PA2, 0), PIECE_B(0, 0, PW2, 0), PIECE_A(0, 0, PA2, 1), PIECE_B(0, 0, PW2, 1)) /* phase 3 */ \
-        WAIT_PRO(6)                                                                                                     \
-            COMPUTE(1, 0, 2, PIECE_B(1, 0, PW2, 0), PIECE_B(1, 0, PW2, 1), , )                             /* phase 4 */
+        READ_B(0, 0) READ_A(0, 0) READ_B(1, 0) WAIT_PRO(6)                                                               \
+            COMPUTE(0, 2, PIECE_A(1, 1, PA1, 0), PIECE_A(1, 1, PA1, 1), , , , )                         /* phase a0 */   \
+        READ_A(1, 0) WAIT_PRO(2)                                                                                        \
+            COMPUTE(1, 6, PIECE_A(0, 0, PA2, 0), PIECE_B(0, 0, PW2, 0), PIECE_B(1, 0, PW2, 0),                           \
+                    PIECE_A(0, 0, PA2, 1), PIECE_B(0, 0, PW2, 1), PIECE_B(1, 0, PW2, 1))                /* phase b0 */
 #define KTILE_D1(PA2, PA3, PW3)                                                                                         \
-        READ_B(0, 1) READ_A(0, 1)                                                                                       \
-            COMPUTE(0, 0, 2, PIECE_A(1, 0, PA2, 0), PIECE_A(1, 0, PA2, 1), , )                             /* phase 5 */ \
-        READ_B(1, 1) WAIT_A1()                                                                                          \
-            COMPUTE(0, 1, 0, , , , )                                                                       /* phase 6 */ \
-        READ_A(1, 1)                                                                                                    \
-            COMPUTE(1, 1, 4, PIECE_A(0, 1, PA3, 0), PIECE_B(0, 1, PW3, 0), PIECE_A(0, 1, PA3, 1), PIECE_B(0, 1, PW3, 1)) /* phase 7 */ \
-        WAIT_ABB()                                                                                                      \
-            COMPUTE(1, 0, 2, PIECE_B(1, 1, PW3, 0), PIECE_B(1, 1, PW3, 1), , )                             /* phase 8 */
+        READ_B(0, 1) READ_A(0, 1) READ_B(1, 1) WAIT_A1()                                                                \
+            COMPUTE(0, 2, PIECE_A(1, 0, PA2, 0), PIECE_A(1, 0, PA2, 1), , , , )                         /* phase a1 */   \
+        READ_A(1, 1) WAIT_ABB()                                                                                         \
+            COMPUTE(1, 6, PIECE_A(0, 1, PA3, 0), PIECE_B(0, 1, PW3, 0), PIECE_B(1, 1, PW3, 0),                           \
+                    PIECE_A(0, 1, PA3, 1), PIECE_B(0, 1, PW3, 1), PIECE_B(1, 1, PW3, 1))                /* phase b1 */
         // K-tiles past the end of this tile: the next tile's first two when the seam streams, else this tile's last one
         const char* const A_e0 = stream ? A_nx : A_z + (nk - 1) * 128;
         const char* const A_e1 = stream ? A_nx + 128 : A_e0;
@@ -472,12 +468,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
 #undef ISSUE_A
 #undef ISSUE_B
 #undef ISSUE_A1
+#undef LDS_DMA
+#undef PIECE_A
+#undef PIECE_B
 #undef ISSUE_B1
 #undef ISSUE_PROLOGUE
 #undef READ_A
 #undef READ_B
 #undef MMA_K
 #undef MM
+#undef MM4
 #undef PLACE
 #undef SYNC
 #undef COMPUTE
