@@ -240,8 +240,9 @@ def main():
     step()
     torch.cuda.synchronize()
     recs, ops.PROFILE_GEMM = ops.PROFILE_GEMM, None
-    gemm_ms = sum(s.elapsed_time(e) for _, s, e in recs)
-    gemm_flop = sum(f for f, _, _ in recs)
+    gemm_ms = sum(r[1].elapsed_time(r[2]) for r in recs)
+    gemm_flop = sum(r[0] for r in recs)
+    gemm_alg_bytes = sum(r[3] for r in recs)     # operands + outputs (+ residual, bias) read / written once
     t1 = time.perf_counter(); step(); torch.cuda.synchronize(); step_ms = (time.perf_counter() - t1) * 1e3
 
     if rank == 0:
@@ -267,7 +268,7 @@ def main():
             "path_frac_of_mfma_peak": round(value * alg["per_triplet"] / 1e3 / (PEAK_TFLOPS[args.dtype] * world), 4),
             "roofline": {"bound": "mfma", "kernel": "cir::gemm_kernel (all launches of one step)", "achieved": round(achieved, 1),
                          "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4),
-                         "traffic": traffic, "launches_per_step": len(recs), "avg_launch_us": round(gemm_ms * 1e3 / max(len(recs), 1), 2),
+                         "traffic": traffic, "algorithmic_bytes": round(gemm_alg_bytes / max(len(recs), 1)), "launches_per_step": len(recs), "avg_launch_us": round(gemm_ms * 1e3 / max(len(recs), 1), 2),
                          "gemm_share_of_step": round(gemm_ms / step_ms, 3)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -69,7 +69,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         m, n, k, nb, act, _DT[a.dtype], _DT[out_dtype], _stream())
     if PROFILE_GEMM is not None:
         ev1.record()
-        PROFILE_GEMM.append((2.0 * nb * m * n * k, ev0, ev1))
+        alg_bytes = nb * ((m * k + n * k) * a.element_size() + m * n * o3.element_size()
+                          + (m * n * 4 if residual is not None else 0) + (n * 4 if bias is not None else 0))
+        PROFILE_GEMM.append((2.0 * nb * m * n * k, ev0, ev1, float(alg_bytes)))
     _lib.check(code, "cir_gemm_bias_act")
     return out
 
