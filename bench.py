@@ -164,11 +164,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # (dry-run knobs for a box with ONE GPU: CIR_BENCH_DEVICE pins every rank to that device and CIR_BENCH_BACKEND=gloo
+    #  replaces RCCL, which refuses two ranks on one device - exercises the launch / gather / timing logic only)
+    dev_index = int(os.environ.get("CIR_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("CIR_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from candidate_reranking_cir_amd import config, ops, synthetic, weights
     from candidate_reranking_cir_amd.blip_stage1 import BLIP_Retrieval
@@ -197,8 +204,9 @@ def main():
     n_buf = max(args.steps, args.warmup, 1)
     local_scores = torch.empty((n_buf, q_n, k), dtype=torch.float32, device=dev)
     local_order = torch.empty((n_buf, q_n, k), dtype=torch.int64, device=dev)
-    gathered_scores = torch.empty((world, n_buf, q_n, k), dtype=torch.float32, device=dev) if world > 1 else None
-    gathered_order = torch.empty((world, n_buf, q_n, k), dtype=torch.int64, device=dev) if world > 1 else None
+    # (gather buffers in the concatenated layout - rank-major along dim 0 - which every backend accepts)
+    gathered_scores = torch.empty((world * n_buf, q_n, k), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered_order = torch.empty((world * n_buf, q_n, k), dtype=torch.int64, device=dev) if world > 1 else None
 
     def step(slot=0):
         toks = m2.img_embed16(images)                                   # reference images first, then candidates
@@ -210,9 +218,14 @@ def main():
         return logits, order
 
     def exchange():
-        if world > 1:
+        if world > 1 and backend == "nccl":
             dist.all_gather_into_tensor(gathered_scores, local_scores)
             dist.all_gather_into_tensor(gathered_order, local_order)
+        elif world > 1:                                                 # dry run: the same gather through host memory
+            for dst, src in ((gathered_scores, local_scores), (gathered_order, local_order)):
+                host = torch.empty(dst.shape, dtype=dst.dtype)
+                dist.all_gather_into_tensor(host, src.cpu())
+                dst.copy_(host)
 
     def fence():
         if world > 1:
@@ -230,7 +243,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = te.item()
     assert torch.isfinite(out[0]).all()
