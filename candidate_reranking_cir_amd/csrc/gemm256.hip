@@ -464,6 +464,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         if (!more) break;
         t = tn;
     }
+    // the last tile's dead-slot refills are LDS-DMA writes: retire them before the workgroup gives its LDS back
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef ISSUE_BIAS
 #undef ISSUE_A
 #undef ISSUE_B
