@@ -55,20 +55,25 @@ struct Softmax {
     }
 };
 
-// scores (already in the log2 domain) -> probabilities, running max / sum, rescale of O; returns P^T packed
-template <typename T>
+// raw scores -> probabilities, running max / sum (log2 domain), rescale of O; returns P^T packed.
+// MASKED = false (ViT, and text-side calls without a mask): the scale rides in the exponent's FMA,
+// p = exp2(s * sl - m), and the row maximum is taken on the raw scores (sl > 0) - no per-score multiply, no key
+// indices.  The ViT kernel is bound by VALU issue (PMC: its ~3.5 waves per SIMD are active 28 % of their cycles each),
+// so instructions removed here are time removed.
+template <typename T, bool MASKED>
 __device__ __forceinline__ void softmax_tile(Softmax& st, f32x16& s, float sl, const float* mp, int key0, int hh, int Lk,
                                              typename Elem<T>::x8 (&pf)[2]) {
     float sv[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sv[i] = s[i] * sl;
-    if (mp != nullptr) {
+    if constexpr (MASKED) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
             // clamp keeps finfo.min-style masks finite in the log2 domain (all-masked rows stay uniform, like the reference)
-            sv[i] = fmaf(fmaxf(mp[min(key, Lk - 1)], -2.0e38f), kLog2e, sv[i]);
+            sv[i] = fmaf(fmaxf(mp[min(key, Lk - 1)], -2.0e38f), kLog2e, s[i] * sl);
         }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sv[i] = s[i];
     }
     if (key0 + 32 > Lk) {   // wave-uniform: only the last key tile is ragged
 #pragma unroll
@@ -82,6 +87,7 @@ __device__ __forceinline__ void softmax_tile(Softmax& st, f32x16& s, float sl, c
     for (int i = 3; i < 15; i += 2) mx = fmaxf(fmaxf(mx, sv[i]), sv[i + 1]);
     mx = fmaxf(mx, sv[15]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if constexpr (!MASKED) mx *= sl;
     const float m_new = fmaxf(st.m_run, mx);     // finite: every tile holds at least one valid key
     if (!__all(m_new == st.m_run)) {             // skip the O-wide rescale when no row maximum moved
         const float alpha = __builtin_amdgcn_exp2f(st.m_run - m_new);
@@ -93,7 +99,7 @@ __device__ __forceinline__ void softmax_tile(Softmax& st, f32x16& s, float sl, c
     float psum = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const float p = __builtin_amdgcn_exp2f(sv[i] - st.m_run);
+        const float p = MASKED ? __builtin_amdgcn_exp2f(sv[i] - st.m_run) : __builtin_amdgcn_exp2f(fmaf(sv[i], sl, -st.m_run));
         sv[i] = p;
         psum += p;
     }
@@ -149,7 +155,7 @@ __device__ __forceinline__ void store_out(const Softmax& st, T* op /* row base +
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool MASKED>
 __global__ __launch_bounds__(1024) void attn_shared_kernel(const AttnArgs a, int lk_pad) {
     using X8 = typename Elem<T>::x8;
     extern __shared__ __attribute__((aligned(16))) char dyn[];
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(1024) void attn_shared_kernel(const AttnArgs a, int
     const int64_t kb1 = a.kv_index ? a.kv_index[b1] : b1;
     const T* kb = reinterpret_cast<const T*>(a.k) + kb1 * a.k_s1 + b0 * a.k_s0 + h * 64;
     const T* vb = reinterpret_cast<const T*>(a.v) + kb1 * a.v_s1 + b0 * a.v_s0 + h * 64;
-    const float* mp = a.mask ? a.mask + b1 * a.m_s1 + b0 * a.m_s0 : nullptr;
+    const float* mp = MASKED ? a.mask + b1 * a.m_s1 + b0 * a.m_s0 : nullptr;
 
     // ---- stage K (chunk ^ ((row>>1)&7): conflict-free 32x32x16 A-operand reads) and V (halves swapped on bit 1) ----
     for (int c = threadIdx.x; c < lk_pad * 8; c += blockDim.x) {
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(1024) void attn_shared_kernel(const AttnArgs a, int
                 s = Elem<T>::mfma32(kf, qf[sx], s);
             }
             X8 pf[2];
-            softmax_tile<T>(st, s, sl, mp, key0, hh, a.Lk, pf);
+            softmax_tile<T, MASKED>(st, s, sl, mp, key0, hh, a.Lk, pf);
             pv_tile<T>(st, Vs + key0 * 128, tr_off, pf);
         }
         if (q0 + r < a.Lq) {
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(1024) void attn_shared_kernel(const AttnArgs a, int
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool MASKED>
 __global__ __launch_bounds__(256) void attn_stream_kernel(const AttnArgs a) {
     using X8 = typename Elem<T>::x8;
     __shared__ __attribute__((aligned(16))) char smem[4 * 4096];  // one 32-key x 64-dh V tile per wave
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const AttnArgs a) {
     const int64_t kb1 = a.kv_index ? a.kv_index[b1] : b1;
     const T* kb = reinterpret_cast<const T*>(a.k) + kb1 * a.k_s1 + b0 * a.k_s0 + h * 64 + 8 * hh;
     const T* vb = reinterpret_cast<const T*>(a.v) + kb1 * a.v_s1 + b0 * a.v_s0 + h * 64;
-    const float* mp = a.mask ? a.mask + b1 * a.m_s1 + b0 * a.m_s0 : nullptr;
+    const float* mp = MASKED ? a.mask + b1 * a.m_s1 + b0 * a.m_s0 : nullptr;
 
     X8 qf[4];
 #pragma unroll
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const AttnArgs a) {
         }
         if (kt + 1 < nkt) load_tile(kt + 1, kf, vr);   // prefetch the next tile under this tile's softmax / PV
         X8 pf[2];
-        softmax_tile<T>(st, s, sl, mp, key0, hh, a.Lk, pf);
+        softmax_tile<T, MASKED>(st, s, sl, mp, key0, hh, a.Lk, pf);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         pv_tile<T>(st, vl, tr_off, pf);
@@ -341,20 +347,22 @@ extern "C" int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t 
         const int waves = (a.nqt + rounds - 1) / rounds;
         dim3 grid((unsigned)nblk), block(waves * 64);
         const size_t lds = (size_t)lk_pad * 256;
-        const void* fn = dtype == CIR_BF16 ? reinterpret_cast<const void*>(&attn_shared_kernel<__bf16>)
-                                           : reinterpret_cast<const void*>(&attn_shared_kernel<_Float16>);
+        const bool bf = dtype == CIR_BF16, mk = mask != nullptr;
+        const void* fn = bf ? (mk ? reinterpret_cast<const void*>(&attn_shared_kernel<__bf16, true>) : reinterpret_cast<const void*>(&attn_shared_kernel<__bf16, false>))
+                            : (mk ? reinterpret_cast<const void*>(&attn_shared_kernel<_Float16, true>) : reinterpret_cast<const void*>(&attn_shared_kernel<_Float16, false>));
         if (lds > 64 * 1024) {   // opt in to more than 64 KiB of dynamic LDS (idempotent, per function)
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
-        if (dtype == CIR_BF16) hipLaunchKernelGGL((attn_shared_kernel<__bf16>), grid, block, lds, s, a, lk_pad);
-        else hipLaunchKernelGGL((attn_shared_kernel<_Float16>), grid, block, lds, s, a, lk_pad);
+        if (bf) { if (mk) hipLaunchKernelGGL((attn_shared_kernel<__bf16, true>), grid, block, lds, s, a, lk_pad); else hipLaunchKernelGGL((attn_shared_kernel<__bf16, false>), grid, block, lds, s, a, lk_pad); }
+        else { if (mk) hipLaunchKernelGGL((attn_shared_kernel<_Float16, true>), grid, block, lds, s, a, lk_pad); else hipLaunchKernelGGL((attn_shared_kernel<_Float16, false>), grid, block, lds, s, a, lk_pad); }
         CIR_LAUNCH_RESULT();
     }
     const int64_t nblk = (a.total + 3) / 4;
     if (nblk > 0x7fffffff) return CIR_ESHAPE;
     dim3 grid((unsigned)nblk), block(256);
-    if (dtype == CIR_BF16) hipLaunchKernelGGL((attn_stream_kernel<__bf16>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((attn_stream_kernel<_Float16>), grid, block, 0, s, a);
+    const bool mk = mask != nullptr;
+    if (dtype == CIR_BF16) { if (mk) hipLaunchKernelGGL((attn_stream_kernel<__bf16, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((attn_stream_kernel<__bf16, false>), grid, block, 0, s, a); }
+    else { if (mk) hipLaunchKernelGGL((attn_stream_kernel<_Float16, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((attn_stream_kernel<_Float16, false>), grid, block, 0, s, a); }
     CIR_LAUNCH_RESULT();
 }
