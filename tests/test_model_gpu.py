@@ -232,6 +232,47 @@ def test_full384_cirr_loop(cuda):
     assert e_bank < 5e-2 and e1 < LOGIT_TOL[torch.bfloat16] and e2 < LOGIT_TOL[torch.bfloat16]
 
 
+def test_full_size_properties(cuda):
+    """BASELINE-size batch (queries x K=100 candidates from pixels, 224 px, the shapes bench.py runs: every large Linear
+    goes through the persistent 256 x 256 GEMM) checked through size-independent properties instead of an oracle run:
+      * rows are independent: permuting the candidates permutes the logits BIT FOR BIT (no kernel reduces across rows,
+        and a row's reduction order does not depend on where the row sits);
+      * batch invariance: a candidate scored in a small batch (128 x 128 GEMM, other tiling) agrees within the bf16 bound;
+      * the order returned by cir_topk_desc is a permutation that sorts the logits (ties only among equal values)."""
+    from candidate_reranking_cir_amd import ops
+    g, v = H.geometry(H.FULL_BERT, dict(image_size=224))
+    m2, m1 = build_models(g, v, 0, "test", torch.bfloat16, cuda)
+    q_n, k = 4, 100
+    gen = torch.Generator(device="cuda").manual_seed(99)
+    images = torch.randn((q_n + q_n * k, 3, 224, 224), generator=gen, device="cuda").bfloat16()
+    ids = torch.stack([synthetic.caption_ids(q, 32) for q in range(q_n)]).cuda()
+    mask = torch.ones_like(ids)
+    qidx = torch.arange(q_n, device="cuda").repeat_interleave(k)
+    toks = m2.img_embed16(images)
+    z = m1.z_t(toks[:q_n], ids, mask).last_hidden_state
+    logits = m2.score(z, ids, mask, toks[q_n:], qidx)
+    assert logits.shape == (q_n * k,) and torch.isfinite(logits).all()
+    # permutation of the candidates (and of their query assignment with them)
+    perm = torch.randperm(q_n * k, generator=torch.Generator().manual_seed(5)).cuda()
+    logits_p = m2.score(z, ids, mask, toks[q_n:][perm], qidx[perm])
+    assert torch.equal(logits_p, logits[perm])
+    # a permutation of the images through the ViT as well
+    iperm = torch.randperm(q_n * k, generator=torch.Generator().manual_seed(6)).cuda()
+    toks_p = m2.img_embed16(images[q_n:][iperm])
+    assert torch.equal(toks_p, toks[q_n:][iperm])
+    # batch invariance against a small batch (other GEMM kernel / tiling)
+    small = m2.score(z[:1], ids[:1], mask[:1], m2.img_embed16(images[q_n:q_n + 6]), torch.zeros(6, dtype=torch.int64, device="cuda"))
+    e = (small - logits[:6]).abs().max().item()
+    print(f"\n[full size] batch-invariance drift {e:.3e}")
+    assert e < LOGIT_TOL[torch.bfloat16]
+    # ranking
+    lv = logits.view(q_n, k)
+    order = ops.argsort_desc(lv)
+    assert torch.equal(torch.sort(order, dim=1).values, torch.arange(k, device="cuda").expand(q_n, k))
+    sorted_l = torch.gather(lv, 1, order)
+    assert (sorted_l[:, 1:] <= sorted_l[:, :-1]).all()
+
+
 def test_state_dict_roundtrip_and_cpu_refusal(cuda):
     from candidate_reranking_cir_amd.blip_stage2 import blip_stage2
     z = H.load("tiny_loop.npz")
