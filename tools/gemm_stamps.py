@@ -6,9 +6,13 @@ os.environ.setdefault("CIR_LIB", os.path.join(os.path.dirname(os.path.dirname(os
 from candidate_reranking_cir_amd import ops, lib
 m, n, k = (int(x) for x in sys.argv[1:4])
 act = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+res = int(sys.argv[5]) if len(sys.argv) > 5 else 0      # 1: fp32 out + fp32 residual in place (proj / fc2 epilogue)
 a = torch.randn((m, k), device="cuda").bfloat16(); w = (torch.randn((n, k), device="cuda") * 0.02).bfloat16(); b = torch.randn((n,), device="cuda")
 out = torch.empty((m, n), device="cuda", dtype=torch.bfloat16)
-for _ in range(3): ops.gemm(a, w, b, act=act, out=out)
+x = torch.randn((m, n), device="cuda") if res else None
+for _ in range(3):
+    if res: ops.gemm(a, w, b, residual=x, out_dtype=torch.float32, out=x)
+    else: ops.gemm(a, w, b, act=act, out=out)
 torch.cuda.synchronize()
 l = lib.load(); l.cir_debug_read_stamps.argtypes = [ctypes.c_void_p]
 buf = np.zeros((2, 64, 8), dtype=np.uint64)
