@@ -8,28 +8,26 @@
 //     rows, the fp32 residual (fetched row-contiguously two passes ahead) and 16-byte stores that drain during the
 //     next main loop.
 //
-// Main-loop schedule (after the 8-phase structure of the CDNA4 programming guide, re-derived with
-// conservative hazards; see DESIGN.md "GEMM"):
+// Main-loop schedule (two-wave-per-SIMD ping-pong after the CDNA4 programming guide, re-derived with conservative
+// hazards and re-cut by measurement; see DESIGN.md "GEMM"):
 //   * LDS holds two K-tiles (dbuf 0/1), each as four 16-KiB half-tiles A0 A1 (activation rows 0-127 /
 //     128-255 of the tile) and B0 B1 (weight rows 0-127 / 128-255); 128 KiB in total, one block per CU.
-//   * a K-tile is consumed in four phases, one 64x32 output quadrant per wave and phase (16 MFMAs):
-//       q0 = (A0,B0)  reads B0 then A0 (12 ds_read_b128)      q1 = (A0,B1)  reads B1 (4)
-//       q2 = (A1,B1)  reads A1 (8)                             q3 = (A1,B0)  reads nothing (B0 fragments kept)
-//   * refills go by LDS-DMA (2 x global_load_lds_dwordx4 per lane and half-tile), always into a half-tile whose last
-//     read lies at least two phases back (the staggered group reads one slot later), as early as that allows:
-//       phase:   1        2     3            4        5        6     7            8
-//       refill:  A1>d1    -     A0,B0>d0     B1>d0    A1>d0    -     A0,B0>d1     B1>d1
-//       tile:    t+1            t+2          t+2      t+2            t+3          t+3
-//     Each half-tile is two 1-KiB pieces per wave, issued BETWEEN the MFMAs of the phase's MFMA segment (one
-//     scheduling region, sched_group_barrier): the ~100 wave-cycles of an LDS-DMA issue then hide in the issue gaps
-//     behind the MFMAs instead of idling the matrix pipe.  The only vector-memory waits in the loop are counted:
-//     `vmcnt(6)` in the read segments of phases 4 / 8 (A0, B0, B1 of the other buffer) and `vmcnt(8)` in those of
-//     phases 2 / 6 (the A1 half-tile, consumed and refilled last): three to four half-tiles stay in flight and every
-//     refill has >= 3.5 phases to land.  (The loop is bound by
-//     operand delivery, not by the MFMA pipe: with the MFMAs compiled out it takes the same time; bytes in flight /
-//     latency is what sets the rate.)  The buffer a wait retires is first read one phase later, behind a barrier.
-//   * the two wave groups (waves 0-3 / 4-7 = the two waves of each SIMD) run staggered by one barrier,
-//     so one group's MFMA segment overlaps the other group's LDS-read / DMA-issue segment.
+//   * a K-tile is consumed in TWO phases of 32 MFMAs per wave, one M-half (64 x 64 outputs per wave) each:
+//       a = (A0 x B0,B1)  reads B0, A0, B1 (16 ds_read_b128)      b = (A1 x B0,B1)  reads A1 (8; weights kept)
+//     phase = { reads + one counted wait } | barrier | { 32 in-place MFMAs, refill pieces between them } | barrier.
+//   * the two wave groups (waves 0-3 / 4-7 = the two waves of each SIMD) run one barrier apart, so one group's MFMA
+//     segment covers the other group's read segment.
+//   * refills go by LDS-DMA (SADDR-form global_load_lds_dwordx4, two 1-KiB pieces per wave and half-tile), always into
+//     a half-tile whose last read lies a full phase back (the other group reads one barrier later):
+//       phase:   a0            b0               a1            b1
+//       refill:  A1>d1 (2)     A0,B0,B1>d0 (6)  A1>d0 (2)     A0,B0,B1>d1 (6)        (pieces per wave)
+//       K-tile:  t+1           t+2              t+2           t+3
+//     Pieces are issued in the 12 idle issue cycles behind an MFMA: as a block between k-steps (with address selects)
+//     an issue idled the matrix pipe ~100 cycles per phase.  The loop body is branch-free (refills past the end of the
+//     tile fetch the next tile's first K-tiles, or re-fetch the last K-tile into a dead slot; the last K-tile pair is
+//     peeled) and waits are counted: `vmcnt(2)` for the other buffer's A0/B0/B1 in the read segment of b, `vmcnt(6)`
+//     for an A1 half-tile in that of a - each one phase (and one barrier) before the first read; every refill has two
+//     phases to land.  A K-tile pair takes ~4400 cycles against 4096 cycles of MFMA issue.
 // Operand layout, swizzle and the swapped MFMA orientation are those of gemm.hip.
 #include <stdlib.h>
 
