@@ -125,19 +125,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         if (!c.interior || !rel_interior) lane_offsets(c.interior);
         rel_interior = c.interior;
     };
-    // Operand stream across tile seams: when this and the next tile are interior (same lane offsets) and K holds an
-    // even number of K-tiles, the refill slots of the LAST iteration - idle otherwise - fetch the next tile's first
-    // K-tile(s), exactly the set a prologue would request, several phases before this tile even ends.
+    // Operand stream across tile seams: when this and the next tile are interior (same lane offsets), the refill slots of
+    // the LAST K-tile pair - which have nothing of this tile left to fetch - request the next tile's first K-tiles,
+    // exactly the set a prologue would request, several phases before this tile even ends.
     const char* A_nx = nullptr;
     const char* W_nx = nullptr;
     bool stream = false;
 
-// One half-tile = two 1-KiB pieces per wave (P selects the piece).  Refills are UNCONDITIONAL and branch-free: past the
-// end of the tile they fetch the next tile's first K-tiles when the seam streams, and otherwise re-fetch this tile's last
-// K-tile into a slot nobody reads again (a later prologue of the same wave overwrites it in order).  Every K-tile
-// therefore issues the same pieces, the counted waits need no cases, and - the point - a phase's MFMA segment stays ONE
-// scheduling region in which the pieces are interleaved between MFMAs (sched_group_barrier below).
-#define KBASE(KT, CUR, NXT) ((KT) < nk ? (CUR) + (KT) * 128 : (stream ? (NXT) + ((KT) - nk) * 128 : (CUR) + (nk - 1) * 128))
+// One half-tile = two 1-KiB pieces per wave (P selects the piece).  Refills are UNCONDITIONAL and branch-free: every
+// K-tile pair issues the same 16 pieces per wave from wave-uniform base pointers computed outside the MFMA segments;
+// in the (peeled) last pair those bases point at the next tile's first K-tiles when the seam streams and otherwise at
+// this tile's last K-tile, re-fetched into a slot nobody reads again (a later prologue of the same wave overwrites it
+// in order).  The counted waits therefore need no cases, and the pieces can sit between the MFMAs.
 // piece P of half-tile H from the K-tile whose (wave-uniform) base pointer is KB
 // (inline asm, SADDR form: wave-uniform 64-bit base in an SGPR pair + the lane's 32-bit offset; the builtin takes a
 // 64-bit per-lane address, i.e. two VALU ops per piece and - hoisted out of the loop by the compiler - 32 more VGPRs)
@@ -146,11 +145,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                  :: "s"((unsigned)(size_t)(lptr_t)(LDS_DST)), "v"(VOFF), "s"(SRC_BASE) : "memory");   /* (M0 is reserved: the compiler re-loads it before each of its own uses) */
 #define PIECE_A(H, DB, KB, P) LDS_DMA(KB, a_off[H][P], stage_base + (DB) * kDbuf + (H) * kHalf + (P) * 1024)
 #define PIECE_B(H, DB, KB, P) LDS_DMA(KB, w_off[H][P], stage_base + (DB) * kDbuf + (2 + (H)) * kHalf + (P) * 1024)
-#define ISSUE_A1(H, DB, KT, P) { const char* kb_ = KBASE(KT, A_z, A_nx); PIECE_A(H, DB, kb_, P) }
-#define ISSUE_B1(H, DB, KT, P) { const char* kb_ = KBASE(KT, W_z, W_nx); PIECE_B(H, DB, kb_, P) }
+// (prologue: K-tiles 0 and 1 of the adopted tile - the dispatcher guarantees at least two)
+#define ISSUE_A1(H, DB, KT, P) { const char* kb_ = A_z + (KT) * 128; PIECE_A(H, DB, kb_, P) }
+#define ISSUE_B1(H, DB, KT, P) { const char* kb_ = W_z + (KT) * 128; PIECE_B(H, DB, kb_, P) }
 #define ISSUE_A(H, DB, KT) ISSUE_A1(H, DB, KT, 0) ISSUE_A1(H, DB, KT, 1)
 #define ISSUE_B(H, DB, KT) ISSUE_B1(H, DB, KT, 0) ISSUE_B1(H, DB, KT, 1)
-    // first K-tile complete in dbuf 0 plus the first two half-tiles of K-tile 1 (what phases 7, 8 would have issued)
+    // first K-tile complete in dbuf 0 plus A0, B0, B1 of K-tile 1 (what the last K-tile pair of a streaming seam issues)
 #define ISSUE_PROLOGUE()                                                \
     ISSUE_A(0, 0, 0) ISSUE_A(1, 0, 0) ISSUE_B(0, 0, 0) ISSUE_B(1, 0, 0) \
     ISSUE_A(0, 1, 1) ISSUE_B(0, 1, 1) ISSUE_B(1, 1, 1)
@@ -172,10 +172,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         wf[H][ni][0] = *reinterpret_cast<const X8*>(b_rd + (DB) * kDbuf + (H) * kHalf + ni * 2048 + c0);  \
         wf[H][ni][1] = *reinterpret_cast<const X8*>(b_rd + (DB) * kDbuf + (H) * kHalf + ni * 2048 + c1);  \
     }
-#define MMA_K(MH, NH, KS)                                                                              \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                   \
-        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                               \
-            acc[MH][mi][NH][ni] = Elem<T>::mfma16(wf[NH][ni][KS], af[mi][KS], acc[MH][mi][NH][ni]);
 #define SYNC()                                   \
     __builtin_amdgcn_sched_barrier(0);           \
     __builtin_amdgcn_s_barrier();                \
@@ -475,7 +471,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
 #undef ISSUE_PROLOGUE
 #undef READ_A
 #undef READ_B
-#undef MMA_K
 #undef MM
 #undef MM4
 #undef PLACE
