@@ -279,7 +279,7 @@ def main():
             "algorithmic_gflop_per_triplet": round(alg["per_triplet"], 2),
             "path_tflops": round(value * alg["per_triplet"] / 1e3, 1),
             "path_frac_of_mfma_peak": round(value * alg["per_triplet"] / 1e3 / (PEAK_TFLOPS[args.dtype] * world), 4),
-            "roofline": {"bound": "mfma", "kernel": "cir::gemm_kernel (all launches of one step)", "achieved": round(achieved, 1),
+            "roofline": {"bound": "mfma", "kernel": "cir::gemm256_kernel + cir::gemm_kernel (every GEMM launch of one step)", "achieved": round(achieved, 1),
                          "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4),
                          "traffic": traffic, "algorithmic_bytes": round(gemm_alg_bytes / max(len(recs), 1)), "launches_per_step": len(recs), "avg_launch_us": round(gemm_ms * 1e3 / max(len(recs), 1), 2),
                          "gemm_share_of_step": round(gemm_ms / step_ms, 3)},
