@@ -1,4 +1,6 @@
-"""Diagnostic: per-tile phase shares of gemm256 from in-kernel s_memtime stamps (libcirrank_stamp.so)."""
+"""Diagnostic: per-tile phase shares of gemm256 from in-kernel s_memtime stamps.
+Build the stamped library first: make -C candidate_reranking_cir_amd/csrc stamp
+  python tools/gemm_stamps.py M N K [act] [residual]"""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
