@@ -1,0 +1,49 @@
+"""bench.py end to end on the GPU box: the single-rank contract line, and the multi-rank launch / gather / timing logic
+exercised with TWO ranks sharing the one GPU (gloo instead of RCCL, which refuses two ranks on a device - the knobs
+bench.py documents as CIR_BENCH_BACKEND / CIR_BENCH_DEVICE).  Child processes only: nothing is exec'ed."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(text: str) -> dict:
+    lines = [ln for ln in text.splitlines() if ln.startswith('{"metric"')]
+    assert lines, text[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_single_rank_contract_line():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--queries", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["value"] > 0 and d["unit"] == "triplets/s" and d["dtype"] == "bf16"
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+
+
+def test_two_rank_dry_run_on_one_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, CIR_BENCH_BACKEND="gloo", CIR_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--queries", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["queries_per_step_per_gpu"] == 2
+    assert r.stdout.count('{"metric"') == 1          # rank 0 alone prints the line
