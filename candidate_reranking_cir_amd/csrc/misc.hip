@@ -6,7 +6,7 @@ namespace cir {
 
 // ---- patchify: one thread per (patch, c, ky) moves a 16-pixel row segment (coalesced 32/64-byte reads) ----
 template <typename TI, typename TO>
-__global__ __launch_bounds__(256) void patchify_kernel(const TI* img, TO* out, int B, int C, int H, int Wd, int p) {
+__global__ __launch_bounds__(256) void patchify_kernel(const TI* img, TO* out, int B, int C, int H, int Wd, int p, int vec) {
     const int gw = Wd / p, gh = H / p;
     const int64_t total = (int64_t)B * gh * gw * C * p;  // row segments
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -20,6 +20,25 @@ __global__ __launch_bounds__(256) void patchify_kernel(const TI* img, TO* out, i
     const int64_t b = t / C;
     const TI* src = img + ((b * C + c) * H + (py * p + ky)) * (int64_t)Wd + px * p;
     TO* dst = out + ((b * gh + py) * gw + px) * (int64_t)(C * p * p) + (c * p + ky) * p;
+    if (vec) {   // the ViT-B/16 case (p = 16, aligned rows): a 16-pixel segment = 32 (or 64) contiguous, aligned bytes
+        if constexpr (sizeof(TI) == 2) {   // same 16-bit type in and out: two 16-byte moves
+            const u32x4* s4 = reinterpret_cast<const u32x4*>(src);
+            u32x4* d4 = reinterpret_cast<u32x4*>(dst);
+            const u32x4 v0 = s4[0], v1 = s4[1];
+            d4[0] = v0;
+            d4[1] = v1;
+        } else {                            // fp32 pixels: four 16-byte loads, packed to two 16-byte stores
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            const float4 a0 = s4[0], a1 = s4[1], a2 = s4[2], a3 = s4[3];
+            u32x4 o0, o1;
+            o0.x = pack2<TO>(a0.x, a0.y); o0.y = pack2<TO>(a0.z, a0.w); o0.z = pack2<TO>(a1.x, a1.y); o0.w = pack2<TO>(a1.z, a1.w);
+            o1.x = pack2<TO>(a2.x, a2.y); o1.y = pack2<TO>(a2.z, a2.w); o1.z = pack2<TO>(a3.x, a3.y); o1.w = pack2<TO>(a3.z, a3.w);
+            u32x4* d4 = reinterpret_cast<u32x4*>(dst);
+            d4[0] = o0;
+            d4[1] = o1;
+        }
+        return;
+    }
     for (int kx = 0; kx < p; ++kx) dst[kx] = static_cast<TO>(static_cast<float>(src[kx]));
 }
 
@@ -223,12 +242,13 @@ extern "C" int cir_patchify(const void* image, int img_dtype, void* patches, int
     const int64_t total = (int64_t)B * C * H * (Wd / patch);
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int vec = patch == 16 && Wd % 16 == 0 && cir_aligned16(image) && cir_aligned16(patches);
     if (dtype16 == CIR_BF16) {
-        if (img_dtype == CIR_F32) hipLaunchKernelGGL((patchify_kernel<float, __bf16>), grid, block, 0, s, (const float*)image, (__bf16*)patches, B, C, H, Wd, patch);
-        else hipLaunchKernelGGL((patchify_kernel<__bf16, __bf16>), grid, block, 0, s, (const __bf16*)image, (__bf16*)patches, B, C, H, Wd, patch);
+        if (img_dtype == CIR_F32) hipLaunchKernelGGL((patchify_kernel<float, __bf16>), grid, block, 0, s, (const float*)image, (__bf16*)patches, B, C, H, Wd, patch, vec);
+        else hipLaunchKernelGGL((patchify_kernel<__bf16, __bf16>), grid, block, 0, s, (const __bf16*)image, (__bf16*)patches, B, C, H, Wd, patch, vec);
     } else {
-        if (img_dtype == CIR_F32) hipLaunchKernelGGL((patchify_kernel<float, _Float16>), grid, block, 0, s, (const float*)image, (_Float16*)patches, B, C, H, Wd, patch);
-        else hipLaunchKernelGGL((patchify_kernel<_Float16, _Float16>), grid, block, 0, s, (const _Float16*)image, (_Float16*)patches, B, C, H, Wd, patch);
+        if (img_dtype == CIR_F32) hipLaunchKernelGGL((patchify_kernel<float, _Float16>), grid, block, 0, s, (const float*)image, (_Float16*)patches, B, C, H, Wd, patch, vec);
+        else hipLaunchKernelGGL((patchify_kernel<_Float16, _Float16>), grid, block, 0, s, (const _Float16*)image, (_Float16*)patches, B, C, H, Wd, patch, vec);
     }
     CIR_LAUNCH_RESULT();
 }

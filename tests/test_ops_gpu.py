@@ -229,6 +229,16 @@ def test_patchify_matches_conv(ops, src):
     torch.testing.assert_close(out, ref, atol=2e-3, rtol=1e-3)
 
 
+def test_patchify_patch8_scalar_path(ops):
+    """Patch sizes other than 16 take the element-wise path."""
+    b, c, hw, p = 2, 3, 32, 8
+    img = _rand((b, c, hw, hw), torch.bfloat16, seed=4)
+    patches = ops.patchify(img, p)
+    torch.cuda.synchronize()
+    ref = F.unfold(img.float(), kernel_size=p, stride=p).transpose(1, 2).reshape(-1, c * p * p)
+    assert torch.equal(patches.float(), ref)
+
+
 def test_vit_assemble(ops):
     b, p, d = 3, 16, 128
     proj, cls, pos = _rand((b * p, d), torch.float32, seed=1), _rand((d,), torch.float32, seed=2), _rand((p + 1, d), torch.float32, seed=3)
