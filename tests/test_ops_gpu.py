@@ -51,7 +51,7 @@ def test_gemm_exact_integers(ops, gemm_tile, dtype, m, n, k):
 @pytest.mark.parametrize("act", [0, 1, 2])
 @pytest.mark.parametrize("out32", [True, False])
 def test_gemm_epilogues(ops, gemm_tile, dtype, act, out32):
-    m, n, k = 333, 256, 192
+    m, n, k = 333, 256, 256          # K % 128 == 0: the forced 256-tile run really is the 256 x 256 kernel
     a, w = _rand((m, k), dtype, seed=1), _rand((n, k), dtype, 0.1, seed=2)
     bias = _rand((n,), torch.float32, seed=3)
     res = _rand((m, n), torch.float32, seed=4)
@@ -62,6 +62,23 @@ def test_gemm_epilogues(ops, gemm_tile, dtype, act, out32):
     torch.cuda.synchronize()
     tol = 1e-4 if out32 else (2e-2 if dtype == torch.bfloat16 else 3e-3)
     assert out.dtype == (torch.float32 if out32 else dtype)
+    torch.testing.assert_close(out.float(), ref, atol=tol * 4, rtol=tol)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", [1, 2])
+@pytest.mark.parametrize("out32", [True, False])
+def test_gemm_activation_without_residual(ops, gemm_tile, dtype, act, out32):
+    """GELU / ReLU epilogues with no residual: the combination the 256 x 256 kernel itself serves (fc1 of every FFN),
+    on a ragged M and several K-tile pairs so that tile seams and the peeled last pair are on the path."""
+    m, n, k = 777, 512, 384
+    a, w = _rand((m, k), dtype, seed=11), _rand((n, k), dtype, 0.1, seed=12)
+    bias = _rand((n,), torch.float32, seed=13)
+    y = a.float() @ w.float().T + bias
+    ref = F.gelu(y) if act == 1 else F.relu(y)
+    out = ops.gemm(a, w, bias, act=act, out_dtype=torch.float32 if out32 else dtype)
+    torch.cuda.synchronize()
+    tol = 1e-4 if out32 else (2e-2 if dtype == torch.bfloat16 else 3e-3)
     torch.testing.assert_close(out.float(), ref, atol=tol * 4, rtol=tol)
 
 
