@@ -61,5 +61,5 @@ def sharded_scores(score_rows: Callable[[Sequence[int]], torch.Tensor], n_querie
         dist.all_gather_into_tensor(gathered, block)
     gathered = gathered[:n_queries]
     out = torch.empty_like(gathered)
-    out[torch.as_tensor(order, device=device)] = gathered
+    out[torch.as_tensor(order, dtype=torch.int64, device=device)] = gathered   # (int64 also when the list is empty)
     return out

@@ -52,6 +52,15 @@ def test_two_rank_gather_equals_single_process(n_q, use_balance):
         np.testing.assert_array_equal(ret[r], expect)
 
 
+def test_empty_and_tiny_query_sets_single_process():
+    """No queries at all (an empty split) and fewer queries than ranks are valid inputs."""
+    import torch
+    out = D.sharded_scores(lambda rows: torch.zeros((len(rows), 3)), n_queries=0, k=3, device=torch.device("cpu"))
+    assert out.shape == (0, 3)
+    out = D.sharded_scores(lambda rows: torch.full((len(rows), 2), 7.0), n_queries=1, k=2, device=torch.device("cpu"))
+    assert out.tolist() == [[7.0, 7.0]]
+
+
 def test_shard_bounds_cover_everything():
     for n in (0, 1, 7, 8, 4181):
         for world in (1, 2, 8):
