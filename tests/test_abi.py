@@ -47,3 +47,45 @@ def test_ops_refuse_cpu_tensors():
     from candidate_reranking_cir_amd.lib import CirrankError
     with pytest.raises(CirrankError):
         ops.gemm(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(16, 64, dtype=torch.bfloat16))
+
+
+def test_argument_validation_happens_before_any_launch():
+    """Every entry point checks pointers, extents, alignment and dtype codes on the host and returns a negative CIR_E*
+    code without touching the device - so the error contract of include/cirrank.h can be checked without a GPU
+    (fake, never dereferenced addresses stand in for device pointers)."""
+    from candidate_reranking_cir_amd import lib
+    c = lib.load()
+    EINVAL, ESHAPE, EALIGN, EDTYPE = -1, -2, -3, -4
+    P = 0x10000          # 16-byte aligned fake device address
+    BF16, F16, F32 = 0, 1, 2
+    gemm = c.cir_gemm_bias_act
+    ok_args = [P, 64, 0, P, 64, 0, None, 0, None, 0, 0, P, 16, 0, 4, 16, 64, 1, 0, BF16, BF16, None]
+
+    def call(**over):
+        names = ["A", "lda", "sA", "W", "ldw", "sW", "bias", "sB", "res", "ldr", "sR", "C", "ldc", "sC", "M", "N", "K", "batch",
+                 "act", "in_dtype", "out_dtype", "stream"]
+        a = dict(zip(names, ok_args))
+        a.update(over)
+        return gemm(*[a[n] for n in names])
+
+    assert call(A=None) == EINVAL and call(C=None) == EINVAL and call(M=0) == EINVAL and call(batch=0) == EINVAL
+    assert call(act=7) == EINVAL
+    assert call(K=60) == ESHAPE and call(N=17) == ESHAPE
+    assert call(A=P + 2) == EALIGN and call(lda=60) == EALIGN and call(bias=P + 4) == EALIGN and call(res=P + 8, ldr=16) == EALIGN
+    assert call(in_dtype=F32) == EDTYPE and call(in_dtype=BF16, out_dtype=F16) == EDTYPE
+    # LayerNorm / attention / top-k: the same contract
+    assert c.cir_layernorm(None, 0, None, 0, P, P, 0, P, None, 0, 4, 64, 1, 1e-6, BF16, None) == EINVAL
+    assert c.cir_layernorm(P, 0, None, 0, P, P, 0, None, None, 0, 4, 64, 1, 1e-6, BF16, None) == EINVAL      # no output at all
+    assert c.cir_layernorm(P, 0, None, 0, P, P, 0, P, None, 0, 4, 2048, 1, 1e-6, BF16, None) == ESHAPE       # cols > 1024
+    assert c.cir_layernorm(P, 0, None, 0, P, P, 0, P, None, 0, 4, 64, 1, 1e-6, F32, None) == EDTYPE
+    att = [P, 64, 64, 64, P, 64, 64, 64, P, 64, 64, 64, None, 0, 0, None, P, 64, 64, 64, 1, 1, 1, 4, 4, 0.125, BF16, None]
+    # (the valid argument list itself is never passed: it would launch)
+    bad = list(att); bad[0] = None
+    assert c.cir_attention(*bad) == EINVAL
+    bad = list(att); bad[1] = 60
+    assert c.cir_attention(*bad) == EALIGN
+    bad = list(att); bad[26] = F32
+    assert c.cir_attention(*bad) == EDTYPE
+    assert c.cir_topk_desc(P, P, 1, 9000, None) == ESHAPE and c.cir_topk_desc(None, P, 1, 8, None) == EINVAL
+    for code, word in ((EINVAL, b"null"), (ESHAPE, b"extent"), (EALIGN, b"aligned"), (EDTYPE, b"dtype")):
+        assert word in c.cir_strerror(code).lower()
