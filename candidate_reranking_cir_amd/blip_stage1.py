@@ -91,11 +91,8 @@ class BLIP_Retrieval(_EngineHost):
 def blip_stage1(pretrained: str = "", **kwargs) -> BLIP_Retrieval:
     model = BLIP_Retrieval(**kwargs)
     if pretrained:
-        if not os.path.isfile(pretrained):
-            raise RuntimeError("checkpoint url or path is invalid")
-        ckpt = torch.load(pretrained, map_location="cpu")
-        sd = ckpt.get("BLIP_Retrieval", ckpt.get("model", ckpt))
-        msg = model.load_state_dict(sd, strict=False)
+        from .checkpoint import load_stage1_checkpoint
+        model, msg = load_stage1_checkpoint(model, pretrained)      # blip.py:215-237 semantics
         print("missing keys:")
         print(msg.missing_keys)
     return model

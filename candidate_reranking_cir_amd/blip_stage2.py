@@ -171,15 +171,13 @@ class BLIP_NLVR(_EngineHost):
 
 
 def blip_stage2(pretrained: str = "", **kwargs) -> BLIP_NLVR:
-    """Factory with the reference's signature (blip_stage2.py:139-145).  `pretrained` may name a
-    local checkpoint holding either {'BLIP_NLVR': state_dict} (utils.py:145-150) or a plain state dict."""
+    """Factory with the reference's signature (blip_stage2.py:139-145).  `pretrained` names a local BLIP base
+    checkpoint ({'model': ...}: position embedding resized, single-branch BERT weights copied to both branches, as
+    blip_stage2.py:148-190 does), or a file holding {'BLIP_NLVR': state_dict} (utils.py:145-150) / a plain state dict."""
     model = BLIP_NLVR(**kwargs)
     if pretrained:
-        if not os.path.isfile(pretrained):
-            raise RuntimeError("checkpoint url or path is invalid")        # no network on this path
-        ckpt = torch.load(pretrained, map_location="cpu")
-        sd = ckpt.get("BLIP_NLVR", ckpt.get("model", ckpt))
-        msg = model.load_state_dict(sd, strict=False)
+        from .checkpoint import load_stage2_checkpoint
+        model, msg = load_stage2_checkpoint(model, pretrained)
         print("missing keys:")
         print(msg.missing_keys)
     return model

@@ -273,8 +273,46 @@ def stage1_goldens(R):
     print("   test dicts", list(d_rec.items())[:2], list(d_sub.items())[:2])
 
 
+def checkpoint_goldens(R):
+    """What the reference's own checkpoint loaders (blip_stage2.load_checkpoint, blip.load_checkpoint) make of a BLIP
+    base style file whose ViT was trained on a LARGER image (position-embedding resize) - recorded as per-tensor
+    checksums of the loaded models plus the reported missing keys."""
+    big = dict(TINY_VIT, image_size=96)                       # 6 x 6 + 1 positions in the file, 4 x 4 + 1 in the model
+    g = cfgmod.BertGeometry.from_dict(TINY_BERT)
+    base = weights.synth_state_dict(weights.retrieval_param_spec(g, cfgmod.VitGeometry(**big)), 77, "test")
+    base["text_encoder.embeddings.position_ids"] = torch.arange(g.max_position_embeddings).unsqueeze(0)
+    with tempfile.NamedTemporaryFile(suffix=".pth", delete=False) as fh:
+        path = fh.name
+    torch.save({"model": base}, path)
+    try:
+        m2, m1, g, v = build_reference_models(R, TINY_BERT, TINY_VIT, seed=3, profile="test")
+        _, msg2 = R.s2.load_checkpoint(m2, path)
+        _, msg1 = R.blip.load_checkpoint(m1, path)
+    finally:
+        os.unlink(path)
+    out = {"seed": 77, "profile": "test", "bert_cfg": json.dumps(TINY_BERT), "vit_cfg": json.dumps(TINY_VIT), "file_vit_cfg": json.dumps(big),
+           "model_seed": 3}
+    for tag, m, msg in (("s2", m2, msg2), ("s1", m1, msg1)):
+        sd = m.state_dict()
+        names = sorted(k for k in sd if sd[k].is_floating_point())
+        out[tag + "_names"] = np.array(names)
+        out[tag + "_sum"] = np.array([sd[k].double().sum().item() for k in names])
+        out[tag + "_abs"] = np.array([sd[k].double().abs().sum().item() for k in names])
+        out[tag + "_missing"] = np.array(sorted(msg.missing_keys))
+        out[tag + "_unexpected"] = np.array(sorted(msg.unexpected_keys))
+    out["s2_pos_embed"] = m2.state_dict()["visual_encoder.pos_embed"].numpy()
+    np.savez_compressed(os.path.join(OUT, "ckpt_tiny.npz"), **out)
+    print("ckpt_tiny: stage II missing", len(msg2.missing_keys), "unexpected", len(msg2.unexpected_keys),
+          "| stage I missing", len(msg1.missing_keys), "unexpected", len(msg1.unexpected_keys))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "ckpt":     # only the checkpoint-loader fixture
+        torch.manual_seed(0)
+        R = ref_shim.load_reference_modules()
+        _install_torchvision_stub()
+        return checkpoint_goldens(R)
     if len(sys.argv) > 1 and sys.argv[1] == "stage1":   # only the stage-I / submission fixtures
         torch.manual_seed(0)
         torch.set_num_threads(8)
