@@ -183,9 +183,9 @@ def main():
 
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     g, v = config.BertGeometry(), config.VitGeometry(image_size=args.image_size)
-    m2 = BLIP_NLVR(med_config=g, vit_geometry=v)
+    m2 = BLIP_NLVR(med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer())
     m2.load_state_dict(weights.synth_state_dict(weights.nlvr_param_spec(g, v), 0, "test"))
-    m1 = BLIP_Retrieval(med_config=g, vit_geometry=v)
+    m1 = BLIP_Retrieval(med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer())
     m1.load_state_dict(weights.synth_state_dict(weights.retrieval_param_spec(g, v), 1, "test"))
     m2 = m2.to(dev).eval().set_compute_dtype(dt)
     m1 = m1.to(dev).eval().set_compute_dtype(dt)

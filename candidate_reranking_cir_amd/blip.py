@@ -14,12 +14,28 @@ from .synthetic import HashTokenizer
 
 
 def init_tokenizer(vocab_file: Optional[str] = None, allow_fallback: bool = False):
-    """BertTokenizer + '[DEC]' (bos) + '[ENC]' with `.enc_token_id`, exactly as blip.py:186-191."""
+    """BertTokenizer + '[DEC]' (bos) + '[ENC]' with `.enc_token_id`, exactly as blip.py:186-191.
+
+    `vocab_file` is a WordPiece `vocab.txt` (or a directory holding one); without it the `bert-base-uncased` entry of
+    the local HuggingFace cache is used (no download is attempted).  The two added tokens take the ids vocab_size and
+    vocab_size + 1 (30522 / 30523 for bert-base-uncased)."""
     try:
         from transformers import BertTokenizer
-        tok = BertTokenizer.from_pretrained(vocab_file or "bert-base-uncased", local_files_only=True)   # directory / cache with vocab.txt
-        if tok.vocab_size < 30000:   # transformers >= 5 builds an EMPTY tokenizer instead of failing when nothing is cached
-            raise FileNotFoundError("bert-base-uncased vocabulary (30522 entries) not found")
+        if vocab_file is not None:
+            path = os.path.join(vocab_file, "vocab.txt") if os.path.isdir(vocab_file) else vocab_file
+            if not os.path.isfile(path):
+                raise FileNotFoundError(path)
+            import inspect
+            if "vocab_file" in inspect.signature(BertTokenizer.__init__).parameters:          # transformers 4.x (reference pins 4.25)
+                tok = BertTokenizer(vocab_file=path, do_lower_case=True)                      # bert-base-uncased settings
+            else:                                                                             # transformers 5.x: token -> id mapping
+                with open(path, encoding="utf-8") as fh:
+                    vocab = {line.rstrip("\n"): i for i, line in enumerate(fh)}
+                tok = BertTokenizer(vocab=vocab, do_lower_case=True)
+        else:
+            tok = BertTokenizer.from_pretrained("bert-base-uncased", local_files_only=True)
+            if tok.vocab_size < 30000:   # transformers >= 5 builds an EMPTY tokenizer instead of failing when nothing is cached
+                raise FileNotFoundError("bert-base-uncased vocabulary (30522 entries) not found in the local cache")
     except Exception as exc:  # no vocabulary available offline
         if allow_fallback:
             return HashTokenizer()

@@ -13,11 +13,10 @@ from typing import Optional, Union
 import torch
 
 from . import ops
-from .blip_stage2 import _EngineHost, encode_text, load_bert_geometry
+from .blip_stage2 import _EngineHost, default_tokenizer, encode_text, load_bert_geometry
 from .config import BertGeometry, VitGeometry
 from .engine import MedEngine, VitEngine
 from .param_tree import populate
-from .synthetic import HashTokenizer
 from .weights import retrieval_param_spec
 
 
@@ -37,7 +36,7 @@ class BLIP_Retrieval(_EngineHost):
         self.vit_geometry = vit_geometry or VitGeometry.named(vit, image_size)
         self.bert_geometry = load_bert_geometry(med_config)
         self.bert_geometry.encoder_width = self.vit_geometry.width
-        self.tokenizer = tokenizer if tokenizer is not None else HashTokenizer()
+        self.tokenizer = tokenizer if tokenizer is not None else default_tokenizer()
         populate(self, retrieval_param_spec(self.bert_geometry, self.vit_geometry, embed_dim))
         self.text_encoder.config = self.bert_geometry
 
@@ -91,6 +90,9 @@ class BLIP_Retrieval(_EngineHost):
 def blip_stage1(pretrained: str = "", **kwargs) -> BLIP_Retrieval:
     model = BLIP_Retrieval(**kwargs)
     if pretrained:
+        if model.tokenizer is None:
+            raise RuntimeError("blip_stage1(pretrained=...): real weights need the real WordPiece tokenizer, and no bert-base-uncased "
+                               "vocabulary was found - pass tokenizer=blip.init_tokenizer(vocab_file=...)")
         from .checkpoint import load_stage1_checkpoint
         model, msg = load_stage1_checkpoint(model, pretrained)      # blip.py:215-237 semantics
         print("missing keys:")

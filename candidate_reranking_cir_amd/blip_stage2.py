@@ -21,8 +21,19 @@ from . import ops
 from .config import BertGeometry, VitGeometry
 from .engine import NlvrEngine, VitEngine
 from .param_tree import ParamNode, populate
-from .synthetic import HashTokenizer
 from .weights import nlvr_param_spec
+
+
+def default_tokenizer():
+    """What the reference's constructors do (blip_stage2.py:38-44, blip_stage1.py:34): the real WordPiece tokenizer with
+    [DEC] / [ENC].  Offline there may be no vocabulary; the model then has NO tokenizer and refuses strings loudly
+    (`encode_text`) instead of silently hashing words - pass `tokenizer=synthetic.HashTokenizer()` (tests, benchmark)
+    or `tokenizer=blip.init_tokenizer(vocab_file=...)` explicitly.  Pre-tokenised ids always work."""
+    from .blip import init_tokenizer
+    try:
+        return init_tokenizer()
+    except RuntimeError:
+        return None
 
 def load_bert_geometry(med_config) -> BertGeometry:
     """`med_config` is a path to a JSON file with the reference's keys (blip_stage2.py:46-47 reads
@@ -49,7 +60,8 @@ def encode_text(tokenizer, text, device):
         ids, mask = text.input_ids, text.attention_mask
     else:
         if tokenizer is None:
-            raise RuntimeError("no tokenizer set: pass token ids or assign model.tokenizer")
+            raise RuntimeError("no tokenizer: the bert-base-uncased vocabulary is not available offline - assign model.tokenizer = "
+                               "blip.init_tokenizer(vocab_file=...) (or synthetic.HashTokenizer() for synthetic data), or pass token ids")
         enc = tokenizer(text, padding="longest", return_tensors="pt")
         ids, mask = enc.input_ids, enc.attention_mask
     ids = ids.to(device=device, dtype=torch.int64).clone()
@@ -96,7 +108,7 @@ class BLIP_NLVR(_EngineHost):
         self.bert_geometry = load_bert_geometry(med_config)
         self.bert_geometry.encoder_width = self.vit_geometry.width          # blip_stage2.py:47
         self.fold_merge = fold_merge
-        self.tokenizer = tokenizer if tokenizer is not None else HashTokenizer()
+        self.tokenizer = tokenizer if tokenizer is not None else default_tokenizer()
         populate(self, nlvr_param_spec(self.bert_geometry, self.vit_geometry))
         self.text_encoder.config = self.bert_geometry                        # callers read .config.hidden_size
 
@@ -176,6 +188,9 @@ def blip_stage2(pretrained: str = "", **kwargs) -> BLIP_NLVR:
     blip_stage2.py:148-190 does), or a file holding {'BLIP_NLVR': state_dict} (utils.py:145-150) / a plain state dict."""
     model = BLIP_NLVR(**kwargs)
     if pretrained:
+        if model.tokenizer is None:
+            raise RuntimeError("blip_stage2(pretrained=...): real weights need the real WordPiece tokenizer, and no bert-base-uncased "
+                               "vocabulary was found - pass tokenizer=blip.init_tokenizer(vocab_file=...)")
         from .checkpoint import load_stage2_checkpoint
         model, msg = load_stage2_checkpoint(model, pretrained)
         print("missing keys:")

@@ -22,7 +22,6 @@
 //     current one is processed: the text-side cases (32 x 32 self-attention, 32 x 197 / 32 x 577
 //     cross-attention) where nothing is shared between waves, and any Lk > 608.
 // Ragged extents: rows beyond Lq / Lk are clamped or zero-filled on load; scores of keys >= Lk are -inf.
-#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -337,8 +336,8 @@ extern "C" int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t 
     const int lk_pad = (Lk + 31) & ~31;
     // K/V of a head are shared by its query tiles: stage them once per workgroup when there are several tiles
     // (up to 608 keys = 152 KiB of LDS: the 577-token ViT of the reference's 384-px scripts still fits one CU)
-    bool shared = a.nqt >= 2 && lk_pad <= 608;
-    if (const char* e = getenv("CIR_ATTN_SHARED_MAX")) shared = a.nqt >= 2 && lk_pad <= atoi(e);   // tests, A/B
+    const int shared_max = g_tune[CIR_TUNE_ATTN_SHARED_MAX] == 0 ? 608 : g_tune[CIR_TUNE_ATTN_SHARED_MAX];   // (-1: never)
+    const bool shared = a.nqt >= 2 && lk_pad <= shared_max;
     if (shared) {
         const int64_t nblk = (int64_t)B1 * B0 * H;
         if (nblk > 0x7fffffff) return CIR_ESHAPE;

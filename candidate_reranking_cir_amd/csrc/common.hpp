@@ -133,6 +133,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 }  // namespace cir
 
 // ---- host side ----------------------------------------------------------------------------------
+namespace cir {
+// kernel-selection overrides (cir_set_tuning; misc.hip owns the storage): 0 = automatic
+extern int g_tune[3];
+}  // namespace cir
 #define CIR_CHECK_PTR(p) do { if ((p) == nullptr) return CIR_EINVAL; } while (0)
 #define CIR_LAUNCH_RESULT() do { hipError_t e_ = hipGetLastError(); return e_ == hipSuccess ? CIR_OK : (int)e_; } while (0)
 static inline bool cir_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

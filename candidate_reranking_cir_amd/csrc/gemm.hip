@@ -15,7 +15,6 @@
 //     features of one output row -> 16/32/64-byte vector stores, fp32 bias/residual as float4.
 //   * Workgroup -> tile mapping is XCD-aware (blocks that share an XCD's L2 walk neighbouring
 //     tiles of one row panel, so the A panel is fetched from HBM once per XCD).
-#include <stdlib.h>
 
 #include "gemm_args.hpp"
 
@@ -207,15 +206,13 @@ extern "C" int cir_gemm_bias_act(const void* A, int64_t lda, int64_t strideA, co
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool f32out = out_dtype == CIR_F32;
     // Tile choice: the 256x256 8-phase kernel needs about a full wave of workgroups (256 CUs) to pay;
-    // small problems keep the 128x128 kernel (more, smaller tiles).  CIR_GEMM_TILE=128|256 forces one (tests, A/B).
+    // small problems keep the 128x128 kernel (more, smaller tiles).  cir_set_tuning(CIR_TUNE_GEMM_TILE, 128|256) forces one.
     const int64_t nblk256 = ((M + 255) / 256) * ((N + 255) / 256) * batch;
     // (the 256 kernel adds the residual in its fp32 row layout: linear fp32-out epilogues only; 32-bit operand offsets)
     bool use256 = N >= 256 && nblk256 >= 192;
     const bool can256 = !(residual && (act != CIR_ACT_NONE || !f32out)) && K % 128 == 0 && lda < (1 << 21) && ldw < (1 << 21);   // K-tile pairs; tile-relative 32-bit offsets
-    if (const char* force = getenv("CIR_GEMM_TILE")) {
-        if (force[0] == '1') use256 = false;
-        else if (force[0] == '2') use256 = true;
-    }
+    if (g_tune[CIR_TUNE_GEMM_TILE] == 128) use256 = false;
+    else if (g_tune[CIR_TUNE_GEMM_TILE] == 256) use256 = true;
     if (use256 && can256) {
         launch_gemm256(a, in_dtype, f32out, s);
         CIR_LAUNCH_RESULT();

@@ -29,7 +29,6 @@
 //     for an A1 half-tile in that of a - each one phase (and one barrier) before the first read; every refill has two
 //     phases to land.  A K-tile pair takes ~4400 cycles against 4096 cycles of MFMA issue.
 // Operand layout, swizzle and the swapped MFMA orientation are those of gemm.hip.
-#include <stdlib.h>
 
 #include "gemm_args.hpp"
 
@@ -516,7 +515,7 @@ void launch_gemm256(const GemmArgs& a_in, int in_dtype, bool f32out, hipStream_t
         const float cost = d + 32.0f / d + (a.tiles_n % d ? 1.5f : 0.f);
         if (cost < best) { best = cost; gw = d; }
     }
-    if (const char* e = getenv("CIR_GEMM_GW")) { const int v = atoi(e); if (v > 0) gw = v < a.tiles_n ? v : a.tiles_n; }
+    if (const int v = g_tune[CIR_TUNE_GEMM_GROUP_W]; v > 0) gw = v < a.tiles_n ? v : a.tiles_n;
     a.group_w = gw;
     const int64_t g = persistent_grid();
     dim3 grid((unsigned)(ntiles < g ? ntiles : g)), block(512);

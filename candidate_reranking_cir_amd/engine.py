@@ -11,7 +11,6 @@ nlvr_encoder.py:414-476 / 777-908, blip_stage2.py:101-136.
 """
 from __future__ import annotations
 
-import os
 from typing import Dict, Optional
 
 import torch
@@ -176,7 +175,7 @@ class NlvrEngine:
         geo.validate()
         self.geo, self.dtype, self.device, self.fold_merge = geo, dtype, device, fold_merge
         self.trim_last = True   # last layer: per-token work on the CLS rows only (results identical for the rows that are used)
-        self.kv_chunk = int(os.environ.get("CIR_KV_CHUNK", "0"))   # candidates per K|V + cross-attention chunk (0 = all at once)
+        self.kv_chunk = 0       # candidates per K|V + cross-attention chunk (0 = all at once; attribute, for A/B runs)
         e = prefix + "embeddings."
         self.word, self.posemb = _f32(sd[e + "word_embeddings.weight"], device), _f32(sd[e + "position_embeddings.weight"], device)
         self.ge, self.be = _f32(sd[e + "LayerNorm.weight"], device), _f32(sd[e + "LayerNorm.bias"], device)
@@ -307,7 +306,7 @@ class NlvrEngine:
             qc = ops.gemm(a16, ly["wq"], ly["bq"]).view(2, t_n, lq, d).permute(1, 0, 2, 3)              # (T, 2, Lq, D) view
             ccl = cc if not cls_only else torch.empty((t_n, 1, 2, d), dtype=dt, device=cc.device)
             if kv_bank is None:
-                # K|V projection + cross-attention, optionally in candidate chunks (CIR_KV_CHUNK; measured: no gain from
+                # K|V projection + cross-attention, optionally in candidate chunks (`kv_chunk`; measured: no gain from
                 # keeping a chunk's K|V in the Infinity Cache, so the default is one launch each)
                 step_c = self.kv_chunk if self.kv_chunk > 0 else t_n
                 for c0 in range(0, t_n, step_c):

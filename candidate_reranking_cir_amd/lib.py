@@ -13,12 +13,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CIR_LIB", os.path.join(_HERE, "libcirrank.so"))   # CIR_LIB: A/B a second build
 
 CIR_BF16, CIR_F16, CIR_F32 = 0, 1, 2
+TUNE_GEMM_TILE, TUNE_GEMM_GROUP_W, TUNE_ATTN_SHARED_MAX = 0, 1, 2   # cir_set_tuning knobs (tests / A-B only)
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 # name -> argtypes; mirrors include/cirrank.h declaration by declaration
 SIGNATURES = {
     "cir_version": (c_int, []),
     "cir_strerror": (c_char_p, [c_int]),
+    "cir_set_tuning": (c_int, [c_int, c_int]),
     "cir_gemm_bias_act": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                                   c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                   c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -66,6 +68,11 @@ def load() -> ctypes.CDLL:
         raise ImportError(f"libcirrank.so ABI {lib.cir_version()} != expected {ABI_VERSION}: rebuild")
     _lib = lib
     return lib
+
+
+def set_tuning(knob: int, value: int):
+    """Kernel-selection override (include/cirrank.h: cir_set_tuning); 0 restores the automatic choice."""
+    check(load().cir_set_tuning(knob, value), "cir_set_tuning")
 
 
 def check(code: int, what: str):

@@ -27,6 +27,27 @@ def images(ids: Sequence[int], size: int = 224) -> torch.Tensor:
     return torch.stack([image(i, size) for i in ids])
 
 
+def scene_image(image_id: int, size: int = 224) -> torch.Tensor:
+    """A structured synthetic image: per-image colour offset + three oriented sinusoidal gratings + a little noise.
+    Unlike `image` (i.i.d. noise, statistically identical for every id) its ViT tokens carry a strong per-image
+    signature, so candidates of one query receive well separated logits even with random-init weights - the inputs
+    of the rank-order fixtures (tests/golden/rank224.npz).  Pure numpy float64 arithmetic, then one cast."""
+    import math
+    rng = np.random.RandomState(7000 + int(image_id))
+    lin = np.linspace(-1.0, 1.0, size)
+    yy, xx = np.meshgrid(lin, lin, indexing="ij")
+    img = np.zeros((3, size, size), dtype=np.float64) + rng.randn(3, 1, 1) * 1.5
+    for _ in range(3):
+        theta, freq, phase = rng.rand() * math.pi, rng.uniform(1.0, 12.0), rng.rand() * 2.0 * math.pi
+        amp = rng.randn(3, 1, 1) * 0.6
+        img += amp * np.sin(freq * math.pi * (xx * math.cos(theta) + yy * math.sin(theta)) + phase)
+    return torch.from_numpy(img.astype(np.float32)) + 0.2 * image(image_id, size)
+
+
+def scene_images(ids: Sequence[int], size: int = 224) -> torch.Tensor:
+    return torch.stack([scene_image(i, size) for i in ids])
+
+
 def caption_ids(query_id: int, length: int = 32) -> torch.Tensor:
     g = torch.Generator(device="cpu")
     g.manual_seed(2000 + int(query_id))

@@ -79,7 +79,8 @@ def _length_buckets(ds: RelativeValSet, tokenizer, rows: Sequence[int]):
     if ds.input_ids is not None:
         lens = ds.attention_mask[list(rows)].sum(1).tolist()
     else:
-        lens = [int(tokenizer(ds.captions[i]).input_ids.shape[1]) for i in rows]
+        # (works for any tokenizer with the HF call convention: a real BertTokenizer returns plain lists for a single string)
+        lens = [int(tokenizer([ds.captions[i]], padding="longest", return_tensors="pt").attention_mask.sum()) for i in rows]
     buckets = {}
     for r, n in zip(rows, lens):
         buckets.setdefault(int(n), []).append(r)

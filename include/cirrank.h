@@ -10,7 +10,8 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer (tensor.data_ptr()); the caller owns all buffers; the
- *     library allocates nothing, keeps no state, never synchronises the device;
+ *     library allocates nothing, never synchronises the device, and keeps no state besides the
+ *     kernel-selection overrides of cir_set_tuning (default: none) and the cached CU count;
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
  *     work is enqueued on it and nowhere else;
  *   - leading dimensions / strides are in ELEMENTS of the tensor they describe;
@@ -29,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIR_ABI_VERSION 3
+#define CIR_ABI_VERSION 4
 
 enum { CIR_BF16 = 0, CIR_F16 = 1, CIR_F32 = 2 };
 enum { CIR_ACT_NONE = 0, CIR_ACT_GELU = 1, CIR_ACT_RELU = 2 };
@@ -43,6 +44,20 @@ enum {
 
 int cir_version(void);
 const char* cir_strerror(int code);
+
+/*
+ * Kernel-selection overrides for tests and A/B measurements (the library reads NO environment
+ * variables).  Every knob defaults to 0 = automatic choice; a process that never calls this
+ * function always gets the automatic choice.  Returns CIR_EINVAL for an unknown knob or a
+ * value outside the knob's range.  Not part of any reference interface.
+ *   CIR_TUNE_GEMM_TILE        0 auto | 128 | 256 : force the 128x128 or the persistent 256x256 GEMM
+ *                             kernel where the shape allows it (cir_gemm_bias_act)
+ *   CIR_TUNE_GEMM_GROUP_W     0 auto | 1..64    : n-panels per raster group of the 256x256 kernel
+ *   CIR_TUNE_ATTN_SHARED_MAX  0 auto (608) | -1 never | 32..608 : largest padded key count for which
+ *                             cir_attention stages a head's K/V once per workgroup in LDS
+ */
+enum { CIR_TUNE_GEMM_TILE = 0, CIR_TUNE_GEMM_GROUP_W = 1, CIR_TUNE_ATTN_SHARED_MAX = 2 };
+int cir_set_tuning(int knob, int value);
 
 /*
  * C[b] = act(A[b] * W[b]^T + bias[b]) (+ residual[b]),   b = 0..batch-1

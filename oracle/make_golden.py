@@ -20,6 +20,13 @@ and `.weights`, so fixtures hold only seeds, small input checksums and the refer
                   synthetic (Q,K) logit/label matrices (prediction generators stubbed out).
   stage1_tiny.npz stage-I retrieval (validate.py) incl. the top-K files the reference writes itself, and the
                   CIRR test-split prediction dicts of cirr_test_submission_stage2.py (`make_golden.py stage1`).
+  rank224.npz     rank-order fixture at the benchmark geometry (224 px, hidden 768, 12 layers): a 256-image bank of
+                  STRUCTURED images (synthetic.scene_image: candidates get well separated logits) scored by the
+                  reference's own loops at K=100 (+5 CIRR subset, one skipped row), K=50 (FashionIQ style) and K=200
+                  (+5); labels placed on candidates whose logit is isolated, so Recall@k is decided by a margin; the
+                  reference's recall tuples for those labels (`make_golden.py rank`, ~4 minutes).
+  bxb224.npz      training-mode surface `BLIP_NLVR.img_txt_fusion` (blip_stage2.py:65-99) in eval mode: B=4 ragged
+                  captions (padding='longest' -> real masks) -> (B,B) logits (`make_golden.py rank`).
 """
 from __future__ import annotations
 
@@ -306,8 +313,144 @@ def checkpoint_goldens(R):
           "| stage I missing", len(msg1.missing_keys), "unexpected", len(msg1.unexpected_keys))
 
 
+def _import_reference_scripts():
+    cwd = os.getcwd()
+    os.chdir(ref_shim.REFERENCE_ROOT)
+    import utils as ref_utils          # reference src/utils.py
+    import validate_stage2 as ref_val  # reference src/validate_stage2.py
+    os.chdir(cwd)
+    return ref_utils, ref_val
+
+
+RANK_TOL = 8e-3      # margin unit of the rank fixture: ~2x the bf16 logit drift measured on MI355X for these weights
+
+
+def _rank_interval(row: np.ndarray, value: float, skip: int, margin: float):
+    """Possible ranks [lo, hi] of a candidate with logit `value` among the other entries of `row` (index `skip`
+    excluded) when every logit may move by up to margin / 2."""
+    others = np.delete(row, skip) if skip >= 0 else row
+    return int((others > value + margin).sum()), int((others >= value - margin).sum())
+
+
+def _robust(row: np.ndarray, value: float, skip: int, margin: float, bounds) -> bool:
+    lo, hi = _rank_interval(row, value, skip, margin)
+    return not any(lo < k <= hi for k in bounds)
+
+
+def _pick_robust(row: np.ndarray, want_rank: int, margin: float, bounds, also=None):
+    """Candidate index closest to sorted position `want_rank` whose Recall@k membership (k in bounds) cannot change
+    under per-logit perturbations below margin / 2; `also(i)` is an extra acceptance test."""
+    order = np.argsort(-row, kind="stable")
+    for pos in sorted(range(len(row)), key=lambda p: abs(p - want_rank)):
+        i = int(order[pos])
+        if _robust(row, row[i], i, margin, bounds) and (also is None or also(i)):
+            return i
+    raise AssertionError("no robust candidate: lower the margin")
+
+
+def rank_goldens(R, ref_val, full_bert):
+    """tests/golden/rank224.npz + bxb224.npz (see the module docstring)."""
+    m2, m1, g, v = build_reference_models(R, full_bert, dict(image_size=224, width=768, depth=12, num_heads=12), seed=21, profile="test")
+    n_index = 256
+    names = ["img%04d" % i for i in range(n_index)]
+    with torch.no_grad():
+        bank = torch.cat([m2.img_embed(synthetic.scene_images(range(i, i + 32), 224)) for i in range(0, n_index, 32)])
+    rng = np.random.RandomState(31)
+    margin = 4 * RANK_TOL
+    out = dict(seed=21, profile="test", n_index=n_index, tol_unit=RANK_TOL,
+               bank_slice=bank[:, :3, :8].numpy(), bank_sum=bank.double().sum().item())
+
+    def case(n_q, k, n_words, with_groups):
+        refs = rng.randint(0, n_index, n_q)
+        cand = np.stack([rng.permutation(n_index)[:k] for _ in range(n_q)])
+        groups = np.stack([np.array([j for j in rng.permutation(n_index) if j != refs[q] and j not in cand[q]][:5])
+                           for q in range(n_q)]) if with_groups else None
+        caps = [synthetic.caption_text(700 + 13 * k + q, n_words) for q in range(n_q)]
+        return refs, cand, groups, caps
+
+    saved = (ref_val.generate_fiq_val_predictions, ref_val.generate_cirr_val_predictions)
+    # ---- CIRR style, K = 100 (+5 subset), 5 queries of which one is skipped; and K = 200 (+5), 2 queries ------------
+    # Pass 1 scores every query with the reference's loop; the target of a query is then chosen among its top-K
+    # candidates as one whose Recall@{1,5,10,50} membership is decided by a margin, and becomes a member of the query's
+    # subset (as in CIRR) at a position where its Recall_subset@{1,2,3} membership is decided too.  Pass 2 is the
+    # reference's loop on the final dataset (labels, skip rule, subset) - its outputs are the fixture.
+    for tag, n_q, k, want in (("c100", 5, 100, (0, 3, 7, 28, None)), ("c200", 2, 200, (6, 120))):
+        refs, cand, groups, caps = case(n_q, k, 30, True)
+        ds = FakeCIRR(names, refs, cand[:, 0], caps, cand, np.ones((n_q, k), dtype=bool), groups)
+        logits, glogits, *_ = ref_val.generate_cirr_val_predictions(m2, m1, ds, names, bank)
+        logits, glogits = logits.numpy(), glogits.numpy()
+        labels = np.zeros((n_q, k), dtype=bool)
+        targets = np.zeros(n_q, dtype=np.int64)
+        for q in range(n_q):
+            slot = q % 5                                            # subset member the target replaces
+            if want[q] is None:                                     # skipped row: target outside the top-K
+                targets[q] = groups[q][_pick_robust(glogits[q], 1, margin, (1, 2, 3))]
+                continue
+            ci = _pick_robust(logits[q], want[q], margin, (1, 5, 10, 50),
+                              also=lambda i: _robust(glogits[q], logits[q][i], slot, margin, (1, 2, 3)))
+            labels[q, ci] = True
+            targets[q] = cand[q, ci]
+            groups[q, slot] = cand[q, ci]
+        ds = FakeCIRR(names, refs, targets, caps, cand, labels, groups)
+        logits2, glogits2, _, tnames, gnames = ref_val.generate_cirr_val_predictions(m2, m1, ds, names, bank)
+        l2, g2 = logits2.numpy(), glogits2.numpy()
+        for q in range(n_q):                                        # the margins hold on the final outputs
+            gi = int(np.where(groups[q] == targets[q])[0][0])
+            assert _robust(g2[q], g2[q][gi], gi, margin, (1, 2, 3))
+            if labels[q].any():
+                ci = int(labels[q].argmax())
+                assert _robust(l2[q], l2[q][ci], ci, margin, (1, 5, 10, 50)) and abs(l2[q][ci] - g2[q][gi]) < 1e-5
+            else:
+                assert np.all(l2[q] == np.float32(-99999.99))
+        ref_val.generate_cirr_val_predictions = lambda *a, **kw: (logits2, glogits2, None, tnames, gnames)
+        try:
+            metrics = ref_val.compute_cirr_val_metrics(ds, None, None, None, None)
+        finally:
+            ref_val.generate_cirr_val_predictions = saved[1]
+        out.update({f"{tag}_refs": refs, f"{tag}_cand": cand, f"{tag}_groups": groups, f"{tag}_caps": np.array(caps),
+                    f"{tag}_labels": labels, f"{tag}_targets": targets,
+                    f"{tag}_logits": l2, f"{tag}_group_logits": g2, f"{tag}_metrics": np.array(metrics)})
+        print(f"rank224 {tag}: metrics {np.round(metrics, 2)}  logit std {l2[labels.any(1)].std():.4f}  positives at ranks",
+              [int((l2[q] > l2[q][labels[q].argmax()]).sum()) for q in range(n_q) if labels[q].any()])
+    # ---- FashionIQ style, K = 50, 3 queries (two captions joined by the reference, validate_stage2.py:97-100) -------
+    n_q, k = 3, 50
+    refs, cand, _, _ = case(n_q, k, 30, False)
+    fcaps = [(synthetic.caption_text(900 + q, 14) + ".", "  " + synthetic.caption_text(950 + q, 15) + "?") for q in range(n_q)]
+    ds = FakeFIQ(names, refs, cand[:, 0], fcaps, cand, np.ones((n_q, k), dtype=bool))
+    logits, _ = ref_val.generate_fiq_val_predictions(m2, m1, ds, names, bank)
+    labels = np.zeros((n_q, k), dtype=bool)
+    for q, want in enumerate((2, 7, 25)):
+        labels[q, _pick_robust(logits.numpy()[q], want, margin, (10, 50))] = True
+    ds = FakeFIQ(names, refs, cand[np.arange(n_q), labels.argmax(1)], fcaps, cand, labels)
+    ref_val.generate_fiq_val_predictions = lambda *a, **kw: (logits, None)
+    try:
+        fmetrics = ref_val.compute_fiq_val_metrics(ds, None, None, None, None)
+    finally:
+        ref_val.generate_fiq_val_predictions = saved[0]
+    out.update(f50_refs=refs, f50_cand=cand, f50_caps=np.array(fcaps), f50_labels=labels, f50_logits=logits.numpy(), f50_metrics=np.array(fmetrics))
+    print(f"rank224 f50: metrics {np.round(fmetrics, 2)}  logit std {logits.numpy().std():.4f}")
+    np.savez_compressed(os.path.join(OUT, "rank224.npz"), **out)
+
+    # ---- B x B training-mode surface in eval mode (blip_stage2.py:65-99) ------------------------------------------------
+    caps = [synthetic.caption_text(800 + q, n) for q, n in enumerate((5, 12, 8, 3))]      # ragged -> padding='longest' masks
+    with torch.no_grad():
+        z = m1.img_txt_fusion(bank[:4], bank[:4], caps, train=False, return_raw=True)   # stage2_train.py:202-203
+        bxb = m2.img_txt_fusion(z, bank[4:8], caps, train=True)                         # stage2_train.py:207 (train flag unused, model in eval())
+    np.savez_compressed(os.path.join(OUT, "bxb224.npz"), seed=21, profile="test", caps=np.array(caps), logits=bxb.numpy(),
+                        z_t_cls=z.last_hidden_state[:, 0].numpy())
+    print("bxb224 logits", bxb.numpy().round(4))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "rank":     # only the rank-order / B x B fixtures
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        R = ref_shim.load_reference_modules()
+        _install_torchvision_stub()
+        _, ref_val = _import_reference_scripts()
+        full_bert = json.load(open(os.path.join(ref_shim.REFERENCE_ROOT, "configs", "med_config.json")))
+        return rank_goldens(R, ref_val, full_bert)
     if len(sys.argv) > 1 and sys.argv[1] == "ckpt":     # only the checkpoint-loader fixture
         torch.manual_seed(0)
         R = ref_shim.load_reference_modules()
@@ -323,11 +466,7 @@ def main():
     torch.set_num_threads(8)
     R = ref_shim.load_reference_modules()
     _install_torchvision_stub()        # after `transformers` is imported (it probes for torchvision)
-    cwd = os.getcwd()
-    os.chdir(ref_shim.REFERENCE_ROOT)
-    import utils as ref_utils          # reference src/utils.py
-    import validate_stage2 as ref_val  # reference src/validate_stage2.py
-    os.chdir(cwd)
+    ref_utils, ref_val = _import_reference_scripts()
 
     # ------------------------------------------------------------------ tiny_loop
     m2, m1, g, v = build_reference_models(R, TINY_BERT, TINY_VIT, seed=11, profile="test")
@@ -432,6 +571,7 @@ def main():
             del m2b, m1b
         del m2, m1
     stage1_goldens(R)
+    rank_goldens(R, ref_val, full_bert)
 
 
 if __name__ == "__main__":

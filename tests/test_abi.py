@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_symbol():
     cdll = lib.load()
     for name in _declared():
         assert hasattr(cdll, name), name
-    assert cdll.cir_version() == 3
+    assert cdll.cir_version() == 4
     assert b"aligned" in cdll.cir_strerror(-3)
 
 
@@ -87,5 +87,11 @@ def test_argument_validation_happens_before_any_launch():
     bad = list(att); bad[26] = F32
     assert c.cir_attention(*bad) == EDTYPE
     assert c.cir_topk_desc(P, P, 1, 9000, None) == ESHAPE and c.cir_topk_desc(None, P, 1, 8, None) == EINVAL
+    # kernel-selection overrides: range-checked, default automatic, and the library reads no environment variables
+    assert c.cir_set_tuning(7, 0) == EINVAL and c.cir_set_tuning(0, 64) == EINVAL and c.cir_set_tuning(2, 9000) == EINVAL
+    assert c.cir_set_tuning(0, 128) == 0 and c.cir_set_tuning(0, 0) == 0 and c.cir_set_tuning(2, -1) == 0 and c.cir_set_tuning(2, 0) == 0
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--undefined-only", lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
     for code, word in ((EINVAL, b"null"), (ESHAPE, b"extent"), (EALIGN, b"aligned"), (EDTYPE, b"dtype")):
         assert word in c.cir_strerror(code).lower()

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from candidate_reranking_cir_amd import config as cfgmod, weights
+from candidate_reranking_cir_amd import config as cfgmod, synthetic, weights
 from candidate_reranking_cir_amd.blip_stage1 import blip_stage1
 from candidate_reranking_cir_amd.blip_stage2 import blip_stage2
 from tests import helpers as H
@@ -41,7 +41,7 @@ def test_stage2_pretrained_matches_reference_loader(case, capsys):
     g, v = H.geometry(bert, vit)
     from candidate_reranking_cir_amd.blip_stage2 import BLIP_NLVR
     from candidate_reranking_cir_amd.checkpoint import load_stage2_checkpoint
-    model = BLIP_NLVR(med_config=g, vit_geometry=v)
+    model = BLIP_NLVR(med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer())
     _seeded(model, weights.nlvr_param_spec, g, v, int(z["model_seed"]))         # what the reference model held before loading
     model, msg = load_stage2_checkpoint(model, path)
     assert sorted(msg.missing_keys) == list(z["s2_missing"]) and sorted(msg.unexpected_keys) == list(z["s2_unexpected"])
@@ -55,7 +55,7 @@ def test_stage2_pretrained_matches_reference_loader(case, capsys):
     k0 = "text_encoder.encoder.layer.0.crossattention.self0.key.weight"
     assert torch.equal(sd[k0], sd[k0.replace("self0", "self1")])
     # the factory prints what the reference's prints
-    m = blip_stage2(pretrained=path, med_config=g, vit_geometry=v)
+    m = blip_stage2(pretrained=path, med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer())
     out = capsys.readouterr().out
     assert "reshape position embedding from 36 to 16" in out and "missing keys:" in out and isinstance(m, BLIP_NLVR)
 
@@ -65,7 +65,7 @@ def test_stage1_pretrained_matches_reference_loader(case):
     g, v = H.geometry(bert, vit)
     from candidate_reranking_cir_amd.blip_stage1 import BLIP_Retrieval
     from candidate_reranking_cir_amd.checkpoint import load_stage1_checkpoint
-    model = BLIP_Retrieval(med_config=g, vit_geometry=v)
+    model = BLIP_Retrieval(med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer())
     _seeded(model, weights.retrieval_param_spec, g, v, int(z["model_seed"]) + 1)
     model, msg = load_stage1_checkpoint(model, path)
     assert sorted(msg.missing_keys) == list(z["s1_missing"]) and sorted(msg.unexpected_keys) == list(z["s1_unexpected"])
@@ -78,10 +78,21 @@ def test_bad_path_and_trained_checkpoint_formats(case, tmp_path):
     z, bert, vit, _ = case
     g, v = H.geometry(bert, vit)
     with pytest.raises(RuntimeError, match="checkpoint url or path is invalid"):      # no network on this path
-        blip_stage2(pretrained="https://example.invalid/model_base.pth", med_config=g, vit_geometry=v)
+        blip_stage2(pretrained="https://example.invalid/model_base.pth", med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer())
     # a file written by the reference's training scripts ({'BLIP_NLVR': state_dict}, utils.py:145-150) loads as it is
     sd = weights.synth_state_dict(weights.nlvr_param_spec(g, v), 5, "test")
     path = str(tmp_path / "tuned.pth")
     torch.save({"BLIP_NLVR": sd}, path)
-    m = blip_stage2(pretrained=path, med_config=g, vit_geometry=v)
+    m = blip_stage2(pretrained=path, med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer())
     assert all(torch.equal(m.state_dict()[k], t) for k, t in sd.items())
+
+
+def test_pretrained_without_a_real_vocabulary_is_refused(case):
+    """Real weights scored on hashed token ids would rank garbage silently: with no WordPiece vocabulary available (offline)
+    and no explicit tokenizer, the factories raise instead of falling back (reference: blip_stage2.py:38-44 fails too)."""
+    z, bert, vit, path = case
+    g, v = H.geometry(bert, vit)
+    with pytest.raises(RuntimeError, match="WordPiece"):
+        blip_stage2(pretrained=path, med_config=g, vit_geometry=v)
+    with pytest.raises(RuntimeError, match="WordPiece"):
+        blip_stage1(pretrained=path, med_config=g, vit_geometry=v)

@@ -34,8 +34,8 @@ def build_models(g, v, seed, profile, dtype, device, fold_merge=True):
     from candidate_reranking_cir_amd.blip_stage1 import BLIP_Retrieval
     from candidate_reranking_cir_amd.blip_stage2 import BLIP_NLVR
     sd2, sd1 = H.state_dicts(g, v, seed, profile)
-    m2 = BLIP_NLVR(med_config=g, vit_geometry=v, fold_merge=fold_merge)
-    m1 = BLIP_Retrieval(med_config=g, vit_geometry=v)
+    m2 = BLIP_NLVR(med_config=g, vit_geometry=v, fold_merge=fold_merge, tokenizer=synthetic.HashTokenizer())
+    m1 = BLIP_Retrieval(med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer())
     assert m2.load_state_dict(sd2, strict=True) is not None and m1.load_state_dict(sd1, strict=True) is not None
     m2 = m2.to(device).float().eval().set_compute_dtype(dtype)
     m1 = m1.to(device).float().eval().set_compute_dtype(dtype)
@@ -277,7 +277,7 @@ def test_state_dict_roundtrip_and_cpu_refusal(cuda):
     from candidate_reranking_cir_amd.blip_stage2 import blip_stage2
     z = H.load("tiny_loop.npz")
     g, v = H.geometry(json.loads(str(z["bert_cfg"])), json.loads(str(z["vit_cfg"])))
-    m = blip_stage2(med_config=g, vit_geometry=v)
+    m = blip_stage2(med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer())
     sd = m.state_dict()
     assert "text_encoder.encoder.layer.6.crossattention.output.merge_layer.weight" in sd
     assert "text_encoder.encoder.layer.5.crossattention.output.merge_layer.weight" not in sd

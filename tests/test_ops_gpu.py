@@ -25,11 +25,13 @@ def _rand(shape, dtype, scale=1.0, seed=0):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-@pytest.fixture(params=["128", "256"])
-def gemm_tile(request, monkeypatch):
-    """Run the GEMM tests once per kernel (CIR_GEMM_TILE forces the 128x128 or the 256x256 8-phase kernel)."""
-    monkeypatch.setenv("CIR_GEMM_TILE", request.param)
-    return request.param
+@pytest.fixture(params=[128, 256], ids=["128", "256"])
+def gemm_tile(request):
+    """Run the GEMM tests once per kernel (cir_set_tuning forces the 128x128 or the persistent 256x256 kernel)."""
+    from candidate_reranking_cir_amd import lib
+    lib.set_tuning(lib.TUNE_GEMM_TILE, request.param)
+    yield str(request.param)
+    lib.set_tuning(lib.TUNE_GEMM_TILE, 0)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -2,7 +2,7 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from candidate_reranking_cir_amd import ops
+from candidate_reranking_cir_amd import lib, ops
 
 def timeit(fn, reps=20):
     for _ in range(3): fn()
@@ -18,12 +18,12 @@ d = 768
 for B, N in [(808, 197), (202, 197), (64, 577), (404, 577)]:
     qkv = torch.randn((B, N, 3, d), device="cuda").bfloat16()
     out = torch.empty((B, N, d), device="cuda", dtype=torch.bfloat16)
-    for cap in ("608", "256"):       # K/V of a head shared through LDS up to this many keys (256 = streamed for N=577)
-        os.environ["CIR_ATTN_SHARED_MAX"] = cap
+    for cap in (608, 256):           # K/V of a head shared through LDS up to this many keys (256 = streamed for N=577)
+        lib.set_tuning(lib.TUNE_ATTN_SHARED_MAX, cap)
         us = timeit(lambda: ops.attention(qkv[:, :, 0].unsqueeze(1), qkv[:, :, 1].unsqueeze(1), qkv[:, :, 2].unsqueeze(1), out.unsqueeze(1), 0.125))
         fl = 4.0 * B * 12 * N * N * 64
         print(f"vit    B={B:4d} N={N} shared<={cap}: {us:8.1f} us  {fl/us/1e6:7.1f} TF/s")
-os.environ.pop("CIR_ATTN_SHARED_MAX")
+lib.set_tuning(lib.TUNE_ATTN_SHARED_MAX, 0)
 T, L, N = 1600, 32, 197
 qb = torch.randn((2, T, L, d), device="cuda").bfloat16()
 kv = torch.randn((T, N, 4, d), device="cuda").bfloat16()

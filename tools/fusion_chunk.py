@@ -7,8 +7,8 @@ from candidate_reranking_cir_amd.blip_stage1 import BLIP_Retrieval
 from candidate_reranking_cir_amd.blip_stage2 import BLIP_NLVR
 dev = torch.device("cuda")
 g, v = config.BertGeometry(), config.VitGeometry(image_size=224)
-m2 = BLIP_NLVR(med_config=g, vit_geometry=v).to(dev).eval()
-m1 = BLIP_Retrieval(med_config=g, vit_geometry=v).to(dev).eval()
+m2 = BLIP_NLVR(med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer()).to(dev).eval()
+m1 = BLIP_Retrieval(med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer()).to(dev).eval()
 q_n, k = 16, 100
 toks = torch.randn((q_n + q_n * k, 197, 768), device=dev).bfloat16()
 ids = torch.stack([synthetic.caption_ids(q, 32) for q in range(q_n)]).to(dev); mask = torch.ones_like(ids)

@@ -3,7 +3,9 @@ usage: python tools/gemm_bench.py [M N K [act out32 reps]]   (no args: the path'
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from candidate_reranking_cir_amd import ops
+from candidate_reranking_cir_amd import lib, ops
+TILE = int(os.environ.get("TILE", "0"))   # 0 auto | 128 | 256
+lib.set_tuning(lib.TUNE_GEMM_TILE, TILE)
 
 def run(m, n, k, act=0, out32=False, reps=20, res=False):
     a = (torch.randn((m, k), device="cuda")).bfloat16()
@@ -20,7 +22,7 @@ def run(m, n, k, act=0, out32=False, reps=20, res=False):
         ops.gemm(a, w, b, residual=r, act=act, out_dtype=out.dtype, out=out)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
-    print(f"M={m:7d} N={n:5d} K={k:5d} act={act} out32={int(out32)} res={int(res)} tile={os.environ.get('CIR_GEMM_TILE','auto'):>4s}: {us:9.1f} us  {2.0*m*n*k/us/1e6:8.1f} TF/s", flush=True)
+    print(f"M={m:7d} N={n:5d} K={k:5d} act={act} out32={int(out32)} res={int(res)} tile={TILE or 'auto'!s:>4s}: {us:9.1f} us  {2.0*m*n*k/us/1e6:8.1f} TF/s", flush=True)
 
 if len(sys.argv) >= 4:
     m, n, k = map(int, sys.argv[1:4])

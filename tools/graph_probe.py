@@ -9,8 +9,8 @@ from candidate_reranking_cir_amd.blip_stage2 import BLIP_NLVR
 
 dev = torch.device("cuda")
 g, v = config.BertGeometry(), config.VitGeometry(image_size=224)
-m2 = BLIP_NLVR(med_config=g, vit_geometry=v).to(dev).eval()
-m1 = BLIP_Retrieval(med_config=g, vit_geometry=v).to(dev).eval()
+m2 = BLIP_NLVR(med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer()).to(dev).eval()
+m1 = BLIP_Retrieval(med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer()).to(dev).eval()
 k = 100
 for q_n in (1, 2, 4):
     images = torch.randn((q_n + q_n * k, 3, 224, 224), device=dev).bfloat16()

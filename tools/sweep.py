@@ -8,8 +8,8 @@ from candidate_reranking_cir_amd.blip_stage2 import BLIP_NLVR
 
 dev = torch.device("cuda")
 g, v = config.BertGeometry(), config.VitGeometry(image_size=224)
-m2 = BLIP_NLVR(med_config=g, vit_geometry=v).to(dev).eval()
-m1 = BLIP_Retrieval(med_config=g, vit_geometry=v).to(dev).eval()
+m2 = BLIP_NLVR(med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer()).to(dev).eval()
+m1 = BLIP_Retrieval(med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer()).to(dev).eval()
 k = 100
 cases = [(16, 1616), (16, 808), (16, 404), (16, 539), (16, 270), (32, 1616), (32, 808)]
 for rep in range(2):
