@@ -2,11 +2,15 @@
 """Headline benchmark: query-candidate triplets scored / s at K=100 on synthetic 224x224 images and
 32-token captions (BASELINE.json metric).
 
-One step = one batch of `--queries` queries, each with its own K=100 candidate images, taken from
-pixels and token ids already resident in HBM to sorted scores:
-    ViT-B/16 over the Q*K candidate images and the Q reference images -> stage-I z_t per query ->
-    two-branch fusion + cls_head per (query, candidate) -> per-query descending argsort
-    [-> RCCL all-gather of the (Q,K) scores / indices when world_size > 1].
+One step = one batch of `--queries` CIRR-val-style queries, each with its own K=100 stage-I candidates plus the 5
+non-reference members of its CIRR subset (validate_stage2.py:261-269; SURVEY 8(d) config 3: 4181 x 105 triplets),
+taken from pixels and token ids already resident in HBM to sorted scores:
+    ViT-B/16 over the Q*(K+5) candidate images and the Q reference images -> stage-I z_t per query ->
+    two-branch fusion + cls_head per (query, candidate) -> per-query descending argsort of the K logits and of the 5
+    subset logits [-> RCCL all-gather of the scores / indices when world_size > 1].
+`--skip-rate r` gives a fraction r of the queries no positive in their top-K: the reference's skip rule fills their
+row with -99999.99 and scores only their subset (validate_stage2.py:239/258); ranks then take blocks of
+`distributed.balanced_order`.  Only scored (query, candidate) pairs count as triplets.
 Queries shard across ranks with no data-path collective (weak scaling: per-GPU work fixed).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
@@ -64,10 +68,11 @@ def usable_cpus() -> int:
     return n
 
 
-def cpu_baseline(threads: int):
-    """Oracle (fp32 CPU port of the reference op sequence) on a bounded sample (~10-20 s of CPU work): 64
-    images through the ViT, 8 queries through stage I, 2 queries x 100 candidates through the fusion;
-    composed to triplets/s at K=100 with the same per-triplet accounting as the GPU metric."""
+def cpu_baseline(threads: int, per_query: int = 105):
+    """Oracle (fp32 CPU port of the reference op sequence) on a bounded sample (~25 s of CPU work): 64 images through
+    the ViT, 8 queries through stage I, 4 queries x 100 candidates through the fusion, every leg run TWICE with a fixed
+    thread count and the faster repeat kept; composed to triplets/s with the same per-triplet accounting as the GPU
+    metric (vit + fuse + (vit + s1) / candidates-per-query)."""
     from candidate_reranking_cir_amd import config, synthetic, weights
     from oracle import cir_oracle as O  # baseline leg only
     torch.set_num_threads(threads)
@@ -76,69 +81,103 @@ def cpu_baseline(threads: int):
     sd1 = weights.synth_state_dict(weights.retrieval_param_spec(g, v), 1, "init")
     ids = torch.stack([synthetic.caption_ids(q, 32) for q in range(8)])
     mask = torch.ones_like(ids)
-    n_img, n_q, n_fq, k = 64, 8, 2, 100
+    n_img, n_q, n_fq, k, reps = 64, 8, 4, 100, 2
+    t_vit = t_s1 = t_fuse = float("inf")
     with torch.no_grad():
         imgs = synthetic.images(range(16), 224)
         O.img_embed(sd2, imgs[:2])                                  # warm the thread pool
-        t0 = time.perf_counter()
-        feats = torch.cat([O.img_embed(sd2, imgs) for _ in range(n_img // 16)])      # batches of 16 like utils.py:32
-        t_vit = (time.perf_counter() - t0) / n_img
-        t0 = time.perf_counter()
-        zs = [O.stage1_z_t(sd1, feats[q:q + 1], ids[q:q + 1], mask[q:q + 1]) for q in range(n_q)]
-        t_s1 = (time.perf_counter() - t0) / n_q
-        cand = torch.cat([feats, feats[: k - n_img]])
-        t0 = time.perf_counter()
-        for q in range(n_fq):
-            O.img_txt_fusion_val(sd2, zs[q], cand, ids[q:q + 1], mask[q:q + 1])
-        t_fuse = (time.perf_counter() - t0) / (n_fq * k)
-    per_triplet = t_vit + t_fuse + (t_vit + t_s1) / 100
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            feats = torch.cat([O.img_embed(sd2, imgs) for _ in range(n_img // 16)])      # batches of 16 like utils.py:32
+            t_vit = min(t_vit, (time.perf_counter() - t0) / n_img)
+            t0 = time.perf_counter()
+            zs = [O.stage1_z_t(sd1, feats[q:q + 1], ids[q:q + 1], mask[q:q + 1]) for q in range(n_q)]
+            t_s1 = min(t_s1, (time.perf_counter() - t0) / n_q)
+            cand = torch.cat([feats, feats[: k - n_img]])
+            t0 = time.perf_counter()
+            for q in range(n_fq):
+                O.img_txt_fusion_val(sd2, zs[q], cand, ids[q:q + 1], mask[q:q + 1])
+            t_fuse = min(t_fuse, (time.perf_counter() - t0) / (n_fq * k))
+    per_triplet = t_vit + t_fuse + (t_vit + t_s1) / per_query
     return {"value": round(1.0 / per_triplet, 3), "unit": "triplets/s", "cores": threads, "kind": "port",
-            "sample": "fp32 oracle: %d images ViT-B/16@224 in batches of 16 (%.3fs/img), %d queries stage-I (%.3fs/query), "
-                      "%d queries x %d candidates fusion L=32 (%.4fs/cand); composed as vit+fuse+(vit+s1)/100"
-                      % (n_img, t_vit, n_q, t_s1, n_fq, k, t_fuse)}
+            "sample": "fp32 oracle, best of %d repeats per leg: %d images ViT-B/16@224 in batches of 16 (%.3fs/img), %d queries stage-I "
+                      "(%.3fs/query), %d queries x %d candidates fusion L=32 (%.4fs/cand); composed as vit+fuse+(vit+s1)/%d"
+                      % (reps, n_img, t_vit, n_q, t_s1, n_fq, k, t_fuse, per_query)}
 
 
-def bank_mode(args, m2, m1, dev, dt, rank, world):
-    """Real-dataset regime, reported separately from the headline metric: the index is encoded once
-    (ViT tokens + per-layer cross-attention K/V stay resident in HBM), then queries draw their K candidates from it."""
-    from candidate_reranking_cir_amd import ops, synthetic
-    import torch.distributed as dist
-    q_n, k, n_idx = args.queries, args.k, args.index_size
-    gen = torch.Generator(device=dev).manual_seed(99)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    bank = torch.cat([m2.img_embed16(torch.randn((min(512, n_idx - i), 3, args.image_size, args.image_size), generator=gen, device=dev).to(dt))
-                      for i in range(0, n_idx, 512)])
-    torch.cuda.synchronize(); t_vit = time.perf_counter() - t0
-    kvb = m2.build_kv_bank(bank)
-    torch.cuda.synchronize(); t_kv = time.perf_counter() - t0 - t_vit
-    ids = torch.stack([synthetic.caption_ids(rank * q_n + q, args.tokens) for q in range(q_n)]).to(dev)
-    mask = torch.ones_like(ids)
-    qidx = torch.arange(q_n, device=dev).repeat_interleave(k)
-    rng = torch.Generator(device="cpu").manual_seed(7 + rank)
-    ref_rows = torch.randint(0, n_idx, (q_n,), generator=rng).to(dev)
-    cand_rows = torch.stack([torch.randperm(n_idx, generator=rng)[:k] for _ in range(q_n)]).reshape(-1).to(dev)
+def device_info():
+    """What the box reports about the GPU (print the clocks rocminfo reports and state the peak used)."""
+    import re
+    import subprocess
+    info = {"name": None, "compute_units": None, "max_clock_mhz": None}
+    try:
+        txt = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=30).stdout
+        for blk in txt.split("*******")[1:]:
+            if "Device Type:             GPU" not in blk and not re.search(r"Device Type:\s+GPU", blk):
+                continue
+            m = re.search(r"Name:\s+(gfx\w+)", blk)
+            c = re.search(r"Compute Unit:\s+(\d+)", blk)
+            f = re.search(r"Max Clock Freq\. \(MHz\):\s+(\d+)", blk)
+            info = {"name": m.group(1) if m else None, "compute_units": int(c.group(1)) if c else None,
+                    "max_clock_mhz": int(f.group(1)) if f else None}
+            break
+    except Exception as exc:  # noqa: BLE001
+        info["error"] = str(exc)[:80]
+    return info
 
-    def step():
-        z = m1.z_t(ops.gather_rows(bank, ref_rows), ids, mask)
-        logits = m2.score(z.last_hidden_state, ids, mask, None, qidx, kv_bank=kvb, cand_rows=cand_rows).view(q_n, k)
-        return logits, ops.argsort_desc(logits)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(); elapsed = time.perf_counter() - t0
-    if rank == 0:
-        n_tok = (args.image_size // 16) ** 2 + 1
-        print(json.dumps({
-            "metric": "query-candidate triplets scored/sec at K=100 (index-bank reuse, SURVEY 8(f)-1; not the headline metric)",
-            "value": round(q_n * k * args.steps / elapsed, 1), "unit": "triplets/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{q_n} queries x {k} candidates per step drawn from a resident bank of {n_idx} index images "
-                                   f"({n_tok} tokens): cached ViT tokens + 12-layer cross-attention K/V", "index_size": n_idx,
-                       "bank_bytes": int(bank.numel() * 2 + sum(t.numel() for t in kvb) * 2),
-                       "one_off_index_vit_s": round(t_vit, 3), "one_off_kv_bank_s": round(t_kv, 3)}}), flush=True)
+class ClockSampler:
+    """Samples the shader clock and the socket power of GPU `index` through librocm_smi64 (rsmi_dev_gpu_clk_freq_get /
+    rsmi_dev_current_socket_power_get - what `rocm-smi --showclocks --showpower` prints) every 0.2 s on a host thread
+    while the timed region runs: the clock the part HOLDS under this load (it is power-capped well below rocminfo's max
+    clock; the in-kernel clock reads up to ~10 % lower still, MI355X_MICROARCH.md 'DVFS give-back')."""
+
+    def __init__(self, index: int):
+        import ctypes
+        self.sclk, self.power, self._stop, self.index = [], [], None, index
+        self.lib = None
+        try:
+            class Freqs(ctypes.Structure):
+                _fields_ = [("has_deep_sleep", ctypes.c_bool), ("num_supported", ctypes.c_uint32), ("current", ctypes.c_uint32),
+                            ("frequency", ctypes.c_uint64 * 33)]
+            self.Freqs = Freqs
+            lib = ctypes.CDLL("librocm_smi64.so")
+            if lib.rsmi_init(ctypes.c_uint64(0)) == 0:
+                self.lib = lib
+        except OSError:
+            pass
+
+    def _sample(self):
+        import ctypes
+        f = self.Freqs()
+        if self.lib.rsmi_dev_gpu_clk_freq_get(ctypes.c_uint32(self.index), ctypes.c_int(0), ctypes.byref(f)) == 0 and f.current < 33:
+            self.sclk.append(f.frequency[f.current] / 1e6)
+        p = ctypes.c_uint64(0)
+        if self.lib.rsmi_dev_current_socket_power_get(ctypes.c_uint32(self.index), ctypes.byref(p)) == 0:
+            self.power.append(p.value / 1e6)
+
+    def _run(self):
+        while not self._stop.is_set():
+            self._sample()
+            self._stop.wait(0.2)
+
+    def __enter__(self):
+        import threading
+        if self.lib is not None:
+            self._stop = threading.Event()
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        if self._stop is not None:
+            self._stop.set()
+            self._th.join()
+
+    def summary(self):
+        med = lambda v: round(sorted(v)[len(v) // 2], 1) if v else None
+        return {"sclk_mhz_under_load_median": med(self.sclk), "socket_power_w_median": med(self.power), "samples": len(self.sclk),
+                "source": "librocm_smi64 (rsmi_dev_gpu_clk_freq_get SYS / rsmi_dev_current_socket_power_get) every 0.2 s during the timed region"}
 
 
 def main():
@@ -148,6 +187,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--queries", type=int, default=16, help="queries per step per GPU")
     ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--subset", type=int, default=5, help="CIRR subset members scored per query besides the K candidates (0: FashionIQ style)")
+    ap.add_argument("--skip-rate", type=float, default=0.0, help="fraction of queries without a positive in their top-K (skip rule)")
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--tokens", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
@@ -177,9 +218,10 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from candidate_reranking_cir_amd import config, ops, synthetic, weights
+    from candidate_reranking_cir_amd import config, distributed as D, ops, synthetic, weights
     from candidate_reranking_cir_amd.blip_stage1 import BLIP_Retrieval
     from candidate_reranking_cir_amd.blip_stage2 import BLIP_NLVR
+    from candidate_reranking_cir_amd.validate_stage2 import SKIP_FILL
 
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     g, v = config.BertGeometry(), config.VitGeometry(image_size=args.image_size)
@@ -191,31 +233,57 @@ def main():
     m1 = m1.to(dev).eval().set_compute_dtype(dt)
     m2.engines(); m1.engines()
 
-    q_n, k = args.queries, args.k
+    q_n, k, ns = args.queries, args.k, args.subset
     if args.mode == "bank":
         return bank_mode(args, m2, m1, dev, dt, rank, world)
+    # ---- the step's queries: a global list of world * q_n queries, `skip_rate` of them without a positive in their top-K;
+    #      ranks take contiguous blocks of distributed.balanced_order (equal numbers of scored queries per rank) ------------
+    rng = torch.Generator(device="cpu").manual_seed(4242)
+    active_all = (torch.rand(world * q_n, generator=rng) >= args.skip_rate).tolist()
+    order_all = D.balanced_order(active_all)
+    lo, hi, _ = D.shard_bounds(world * q_n, rank, world)
+    mine = order_all[lo:hi]
+    active = [active_all[q] for q in mine]
+    per_q = [(k if a else 0) + ns for a in active]                       # candidates scored for each of my queries
+    n_cand = sum(per_q)
+    if n_cand == 0:
+        raise SystemExit("nothing to score: --skip-rate 1 with --subset 0")
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    images = torch.randn((q_n + q_n * k, 3, args.image_size, args.image_size), generator=gen, device=dev, dtype=torch.float32).to(dt)
-    ids = torch.stack([synthetic.caption_ids(rank * q_n + q, args.tokens) for q in range(q_n)]).to(dev)
+    images = torch.randn((q_n + n_cand, 3, args.image_size, args.image_size), generator=gen, device=dev, dtype=torch.float32).to(dt)
+    ids = torch.stack([synthetic.caption_ids(q, args.tokens) for q in mine]).to(dev)
     mask = torch.ones_like(ids)
-    qidx = torch.arange(q_n, device=dev).repeat_interleave(k)
-    # per-rank results of every step; ONE all-gather of scores + indices over RCCL at the end of the timed region
-    # (the path has no other exchange step; 16 queries x 100 x (4 + 8) B per step and rank)
+    qidx = torch.repeat_interleave(torch.arange(q_n), torch.tensor(per_q)).to(dev)
+    # where each scored row lands: top-K logits (Q, K) pre-filled with the skip value, subset logits (Q, ns)
+    top_src, top_dst, sub_src, o = [], [], [], 0
+    for j, a in enumerate(active):
+        if a:
+            top_src += range(o, o + k); top_dst += range(j * k, (j + 1) * k); o += k
+        sub_src += range(o, o + ns); o += ns
+    top_src, top_dst, sub_src = (torch.tensor(t, dtype=torch.int64, device=dev) for t in (top_src, top_dst, sub_src))
+    # per-rank results of every step; ONE all-gather of [scores | subset scores] and one of the indices over RCCL at the
+    # end of the timed region (the path has no other exchange step)
     n_buf = max(args.steps, args.warmup, 1)
-    local_scores = torch.empty((n_buf, q_n, k), dtype=torch.float32, device=dev)
-    local_order = torch.empty((n_buf, q_n, k), dtype=torch.int64, device=dev)
+    w = k + ns
+    local_scores = torch.empty((n_buf, q_n, w), dtype=torch.float32, device=dev)
+    local_order = torch.empty((n_buf, q_n, w), dtype=torch.int64, device=dev)
     # (gather buffers in the concatenated layout - rank-major along dim 0 - which every backend accepts)
-    gathered_scores = torch.empty((world * n_buf, q_n, k), dtype=torch.float32, device=dev) if world > 1 else None
-    gathered_order = torch.empty((world * n_buf, q_n, k), dtype=torch.int64, device=dev) if world > 1 else None
+    gathered_scores = torch.empty((world * n_buf, q_n, w), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered_order = torch.empty((world * n_buf, q_n, w), dtype=torch.int64, device=dev) if world > 1 else None
 
     def step(slot=0):
         toks = m2.img_embed16(images)                                   # reference images first, then candidates
         z = m1.z_t(toks[:q_n], ids, mask)
-        logits = m2.score(z.last_hidden_state, ids, mask, toks[q_n:], qidx).view(q_n, k)
-        order = ops.argsort_desc(logits)
-        local_scores[slot].copy_(logits)
-        local_order[slot].copy_(order)
-        return logits, order
+        scored = m2.score(z.last_hidden_state, ids, mask, toks[q_n:], qidx)
+        logits = torch.full((q_n * k,), SKIP_FILL, dtype=torch.float32, device=dev)   # skip rule (validate_stage2.py:258)
+        logits[top_dst] = scored[top_src]
+        logits = logits.view(q_n, k)
+        local_scores[slot, :, :k] = logits
+        local_order[slot, :, :k] = ops.argsort_desc(logits)
+        if ns:
+            sub = scored[sub_src].view(q_n, ns)
+            local_scores[slot, :, k:] = sub
+            local_order[slot, :, k:] = ops.argsort_desc(sub)
+        return scored
 
     def exchange():
         if world > 1 and backend == "nccl":
@@ -236,56 +304,90 @@ def main():
         step(i)
     exchange()                                                          # warm the communicator too
     fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(i)
-    exchange()
-    fence()
-    elapsed = time.perf_counter() - t0
+    with ClockSampler(dev_index) as clocks:
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = step(i)
+        exchange()
+        fence()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = te.item()
-    assert torch.isfinite(out[0]).all()
+        tn = torch.tensor([n_cand], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tn, op=dist.ReduceOp.SUM)
+        total_cand = int(tn.item())
+    else:
+        total_cand = n_cand
+    assert torch.isfinite(out).all()
 
-    # ---- instrumented step: HIP events around every GEMM launch on the launch stream -----------------
-    ops.PROFILE_GEMM = []
+    # ---- instrumented step: HIP events around every GEMM / attention launch on the launch stream ----------------------
+    ops.PROFILE_GEMM, ops.PROFILE_ATTN = [], []
     step()
     torch.cuda.synchronize()
-    recs, ops.PROFILE_GEMM = ops.PROFILE_GEMM, None
-    gemm_ms = sum(r[1].elapsed_time(r[2]) for r in recs)
-    gemm_flop = sum(r[0] for r in recs)
-    gemm_alg_bytes = sum(r[3] for r in recs)     # operands + outputs (+ residual, bias) read / written once
+    recs, arecs = ops.PROFILE_GEMM, ops.PROFILE_ATTN
+    ops.PROFILE_GEMM = ops.PROFILE_ATTN = None
+    by_kernel = {}
+    for fl, e0, e1, nbytes, name in recs:
+        d = by_kernel.setdefault(name, dict(flop=0.0, ms=0.0, launches=0, alg_bytes=0.0))
+        d["flop"] += fl; d["ms"] += e0.elapsed_time(e1); d["launches"] += 1; d["alg_bytes"] += nbytes
+    gemm_ms = sum(d["ms"] for d in by_kernel.values())
+    gemm_flop = sum(d["flop"] for d in by_kernel.values())
+    attn_flop = sum(r[0] for r in arecs)
+    attn_ms = sum(r[1].elapsed_time(r[2]) for r in arecs)
     t1 = time.perf_counter(); step(); torch.cuda.synchronize(); step_ms = (time.perf_counter() - t1) * 1e3
 
     if rank == 0:
         n_tok = (args.image_size // 16) ** 2 + 1
         alg = algorithmic_gflop(n_tok, args.tokens, k)
-        traffic = None   # HBM bytes per GEMM launch from PMC passes collected with rocprofv3 on this same command
-        tpath = os.path.join(ROOT, "profiles", "r1_gemm_traffic.json")
-        if os.path.exists(tpath) and q_n == 16 and k == 100 and args.image_size == 224 and args.dtype == "bf16":
-            traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
-        triplets = world * q_n * k * args.steps
+        # algorithmic work of one step of THIS rank: every image through the ViT, every scored pair through the fusion,
+        # every query through stage I (SURVEY 8(d) formulas; with all queries active = vit + fuse + (vit + s1) / (K + subset))
+        alg_step = (q_n + n_cand) * alg["vit"] + n_cand * alg["fuse"] + q_n * alg["s1"]
+        alg_per_triplet = alg_step / n_cand
+        triplets = total_cand * args.steps
         value = triplets / elapsed
-        achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.dtype]
+        dom_name = max(by_kernel, key=lambda n: by_kernel[n]["ms"])
+        dom = by_kernel[dom_name]
+        dom_tf = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
+        all_tf = gemm_flop / (gemm_ms * 1e-3) / 1e12
+        traffic, traffic_src = None, None    # HBM bytes per launch of the dominant kernel: offline PMC passes of this same command
+        tpath = os.path.join(ROOT, "profiles", "r2_gemm_traffic.json")
+        if os.path.exists(tpath) and q_n == 16 and k == 100 and ns == 5 and args.skip_rate == 0 and args.image_size == 224 and args.dtype == "bf16":
+            tj = json.load(open(tpath))
+            ent = tj.get("by_kernel", {}).get(dom_name)
+            if ent:
+                traffic = round(ent["hbm_bytes_per_launch"])
+                traffic_src = "profiles/r2_gemm_traffic.json: offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (not this run)"
         line = {
             "metric": "query-candidate triplets scored/sec at K=100", "value": round(value, 2), "unit": "triplets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"CIRR-val-style K={k} re-rank from pixels, ViT-B/16 {args.image_size}px ({n_tok} tokens), "
-                                   f"{args.tokens}-token captions, {q_n} queries x {k} candidates per step per GPU, random-init weights",
-                       "queries_per_step_per_gpu": q_n, "k": k, "image_size": args.image_size, "tokens": args.tokens,
-                       "parallelism": f"queries sharded over {world} GPU(s), all-gather of scores+indices"},
-            "algorithmic_gflop_per_triplet": round(alg["per_triplet"], 2),
-            "path_tflops": round(value * alg["per_triplet"] / 1e3, 1),
-            "path_frac_of_mfma_peak": round(value * alg["per_triplet"] / 1e3 / (PEAK_TFLOPS[args.dtype] * world), 4),
-            "roofline": {"bound": "mfma", "kernel": "cir::gemm256_kernel + cir::gemm_kernel (every GEMM launch of one step)", "achieved": round(achieved, 1),
-                         "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4),
-                         "traffic": traffic, "algorithmic_bytes": round(gemm_alg_bytes / max(len(recs), 1)), "launches_per_step": len(recs), "avg_launch_us": round(gemm_ms * 1e3 / max(len(recs), 1), 2),
-                         "gemm_share_of_step": round(gemm_ms / step_ms, 3)},
+            "config": {"workload": f"CIRR-val-style K={k} re-rank from pixels (BASELINE configs[2]): ViT-B/16 {args.image_size}px ({n_tok} tokens), "
+                                   f"{args.tokens}-token captions, {q_n} queries x ({k} candidates + {ns} subset members) per step per GPU, "
+                                   f"skip rate {args.skip_rate:g}, random-init weights",
+                       "queries_per_step_per_gpu": q_n, "k": k, "subset": ns, "skip_rate": args.skip_rate, "image_size": args.image_size,
+                       "tokens": args.tokens, "triplets_per_step_rank0": n_cand,
+                       "parallelism": f"queries sharded over {world} GPU(s) (balanced_order blocks), all-gather of scores+indices"},
+            "algorithmic_gflop_per_triplet": round(alg_per_triplet, 2),
+            "executed_gflop_per_triplet": round((gemm_flop + attn_flop) / 1e9 / n_cand, 2),
+            "path_tflops": round(value * alg_per_triplet / 1e3, 1),
+            "path_frac_of_mfma_peak": round(value * alg_per_triplet / 1e3 / (peak * world), 4),
+            "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(dom_tf, 1), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(dom_tf / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes": round(dom["alg_bytes"] / dom["launches"]), "launches_per_step": dom["launches"],
+                         "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2), "share_of_step": round(dom["ms"] / step_ms, 3),
+                         "all_gemm_kernels": {"achieved": round(all_tf, 1), "frac": round(all_tf / peak, 4), "launches_per_step": len(recs),
+                                              "avg_launch_us": round(gemm_ms * 1e3 / max(len(recs), 1), 2), "share_of_step": round(gemm_ms / step_ms, 3),
+                                              "by_kernel": {n: {"tflops": round(d["flop"] / (d["ms"] * 1e-3) / 1e12, 1), "ms_per_step": round(d["ms"], 2),
+                                                                "launches": d["launches"]} for n, d in sorted(by_kernel.items())}},
+                         "attention_kernels": {"tflops": round(attn_flop / (attn_ms * 1e-3) / 1e12, 1), "ms_per_step": round(attn_ms, 2), "launches": len(arecs)},
+                         "peak_definition": "256 CU x 2.4 GHz x 4096 flop/clk/CU dense bf16/f16 MFMA (MI355X_MICROARCH.md)"},
+            "device": dict(device_info(), **clocks.summary()),
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(usable_cpus())
+            line["cpu_baseline"] = cpu_baseline(usable_cpus(), k + ns)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -171,7 +171,16 @@ class BLIP_NLVR(_EngineHost):
 
     @torch.no_grad()
     def img_txt_fusion(self, r_image_embeds, t_image_embeds, text, train=True):
-        """B queries x B candidates -> (B, B) logits (blip_stage2.py:65-99), forward only."""
+        """B queries x B candidates -> (B, B) logits (blip_stage2.py:65-99): row i scores caption i / z_t i against all B
+        candidates; ragged captions are padded to the longest (real attention masks inside the batch).
+
+        FORWARD ONLY: no autograd graph, no dropout / DropPath.  As in the reference the `train` argument
+        itself is unused - the mode is the module's: in `.eval()` this is the reference's arithmetic (pinned by
+        tests/golden/bxb224.npz); in `.train()` mode the reference would apply dropout and build a graph for backward,
+        which this library does not implement, so it raises instead of returning logits no optimiser could use."""
+        if self.training:
+            raise NotImplementedError("forward only: img_txt_fusion in train() mode needs dropout / DropPath and backward "
+                                      "(stage2_train.py), which the MI355X path does not implement - call model.eval()")
         z = r_image_embeds.last_hidden_state if hasattr(r_image_embeds, "last_hidden_state") else r_image_embeds
         ids, mask = encode_text(self.tokenizer, text, self.device)
         b = z.shape[0]

@@ -174,32 +174,58 @@ __global__ __launch_bounds__(1024) void attn_shared_kernel(const AttnArgs a, int
     const T* vb = reinterpret_cast<const T*>(a.v) + kb1 * a.v_s1 + b0 * a.v_s0 + h * 64;
     const float* mp = MASKED ? a.mask + b1 * a.m_s1 + b0 * a.m_s0 : nullptr;
 
-    // ---- stage K (chunk ^ ((row>>1)&7): conflict-free 32x32x16 A-operand reads) and V (halves swapped on bit 1) ----
-    for (int c = threadIdx.x; c < lk_pad * 8; c += blockDim.x) {
-        const int row = c >> 3, ch = c & 7;
-        X8 kv, vv;
+    const int r = lane & 31, hh = lane >> 5;
+    // Q fragments of this wave's first query tile: requested BEFORE the K/V staging so that their latency overlaps it
+    const T* const qbase = reinterpret_cast<const T*>(a.q) + b1 * a.q_s1 + b0 * a.q_s0 + h * 64 + 8 * hh;
+    X8 qf[4];
+    {
+        const int qrow = min(min(wave, a.nqt - 1) * 32 + r, a.Lq - 1);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { kv[j] = static_cast<T>(0.f); vv[j] = static_cast<T>(0.f); }
-        if (row < a.Lk) {
-            kv = *reinterpret_cast<const X8*>(kb + (int64_t)row * a.k_rs + ch * 8);
-            vv = *reinterpret_cast<const X8*>(vb + (int64_t)row * a.v_rs + ch * 8);
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const X8*>(qbase + (int64_t)qrow * a.q_rs + 16 * s);
+    }
+    // ---- stage K (chunk ^ ((row>>1)&7): conflict-free 32x32x16 A-operand reads) and V (halves swapped on bit 1) ----
+    // Batches of SB chunks per thread: all 2*SB global loads of a batch are in flight before the first LDS write (a
+    // rolled loop exposes one HBM latency per chunk; the whole stage is ~4 chunks per thread at 197 keys).
+    {
+        constexpr int SB = 4;
+        const int nchunks = lk_pad * 8;
+        const int stride = blockDim.x;
+        for (int c0 = threadIdx.x; c0 < nchunks; c0 += SB * stride) {
+            X8 kv[SB], vv[SB];
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int c = c0 + i * stride;
+                const int row = c >> 3, ch = c & 7;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { kv[i][j] = static_cast<T>(0.f); vv[i][j] = static_cast<T>(0.f); }
+                if (c < nchunks && row < a.Lk) {
+                    kv[i] = *reinterpret_cast<const X8*>(kb + (int64_t)row * a.k_rs + ch * 8);
+                    vv[i] = *reinterpret_cast<const X8*>(vb + (int64_t)row * a.v_rs + ch * 8);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int c = c0 + i * stride;
+                const int row = c >> 3, ch = c & 7;
+                if (c < nchunks) {
+                    *reinterpret_cast<X8*>(Ks + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = kv[i];
+                    *reinterpret_cast<X8*>(Vs + row * 128 + ((ch * 16) ^ (((row >> 1) & 1) << 6))) = vv[i];
+                }
+            }
         }
-        *reinterpret_cast<X8*>(Ks + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = kv;
-        *reinterpret_cast<X8*>(Vs + row * 128 + ((ch * 16) ^ (((row >> 1) & 1) << 6))) = vv;
     }
     __syncthreads();
 
-    const int r = lane & 31, hh = lane >> 5;
     const int tr_off = tr_lane_offset(lane);
     const float sl = a.scale * kLog2e;
     const int nkt = (a.Lk + 31) >> 5;
     for (int qt = wave; qt < a.nqt; qt += nwaves) {
         const int q0 = qt * 32;
-        const int qrow = min(q0 + r, a.Lq - 1);
-        const T* qp = reinterpret_cast<const T*>(a.q) + b1 * a.q_s1 + b0 * a.q_s0 + (int64_t)qrow * a.q_rs + h * 64 + 8 * hh;
-        X8 qf[4];
+        if (qt != wave) {   // later rounds (577 tokens: 19 tiles on 10 waves)
+            const int qrow = min(q0 + r, a.Lq - 1);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const X8*>(qp + 16 * s);
+            for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const X8*>(qbase + (int64_t)qrow * a.q_rs + 16 * s);
+        }
         Softmax st;
         st.init();
         for (int kt = 0; kt < nkt; ++kt) {

@@ -15,8 +15,25 @@ from .lib import ACT_GELU, ACT_NONE, ACT_RELU, CIR_BF16, CIR_F16, CIR_F32  # noq
 _DT = {torch.bfloat16: CIR_BF16, torch.float16: CIR_F16, torch.float32: CIR_F32}
 
 
-# bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream
+# bench.py sets these to lists to time every GEMM / attention launch with HIP events on the launch stream
 PROFILE_GEMM = None
+PROFILE_ATTN = None
+
+
+def gemm_kernel_name(m: int, n: int, k: int, nb: int, has_residual: bool, act: int, out32: bool, in_dtype: torch.dtype, tile: int = 0) -> str:
+    """Which kernel instantiation cir_gemm_bias_act launches for a shape (mirror of the dispatch in csrc/gemm.hip; for
+    reporting only - the library decides)."""
+    t = "__bf16" if in_dtype == torch.bfloat16 else "_Float16"
+    nblk256 = -(-m // 256) * -(-n // 256) * nb
+    use256 = n >= 256 and nblk256 >= 192
+    can256 = not (has_residual and (act != ACT_NONE or not out32)) and k % 128 == 0
+    if tile == 128:
+        use256 = False
+    elif tile == 256:
+        use256 = True
+    if use256 and can256:
+        return f"cir::gemm256_kernel<{t},{'true' if out32 else 'false'},{'true' if has_residual else 'false'}>"
+    return f"cir::gemm_kernel<{t},{'true' if out32 else 'false'}>"
 
 
 def _stream() -> int:
@@ -71,7 +88,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         ev1.record()
         alg_bytes = nb * ((m * k + n * k) * a.element_size() + m * n * o3.element_size()
                           + (m * n * 4 if residual is not None else 0) + (n * 4 if bias is not None else 0))
-        PROFILE_GEMM.append((2.0 * nb * m * n * k, ev0, ev1, float(alg_bytes)))
+        PROFILE_GEMM.append((2.0 * nb * m * n * k, ev0, ev1, float(alg_bytes),
+                             gemm_kernel_name(m, n, k, nb, residual is not None, act, out_dtype == torch.float32, a.dtype)))
     _lib.check(code, "cir_gemm_bias_act")
     return out
 
@@ -125,10 +143,16 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     if mask is not None:
         assert mask.dtype == torch.float32 and mask.shape == (b1, b0, lk) and mask.stride(2) == 1
         ms1, ms0 = mask.stride(0), mask.stride(1)
+    if PROFILE_ATTN is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     code = _lib.load().cir_attention(
         q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), k.data_ptr(), k.stride(0), k.stride(1), k.stride(2),
         v.data_ptr(), v.stride(0), v.stride(1), v.stride(2), _ptr(mask), ms1, ms0, _ptr(kv_index),
         out.data_ptr(), out.stride(0), out.stride(1), out.stride(2), b1, b0, d // 64, lq, lk, float(scale), _DT[q.dtype], _stream())
+    if PROFILE_ATTN is not None:
+        ev1.record()
+        PROFILE_ATTN.append((4.0 * b1 * b0 * lq * lk * d, ev0, ev1, (lq, lk)))
     _lib.check(code, "cir_attention")
     return out
 
@@ -139,6 +163,8 @@ def embed_layernorm(ids: torch.Tensor, word: torch.Tensor, pos: torch.Tensor, ga
     _need_cuda(ids, word, pos, gamma, beta)
     r, l = ids.shape
     cols = word.shape[1]
+    if l > pos.shape[0]:      # the reference raises too (position_ids[:, :L] indexes a (max_position_embeddings,) table)
+        raise IndexError(f"caption of {l} tokens exceeds the {pos.shape[0]}-row position-embedding table")
     ids = ids.contiguous()
     y32 = torch.empty((r, l, cols), dtype=torch.float32, device=ids.device)
     y16 = torch.empty((r, l, cols), dtype=dtype16, device=ids.device)

@@ -87,6 +87,17 @@ def _length_buckets(ds: RelativeValSet, tokenizer, rows: Sequence[int]):
     return buckets
 
 
+def _check_bank_rows(ds: RelativeValSet, n_index: int):
+    """Names are integer rows of the index bank: validate them ONCE per dataset on the host (the device kernels clamp or
+    trust their indices; a name the reference could not find raises KeyError in its dict lookup, validate_stage2.py:115)."""
+    for what, arr in (("ref_index", ds.ref_index), ("cand_index", ds.cand_index), ("group_index", ds.group_index)):
+        if arr is None or len(arr) == 0:
+            continue
+        a = np.asarray(arr)
+        if a.min() < 0 or a.max() >= n_index:
+            raise IndexError(f"{what} holds row {int(a.min() if a.min() < 0 else a.max())} outside the index bank of {n_index} images")
+
+
 @torch.no_grad()
 def generate_val_predictions(blip_model, model_stage1, ds: RelativeValSet, index_features: torch.Tensor,
                              query_batch: int = 8, rows: Optional[Sequence[int]] = None, kv_bank: Optional[list] = None):
@@ -95,6 +106,7 @@ def generate_val_predictions(blip_model, model_stage1, ds: RelativeValSet, index
     re-uses the per-image cross-attention K/V across all queries instead of re-projecting every candidate."""
     dev = blip_model.device
     rows = list(range(len(ds))) if rows is None else list(rows)
+    _check_bank_rows(ds, index_features.shape[0] if kv_bank is None else kv_bank[0].shape[0])
     pos = {r: i for i, r in enumerate(rows)}
     k = ds.K
     logits = torch.full((len(rows), k), SKIP_FILL, dtype=torch.float32, device=dev)

@@ -441,8 +441,59 @@ def rank_goldens(R, ref_val, full_bert):
     print("bxb224 logits", bxb.numpy().round(4))
 
 
+def tiny_goldens(R, ref_val):
+    """tests/golden/tiny_loop.npz + masks.npz: reduced geometry through the reference's own loops.  Weights use the
+    "spread" profile and the index images are structured (synthetic.scene_image), so that the candidates of a query get
+    logits spread far wider than a 16-bit rounding error - a scorer that ignored the candidates cannot pass the tests."""
+    m2, m1, g, v = build_reference_models(R, TINY_BERT, TINY_VIT, seed=11, profile="spread")
+    case = loop_case(n_index=14, n_q=8, k=6, seed=5, n_words=6)
+    with torch.no_grad():
+        index_features = m2.img_embed(synthetic.scene_images(range(14), v.image_size))
+    fiq = FakeFIQ(case["names"], case["refs"], case["targets"], case["fiq_caps"], case["cand_idx"], case["labels"])
+    cirr = FakeCIRR(case["names"], case["refs"], case["targets"], case["cirr_caps"], case["cand_idx"], case["labels"], case["groups"])
+    fiq_logits, fiq_targets = ref_val.generate_fiq_val_predictions(m2, m1, fiq, case["names"], index_features)
+    fiq_metrics = ref_val.compute_fiq_val_metrics(fiq, m2, m1, index_features, case["names"])
+    c_logits, c_glogits, c_refs, c_targets, c_groups = ref_val.generate_cirr_val_predictions(m2, m1, cirr, case["names"], index_features)
+    cirr_metrics = ref_val.compute_cirr_val_metrics(cirr, m2, m1, index_features, case["names"])
+    np.savez_compressed(
+        os.path.join(OUT, "tiny_loop.npz"),
+        bert_cfg=json.dumps(TINY_BERT), vit_cfg=json.dumps(TINY_VIT), seed=11, profile="spread", image_kind="scene",
+        refs=case["refs"], cand_idx=case["cand_idx"], labels=case["labels"], targets=case["targets"], groups=case["groups"],
+        cirr_caps=np.array(case["cirr_caps"]), fiq_caps=np.array(case["fiq_caps"]),
+        index_features_slice=index_features[:, :3, :8].numpy(), index_features_sum=index_features.double().sum().item(),
+        fiq_logits=fiq_logits.numpy(), fiq_metrics=np.array(fiq_metrics),
+        cirr_logits=c_logits.numpy(), cirr_group_logits=c_glogits.numpy(), cirr_metrics=np.array(cirr_metrics),
+    )
+    print("tiny_loop: fiq", fiq_metrics, "cirr", cirr_metrics)
+
+    # ------------------------------------------------------------------ masks (padded captions)
+    tok = synthetic.HashTokenizer()
+    enc = tok([synthetic.caption_text(50, 3), synthetic.caption_text(51, 9), synthetic.caption_text(52, 6)])
+    ids = enc.input_ids.clone(); ids[:, 0] = tok.enc_token_id
+    with torch.no_grad():
+        ref_tokens = index_features[:3]
+        s1_out = m1.text_encoder(ids, attention_mask=enc.attention_mask, encoder_hidden_states=ref_tokens,
+                                 encoder_attention_mask=torch.ones(ref_tokens.shape[:2], dtype=torch.long),
+                                 return_dict=True).last_hidden_state
+        cand = index_features[3:6]
+        atts = torch.ones(cand.shape[:2], dtype=torch.long)
+        s2_out = m2.text_encoder(ids, attention_mask=enc.attention_mask, z_t=s1_out, z_t_attention_mask=None,
+                                 encoder_hidden_states=[cand, cand], encoder_attention_mask=[atts, atts], return_dict=True)
+    np.savez_compressed(os.path.join(OUT, "masks.npz"), input_ids=ids.numpy(), attention_mask=enc.attention_mask.numpy(),
+                        stage1_hidden=s1_out.numpy(), stage2_hidden=s2_out.numpy())
+    print("masks:", tuple(s1_out.shape), tuple(s2_out.shape))
+
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "tiny":     # only tiny_loop.npz / masks.npz
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        R = ref_shim.load_reference_modules()
+        _install_torchvision_stub()
+        _, ref_val = _import_reference_scripts()
+        return tiny_goldens(R, ref_val)
     if len(sys.argv) > 1 and sys.argv[1] == "rank":     # only the rank-order / B x B fixtures
         torch.manual_seed(0)
         torch.set_num_threads(8)
@@ -468,45 +519,7 @@ def main():
     _install_torchvision_stub()        # after `transformers` is imported (it probes for torchvision)
     ref_utils, ref_val = _import_reference_scripts()
 
-    # ------------------------------------------------------------------ tiny_loop
-    m2, m1, g, v = build_reference_models(R, TINY_BERT, TINY_VIT, seed=11, profile="test")
-    case = loop_case(n_index=14, n_q=8, k=6, seed=5, n_words=6)
-    with torch.no_grad():
-        index_features = m2.img_embed(synthetic.images(range(14), v.image_size))
-    fiq = FakeFIQ(case["names"], case["refs"], case["targets"], case["fiq_caps"], case["cand_idx"], case["labels"])
-    cirr = FakeCIRR(case["names"], case["refs"], case["targets"], case["cirr_caps"], case["cand_idx"], case["labels"], case["groups"])
-    fiq_logits, fiq_targets = ref_val.generate_fiq_val_predictions(m2, m1, fiq, case["names"], index_features)
-    fiq_metrics = ref_val.compute_fiq_val_metrics(fiq, m2, m1, index_features, case["names"])
-    c_logits, c_glogits, c_refs, c_targets, c_groups = ref_val.generate_cirr_val_predictions(m2, m1, cirr, case["names"], index_features)
-    cirr_metrics = ref_val.compute_cirr_val_metrics(cirr, m2, m1, index_features, case["names"])
-    np.savez_compressed(
-        os.path.join(OUT, "tiny_loop.npz"),
-        bert_cfg=json.dumps(TINY_BERT), vit_cfg=json.dumps(TINY_VIT), seed=11, profile="test",
-        refs=case["refs"], cand_idx=case["cand_idx"], labels=case["labels"], targets=case["targets"], groups=case["groups"],
-        cirr_caps=np.array(case["cirr_caps"]), fiq_caps=np.array(case["fiq_caps"]),
-        index_features_slice=index_features[:, :3, :8].numpy(), index_features_sum=index_features.double().sum().item(),
-        fiq_logits=fiq_logits.numpy(), fiq_metrics=np.array(fiq_metrics),
-        cirr_logits=c_logits.numpy(), cirr_group_logits=c_glogits.numpy(), cirr_metrics=np.array(cirr_metrics),
-    )
-    print("tiny_loop: fiq", fiq_metrics, "cirr", cirr_metrics)
-
-    # ------------------------------------------------------------------ masks (padded captions)
-    tok = synthetic.HashTokenizer()
-    enc = tok([synthetic.caption_text(50, 3), synthetic.caption_text(51, 9), synthetic.caption_text(52, 6)])
-    ids = enc.input_ids.clone(); ids[:, 0] = tok.enc_token_id
-    with torch.no_grad():
-        ref_tokens = index_features[:3]
-        s1_out = m1.text_encoder(ids, attention_mask=enc.attention_mask, encoder_hidden_states=ref_tokens,
-                                 encoder_attention_mask=torch.ones(ref_tokens.shape[:2], dtype=torch.long),
-                                 return_dict=True).last_hidden_state
-        cand = index_features[3:6]
-        atts = torch.ones(cand.shape[:2], dtype=torch.long)
-        s2_out = m2.text_encoder(ids, attention_mask=enc.attention_mask, z_t=s1_out, z_t_attention_mask=None,
-                                 encoder_hidden_states=[cand, cand], encoder_attention_mask=[atts, atts], return_dict=True)
-    np.savez_compressed(os.path.join(OUT, "masks.npz"), input_ids=ids.numpy(), attention_mask=enc.attention_mask.numpy(),
-                        stage1_hidden=s1_out.numpy(), stage2_hidden=s2_out.numpy())
-    print("masks:", tuple(s1_out.shape), tuple(s2_out.shape))
-    del m2, m1
+    tiny_goldens(R, ref_val)
 
     # ------------------------------------------------------------------ metrics on big synthetic matrices
     rng = np.random.RandomState(7)

@@ -20,6 +20,13 @@ def geometry(bert_cfg: dict, vit_cfg: dict):
     return cfgmod.BertGeometry.from_dict(bert_cfg), cfgmod.VitGeometry(**vit_cfg)
 
 
+def fixture_images(z, ids, size):
+    """The images a fixture was generated from: structured `scene_images` when the fixture says so, i.i.d. noise otherwise."""
+    if "image_kind" in z.files and str(z["image_kind"]) == "scene":
+        return synthetic.scene_images(ids, size)
+    return synthetic.images(ids, size)
+
+
 def state_dicts(g, v, seed, profile):
     sd2 = weights.synth_state_dict(weights.nlvr_param_spec(g, v), seed, profile)
     sd1 = weights.synth_state_dict(weights.retrieval_param_spec(g, v), seed + 1, profile)

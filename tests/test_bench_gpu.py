@@ -32,6 +32,9 @@ def test_single_rank_contract_line():
     assert d["n_gpus"] == 1 and d["steps"] == 1 and d["value"] > 0 and d["unit"] == "triplets/s" and d["dtype"] == "bf16"
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["kernel"].startswith("cir::gemm") and "traffic" in rf and rf["all_gemm_kernels"]["launches_per_step"] > 100
+    assert d["config"]["subset"] == 5 and d["config"]["triplets_per_step_rank0"] == 2 * 105
+    assert d["executed_gflop_per_triplet"] > 0 and d["device"]["compute_units"] == 256
 
 
 def test_two_rank_dry_run_on_one_gpu():
@@ -40,10 +43,12 @@ def test_two_rank_dry_run_on_one_gpu():
     env = dict(os.environ, CIR_BENCH_BACKEND="gloo", CIR_BENCH_DEVICE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--queries", "2"]
+           "--queries", "3", "--skip-rate", "0.34"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["queries_per_step_per_gpu"] == 2
+    assert d["config"]["queries_per_step_per_gpu"] == 3 and d["config"]["subset"] == 5
+    # 6 queries, skip rate 0.34: skipped queries score only their 5 subset members, and only scored pairs count
+    assert d["config"]["triplets_per_step_rank0"] in (5 + 2 * 105, 2 * 5 + 105, 3 * 105, 15)
     assert r.stdout.count('{"metric"') == 1          # rank 0 alone prints the line

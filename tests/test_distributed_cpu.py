@@ -33,7 +33,10 @@ def _worker(rank, world, port, n_q, k, active, use_balance, ret):
     try:
         order = D.balanced_order(active) if use_balance else None
         full = D.sharded_scores(lambda rows: _fake_scores(rows, k, active), n_q, k, torch.device("cpu"), order)
-        ret[rank] = full.numpy()
+        # CIRR shape: (logits, subset logits) tuple, plus the gathered argsort of the first
+        (a, b), idx = D.sharded_scores(lambda rows: (_fake_scores(rows, k, active), _fake_scores(rows, 5, active) * 2.0),
+                                       n_q, (k, 5), torch.device("cpu"), order, with_indices=True)
+        ret[rank] = (full.numpy(), a.numpy(), b.numpy(), idx.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -48,8 +51,14 @@ def test_two_rank_gather_equals_single_process(n_q, use_balance):
     ret = mp.Manager().dict()
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n_q, k, active, use_balance, ret), nprocs=world, join=True)
+    expect_b = _fake_scores(list(range(n_q)), 5, active).numpy() * 2.0
+    expect_idx = torch.argsort(torch.tensor(expect), dim=-1, descending=True, stable=True).numpy()
     for r in range(world):
-        np.testing.assert_array_equal(ret[r], expect)
+        full, a, b, idx = ret[r]
+        np.testing.assert_array_equal(full, expect)
+        np.testing.assert_array_equal(a, expect)
+        np.testing.assert_array_equal(b, expect_b)
+        np.testing.assert_array_equal(idx, expect_idx)
 
 
 def test_empty_and_tiny_query_sets_single_process():
@@ -59,6 +68,10 @@ def test_empty_and_tiny_query_sets_single_process():
     assert out.shape == (0, 3)
     out = D.sharded_scores(lambda rows: torch.full((len(rows), 2), 7.0), n_queries=1, k=2, device=torch.device("cpu"))
     assert out.tolist() == [[7.0, 7.0]]
+    (a, b), idx = D.sharded_scores(lambda rows: (torch.tensor([[1.0, 3.0, 2.0]]), torch.zeros((1, 5))), 1, (3, 5), torch.device("cpu"), with_indices=True)
+    assert a.tolist() == [[1.0, 3.0, 2.0]] and b.shape == (1, 5) and idx.tolist() == [[1, 2, 0]]
+    with pytest.raises(ValueError, match="expected widths"):          # a tuple where one tensor was declared
+        D.sharded_scores(lambda rows: (torch.zeros((1, 3)), torch.zeros((1, 5))), 1, 3, torch.device("cpu"))
 
 
 def test_shard_bounds_cover_everything():

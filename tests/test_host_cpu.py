@@ -83,3 +83,15 @@ def test_init_tokenizer_offline_behaviour():
     tok = init_tokenizer(allow_fallback=True)
     assert tok.enc_token_id == 30523
     assert create_vit("base", 384)[1] == 768 and create_vit("large", 224)[0].depth == 24
+
+
+def test_bank_rows_are_validated_on_the_host():
+    """A candidate / reference / subset row outside the index bank raises before anything is launched (the
+    gather kernel would clamp it to a silently wrong image)."""
+    ds = V.RelativeValSet(ref_index=np.array([0, 3]), cand_index=np.array([[1, 2], [2, 9]]), labels=np.ones((2, 2), dtype=bool), captions=["a", "b"])
+    V._check_bank_rows(ds, 10)
+    with pytest.raises(IndexError, match="cand_index holds row 9"):
+        V._check_bank_rows(ds, 9)
+    ds.group_index = np.array([[0, 1, 2, 3, -1]] * 2)
+    with pytest.raises(IndexError, match="group_index holds row -1"):
+        V._check_bank_rows(ds, 10)

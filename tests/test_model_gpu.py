@@ -3,10 +3,15 @@ reference and against the CPU oracle, on a real MI355X.
 
 Tolerances (stated per north_star): the reference computes in fp32; the HIP path rounds GEMM and
 attention operands to bf16 (8-bit mantissa, ~0.4 % per rounding) or fp16 (11-bit) and accumulates
-in fp32.  Measured drift on these fixtures is printed by each test (`-s`); the asserted bounds are
-  ViT tokens / z_t (O(1) LayerNorm outputs): bf16 4e-2, fp16 6e-3 absolute
-  logits:                                   bf16 2e-2 ("test" weights, |logit| ~ 0.2), fp16 3e-3
-  rank order: identical wherever the reference's adjacent sorted-logit gap exceeds 4x the bound.
+in fp32.  Measured drift on these fixtures is printed by each test (`-s`); every asserted bound is
+about 2x the drift measured on MI355X (table in DESIGN.md section 2):
+  ViT tokens / z_t (O(1) LayerNorm outputs): TOK_TOL, absolute
+  logits: LOGIT_TOL per fixture (the fixtures' logit spreads differ by 100x), absolute; tiny fixtures: a fraction
+          of the row's own spread (REL_TOL * sigma)
+  rank order: every candidate pair whose reference gap exceeds 4x the bound keeps its order, the NUMBER of such
+          decided pairs is asserted (>= half of all pairs on the rank fixtures), sorted positions whose two
+          neighbour gaps exceed the margin hold the same candidate, and Recall@k / Recall_subset@k computed from
+          our logits equal the reference's recall tuples on labels whose rank is decided by that margin.
 """
 import json
 
@@ -19,8 +24,16 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
-TOK_TOL = {torch.bfloat16: 4e-2, torch.float16: 6e-3}
-LOGIT_TOL = {torch.bfloat16: 2e-2, torch.float16: 3e-3}
+BF, HF = torch.bfloat16, torch.float16
+TOK_TOL = {BF: 4e-2, HF: 6e-3}
+LOGIT_TOL = {                       # absolute, per fixture (logit sigma over candidates in brackets)
+    "full224": {BF: 6e-3, HF: 1.5e-3},          # [0.026]
+    "full224_spread": {BF: 3e-2, HF: 4.5e-3},   # [0.345]
+    "full384": {BF: 8e-3, HF: 2e-3},
+    "rank224": {BF: 8e-3, HF: 2e-3},            # [0.14]  (= tol_unit the fixture's label margins were cut with)
+    "bxb224": {BF: 6e-3, HF: 1.5e-3},           # [0.135]
+}
+REL_TOL = {BF: 0.25, HF: 0.04}      # tiny geometry: |error| <= REL_TOL * sigma(reference logits of that row) [sigma 0.08..0.17]
 
 
 @pytest.fixture(scope="module")
@@ -42,12 +55,28 @@ def build_models(g, v, seed, profile, dtype, device, fold_merge=True):
     return m2, m1
 
 
-def margin_order_ok(ours: np.ndarray, ref: np.ndarray, tol: float) -> bool:
-    """Every pair whose reference gap exceeds 4*tol must keep its order."""
-    d_ref = ref[:, None] - ref[None, :]
-    d_our = ours[:, None] - ours[None, :]
+def pair_order(ours: np.ndarray, ref: np.ndarray, tol: float):
+    """(decided, total, ok): candidate pairs whose reference gap exceeds 4*tol, all pairs, and whether every decided
+    pair keeps its order in `ours`."""
+    iu = np.triu_indices(len(ref), 1)
+    d_ref = (ref[:, None] - ref[None, :])[iu]
+    d_our = (ours[:, None] - ours[None, :])[iu]
     decided = np.abs(d_ref) > 4 * tol
-    return bool(np.all(np.sign(d_ref[decided]) == np.sign(d_our[decided])))
+    return int(decided.sum()), len(d_ref), bool(np.all(np.sign(d_ref[decided]) == np.sign(d_our[decided])))
+
+
+def margin_order_ok(ours: np.ndarray, ref: np.ndarray, tol: float) -> bool:
+    return pair_order(ours, ref, tol)[2]
+
+
+def fixed_positions(ours: np.ndarray, ref: np.ndarray, tol: float):
+    """Sorted positions whose gaps to BOTH neighbours exceed 4*tol in the reference: (count, all hold the same candidate)."""
+    o_ref, o_our = np.argsort(-ref, kind="stable"), np.argsort(-ours, kind="stable")
+    s = ref[o_ref]
+    up = np.concatenate([[np.inf], s[:-1] - s[1:]])
+    dn = np.concatenate([s[:-1] - s[1:], [np.inf]])
+    pos = np.where((up > 4 * tol) & (dn > 4 * tol))[0]
+    return len(pos), bool(np.all(o_ref[pos] == o_our[pos]))
 
 
 # ------------------------------------------------------------------------------------------------ tiny geometry, full loop
@@ -61,12 +90,12 @@ def tiny(request, cuda):
 
 def test_img_embed_tiny(tiny):
     z, g, v, m2, m1, dt = tiny
-    feats = m2.img_embed(synthetic.images(range(14), v.image_size).cuda())
+    feats = m2.img_embed(H.fixture_images(z, range(14), v.image_size).cuda())
     assert feats.dtype == torch.float32 and feats.shape == (14, v.num_tokens, v.width)
     err = np.abs(feats[:, :3, :8].cpu().numpy() - z["index_features_slice"]).max()
     print(f"\n[tiny vit {dt}] max|err| = {err:.3e}")
     assert err < TOK_TOL[dt]
-    f2, atts = m2.img_embed(synthetic.images(range(2), v.image_size).cuda(), atts=True)
+    f2, atts = m2.img_embed(H.fixture_images(z, range(2), v.image_size).cuda(), atts=True)
     assert atts.dtype == torch.long and atts.shape == f2.shape[:2] and bool((atts == 1).all())
 
 
@@ -75,7 +104,7 @@ def test_img_embed_tiny(tiny):
 def test_scoring_loop_tiny(tiny, flavour, query_batch):
     from candidate_reranking_cir_amd import validate_stage2 as V
     z, g, v, m2, m1, dt = tiny
-    bank = V.extract_index_features(synthetic.images(range(14), v.image_size), m2)
+    bank = V.extract_index_features(H.fixture_images(z, range(14), v.image_size), m2)
     caps = [str(c) for c in z["cirr_caps"]] if flavour == "cirr" else [V.fiq_caption(str(p[0]), str(p[1])) for p in z["fiq_caps"]]
     ds = V.RelativeValSet(ref_index=z["refs"], cand_index=z["cand_idx"], labels=z["labels"], captions=caps,
                           group_index=z["groups"] if flavour == "cirr" else None, target_index=z["targets"])
@@ -84,14 +113,19 @@ def test_scoring_loop_tiny(tiny, flavour, query_batch):
     ref = z[f"{flavour}_logits"]
     skipped = ~z["labels"].any(1)
     assert skipped.any() and np.all(logits[skipped] == np.float32(-99999.99)) and np.all(ref[skipped] == np.float32(-99999.99))
-    err = np.abs(logits[~skipped] - ref[~skipped]).max()
-    print(f"\n[tiny {flavour} {dt} qb={query_batch}] max|dlogit| = {err:.3e} (logit std {ref[~skipped].std():.3f})")
-    assert err < LOGIT_TOL[dt]
+    # the tiny model's logits cluster (sigma ~ 2e-3 per row): the bound is a fraction of each row's own spread, so a model
+    # that ignored the candidates (row mean everywhere, error ~ 1 sigma) cannot pass
+    sig = ref[~skipped].std(axis=1, keepdims=True)
+    rel = (np.abs(logits[~skipped] - ref[~skipped]) / sig).max()
+    print(f"\n[tiny {flavour} {dt} qb={query_batch}] max|dlogit| = {np.abs(logits[~skipped] - ref[~skipped]).max():.3e} "
+          f"= {rel:.3f} sigma (row sigma {sig.min():.2e}..{sig.max():.2e})")
+    assert rel < REL_TOL[dt]
     if flavour == "cirr":
-        gerr = np.abs(out[1].cpu().numpy() - z["cirr_group_logits"]).max()
-        assert gerr < LOGIT_TOL[dt]
+        gref = z["cirr_group_logits"]
+        grel = (np.abs(out[1].cpu().numpy() - gref) / gref.std(axis=1, keepdims=True)).max()
+        assert grel < 2 * REL_TOL[dt]                      # 5 members: the row sigma itself is a noisy estimate
         for q in np.where(~skipped)[0]:
-            assert margin_order_ok(logits[q], ref[q], LOGIT_TOL[dt])
+            assert margin_order_ok(logits[q], ref[q], REL_TOL[dt] * float(sig.min()))
         metrics = V.compute_cirr_val_metrics(out[0], out[1], ds)
         ref_metrics = V.compute_cirr_val_metrics(torch.tensor(ref), torch.tensor(z["cirr_group_logits"]), ds)
         np.testing.assert_allclose(ref_metrics, z["cirr_metrics"], atol=1e-4)     # host metric code == reference's
@@ -106,7 +140,7 @@ def test_padded_masks(tiny):
     z, g, v, m2, m1, dt = tiny
     m = H.load("masks.npz")
     ids, mask = torch.tensor(m["input_ids"]).cuda(), torch.tensor(m["attention_mask"]).cuda()
-    feats16 = m2.img_embed16(synthetic.images(range(6), v.image_size).cuda())
+    feats16 = m2.img_embed16(H.fixture_images(z, range(6), v.image_size).cuda())
     zt = m1.z_t(feats16[:3], ids, mask)
     valid = mask.bool().cpu().numpy()
     err1 = np.abs(zt.last_hidden_state.cpu().numpy() - m["stage1_hidden"])[valid].max()
@@ -126,7 +160,7 @@ def test_batch_invariance_and_api(tiny):
     """A candidate scored alone equals the same candidate scored inside a batch (the reference's
     expand-to-K semantics), through the drop-in img_txt_fusion_val(text=[str]) surface."""
     z, g, v, m2, m1, dt = tiny
-    feats = m2.img_embed(synthetic.images(range(8), v.image_size).cuda())
+    feats = m2.img_embed(H.fixture_images(z, range(8), v.image_size).cuda())
     cap = [str(z["cirr_caps"][2])]
     zt = m1.img_txt_fusion(feats[:1], None, cap, train=False, return_raw=True)
     assert zt.last_hidden_state.shape[0] == 1
@@ -143,7 +177,7 @@ def test_kv_bank_reuse_is_bit_identical(tiny):
     per-candidate projection (same kernel, same rows), including skip rows and the CIRR subset."""
     from candidate_reranking_cir_amd import validate_stage2 as V
     z, g, v, m2, m1, dt = tiny
-    bank = V.extract_index_features(synthetic.images(range(14), v.image_size), m2)
+    bank = V.extract_index_features(H.fixture_images(z, range(14), v.image_size), m2)
     ds = V.RelativeValSet(ref_index=z["refs"], cand_index=z["cand_idx"], labels=z["labels"], captions=[str(c) for c in z["cirr_caps"]],
                           group_index=z["groups"], target_index=z["targets"])
     plain = V.generate_val_predictions(m2, m1, ds, bank, query_batch=3)
@@ -157,7 +191,7 @@ def test_last_layer_cls_trimming_is_equivalent(tiny):
     """The last layer's per-token work on CLS rows only gives the logits of the untrimmed schedule (same rows, same
     kernels up to the tile variant; bias enters the accumulator first or last)."""
     z, g, v, m2, m1, dt = tiny
-    feats = m2.img_embed(synthetic.images(range(9), v.image_size).cuda())
+    feats = m2.img_embed(H.fixture_images(z, range(9), v.image_size).cuda())
     cap = [str(z["cirr_caps"][3])]
     zt = m1.img_txt_fusion(feats[:1], None, cap, train=False, return_raw=True)
     eng = m2.engines()[1]
@@ -168,7 +202,8 @@ def test_last_layer_cls_trimming_is_equivalent(tiny):
         b = m2.img_txt_fusion_val(zt, feats[1:], cap)
     finally:
         eng.trim_last = True
-    assert torch.allclose(a, b, atol=2e-5, rtol=0)
+    print(f"\n[cls trim] max|d| {(a - b).abs().max().item():.3e}")
+    assert torch.allclose(a, b, atol=1e-4, rtol=0)
 
 
 def test_unfolded_merge_matches_folded(cuda):
@@ -177,11 +212,13 @@ def test_unfolded_merge_matches_folded(cuda):
     outs = []
     for fold in (True, False):
         m2, m1 = build_models(g, v, int(z["seed"]), str(z["profile"]), torch.bfloat16, cuda, fold_merge=fold)
-        feats = m2.img_embed(synthetic.images(range(8), v.image_size).cuda())
+        feats = m2.img_embed(H.fixture_images(z, range(8), v.image_size).cuda())
         cap = [str(z["cirr_caps"][2])]
         zt = m1.img_txt_fusion(feats[:1], None, cap, train=False, return_raw=True)
         outs.append(m2.img_txt_fusion_val(zt, feats[1:], cap).cpu().numpy())
-    assert np.abs(outs[0] - outs[1]).max() < LOGIT_TOL[torch.bfloat16]
+    d = np.abs(outs[0] - outs[1]).max()
+    print(f"\n[fold vs unfold] max|d| {d:.3e} (logit sigma {outs[1].std():.3f})")
+    assert d < 0.25 * outs[1].std()                       # the two schedules round Wm*W0 differently (bf16)
 
 
 # ------------------------------------------------------------------------------------------------ reference geometry
@@ -202,13 +239,14 @@ def test_full224(cuda, tag, dtype):
     logits = m2.score(zt.last_hidden_state, ids, mask, feats[1:], torch.zeros(k, dtype=torch.int64), taps=taps).cpu().numpy()
     e_tap = max(np.abs(torch.stack([t[b] for t in taps]).cpu().numpy() - z[f"taps{b}"]).max() for b in (0, 1))
     e_log = np.abs(logits - z["logits"]).max()
-    scale = 1.0 if tag == "full224" else float(np.abs(z["logits"]).max()) / 0.2     # spread weights: larger logits
+    tol = LOGIT_TOL[tag][dtype]
     exact = float((np.argsort(-logits, kind="stable") == z["order"]).mean())
+    decided, total, ok = pair_order(logits, z["logits"], tol)
     print(f"\n[{tag} {dtype}] vit {e_vit:.3e}  z_t {e_zt:.3e}  taps {e_tap:.3e}  logits {e_log:.3e} "
-          f"(std {z['logits'].std():.3f})  exact-rank match {exact:.2f}")
-    assert e_vit < TOK_TOL[dtype] and e_zt < TOK_TOL[dtype] * 1.5 and e_tap < TOK_TOL[dtype] * 2.5
-    assert e_log < LOGIT_TOL[dtype] * scale
-    assert margin_order_ok(logits, z["logits"], LOGIT_TOL[dtype] * scale)
+          f"(std {z['logits'].std():.3f}, tol {tol:.1e})  exact-rank match {exact:.2f}  decided pairs {decided}/{total}")
+    assert e_vit < TOK_TOL[dtype] and e_zt < TOK_TOL[dtype] and e_tap < TOK_TOL[dtype] * 1.5
+    assert e_log < tol
+    assert ok and decided >= (30 if dtype == HF else 9)     # of 45 pairs (bf16 on these clustered logits: few, see rank224)
 
 
 def test_full384_cirr_loop(cuda):
@@ -229,7 +267,7 @@ def test_full384_cirr_loop(cuda):
     e1 = np.abs(logits.cpu().numpy()[~skipped] - z["cirr_logits"][~skipped]).max()
     e2 = np.abs(glogits.cpu().numpy() - z["cirr_group_logits"]).max()
     print(f"\n[full384] bank {e_bank:.3e} logits {e1:.3e} group logits {e2:.3e}")
-    assert e_bank < 5e-2 and e1 < LOGIT_TOL[torch.bfloat16] and e2 < LOGIT_TOL[torch.bfloat16]
+    assert e_bank < TOK_TOL[BF] and e1 < LOGIT_TOL["full384"][BF] and e2 < LOGIT_TOL["full384"][BF]
 
 
 def test_full_size_properties(cuda):
@@ -264,13 +302,116 @@ def test_full_size_properties(cuda):
     small = m2.score(z[:1], ids[:1], mask[:1], m2.img_embed16(images[q_n:q_n + 6]), torch.zeros(6, dtype=torch.int64, device="cuda"))
     e = (small - logits[:6]).abs().max().item()
     print(f"\n[full size] batch-invariance drift {e:.3e}")
-    assert e < LOGIT_TOL[torch.bfloat16]
+    assert e < LOGIT_TOL["full224"][BF]
     # ranking
     lv = logits.view(q_n, k)
     order = ops.argsort_desc(lv)
     assert torch.equal(torch.sort(order, dim=1).values, torch.arange(k, device="cuda").expand(q_n, k))
     sorted_l = torch.gather(lv, 1, order)
     assert (sorted_l[:, 1:] <= sorted_l[:, :-1]).all()
+
+
+
+# ------------------------------------------------------------------------------------------------ rank order at K = 100 / 50 / 200
+@pytest.fixture(scope="module", params=[BF, HF], ids=["bf16", "fp16"])
+def rank(request, cuda):
+    from candidate_reranking_cir_amd import validate_stage2 as V
+    z = H.load("rank224.npz")
+    g, v = H.geometry(H.FULL_BERT, dict(image_size=224))
+    m2, m1 = build_models(g, v, int(z["seed"]), str(z["profile"]), request.param, cuda)
+    imgs = synthetic.scene_images(range(int(z["n_index"])), 224)
+    bank = V.extract_index_features(imgs, m2, batch_size=128)
+    return z, m2, m1, bank, request.param
+
+
+def _rank_asserts(tag, logits, ref, tol, min_decided_frac=0.5):
+    e = np.abs(logits - ref)
+    ec = np.abs((logits - ref) - (logits - ref).mean(axis=1, keepdims=True))
+    n_dec = n_tot = n_fix = 0
+    for q in range(len(ref)):
+        d, t, ok = pair_order(logits[q], ref[q], tol)
+        assert ok, f"{tag} query {q}: a decided pair changed order"
+        nf, okf = fixed_positions(logits[q], ref[q], tol)
+        assert okf, f"{tag} query {q}: a margin-separated sorted position holds another candidate"
+        n_dec, n_tot, n_fix = n_dec + d, n_tot + t, n_fix + nf
+    print(f"   [{tag}] max|dlogit| {e.max():.3e} (centred {ec.max():.3e}, sigma {ref.std(axis=1).mean():.3f}, tol {tol:.1e})  "
+          f"decided pairs {n_dec}/{n_tot} = {n_dec / n_tot:.2f}  fixed positions {n_fix}")
+    assert e.max() < tol
+    assert n_dec >= min_decided_frac * n_tot, "rank check went vacuous"
+    return n_fix
+
+
+def test_rank_bank_tokens(rank):
+    z, m2, m1, bank, dt = rank
+    assert bank.shape == (int(z["n_index"]), 197, 768)
+    err = np.abs(bank[:, :3, :8].float().cpu().numpy() - z["bank_slice"]).max()
+    print(f"\n[rank224 bank {dt}] max|err| {err:.3e}")
+    assert err < TOK_TOL[dt]
+
+
+@pytest.mark.parametrize("tag", ["c100", "c200"])
+def test_rank_order_cirr_k100_k200(rank, tag):
+    """BASELINE configs[2] / the K=200 half of configs[4]: the reference's generate_cirr_val_predictions +
+    compute_cirr_val_metrics at K=100 (+5 subset, one skipped row) and K=200 (+5) on separated logits."""
+    from candidate_reranking_cir_amd import validate_stage2 as V
+    z, m2, m1, bank, dt = rank
+    ds = V.RelativeValSet(ref_index=z[f"{tag}_refs"], cand_index=z[f"{tag}_cand"], labels=z[f"{tag}_labels"],
+                          captions=[str(c) for c in z[f"{tag}_caps"]], group_index=z[f"{tag}_groups"], target_index=z[f"{tag}_targets"])
+    logits_t, glogits_t = V.generate_cirr_val_predictions(m2, m1, ds, bank, query_batch=4)
+    logits, glogits = logits_t.cpu().numpy(), glogits_t.cpu().numpy()
+    ref, gref = z[f"{tag}_logits"], z[f"{tag}_group_logits"]
+    skipped = ~z[f"{tag}_labels"].any(1)
+    assert np.array_equal(logits[skipped], ref[skipped])                         # -99999.99 rows, bit for bit
+    tol = LOGIT_TOL["rank224"][dt]
+    print(f"\n[rank224 {tag} {dt}]")
+    n_fix = _rank_asserts(tag, logits[~skipped], ref[~skipped], tol)
+    _rank_asserts(tag + " subset", glogits, gref, tol, min_decided_frac=0.5)
+    assert n_fix >= {"c100": {BF: 2, HF: 20}, "c200": {BF: 0, HF: 8}}[tag][dt]      # (measured 4 / 31 and 0 / 12)
+    # the target scored as a top-K candidate and as a subset member is the same image through the same z_t
+    for q in np.where(~skipped)[0]:
+        ci, gi = int(z[f"{tag}_labels"][q].argmax()), int(np.where(z[f"{tag}_groups"][q] == z[f"{tag}_targets"][q])[0][0])
+        assert abs(logits[q, ci] - glogits[q, gi]) < 1e-5
+    # Recall@1/5/10/50 and Recall_subset@1/2/3 from OUR logits == the reference's tuple (labels sit on margin-decided ranks)
+    ours = V.compute_cirr_val_metrics(logits_t, glogits_t, ds)
+    print("   recall ours", np.round(ours, 2), "reference", np.round(z[f"{tag}_metrics"], 2))
+    np.testing.assert_allclose(ours, z[f"{tag}_metrics"], atol=1e-4)
+
+
+def test_rank_order_fiq_k50(rank):
+    """BASELINE configs[1]: FashionIQ-style K=50 (two captions joined as validate_stage2.py:97-100) through the reference's
+    generate_fiq_val_predictions / compute_fiq_val_metrics."""
+    from candidate_reranking_cir_amd import validate_stage2 as V
+    z, m2, m1, bank, dt = rank
+    caps = [V.fiq_caption(str(p[0]), str(p[1])) for p in z["f50_caps"]]
+    ds = V.RelativeValSet(ref_index=z["f50_refs"], cand_index=z["f50_cand"], labels=z["f50_labels"], captions=caps)
+    logits_t = V.generate_fiq_val_predictions(m2, m1, ds, bank, query_batch=2)
+    print(f"\n[rank224 f50 {dt}]")
+    _rank_asserts("f50", logits_t.cpu().numpy(), z["f50_logits"], LOGIT_TOL["rank224"][dt])
+    ours = V.compute_fiq_val_metrics(logits_t, ds)
+    np.testing.assert_allclose(ours, z["f50_metrics"], atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [BF, HF], ids=["bf16", "fp16"])
+def test_img_txt_fusion_bxb_matches_reference(cuda, dtype):
+    """SURVEY 8(f)-4, forward half: the training-mode surface img_txt_fusion (blip_stage2.py:65-99; row i's caption and
+    z_t against all B candidates, ragged captions -> padding='longest' masks inside the batch) in eval mode against the
+    reference's (B, B) logits, z_t from our stage I on the padded batch as stage2_train.py:202-207 does."""
+    z = H.load("bxb224.npz")
+    g, v = H.geometry(H.FULL_BERT, dict(image_size=224))
+    m2, m1 = build_models(g, v, int(z["seed"]), str(z["profile"]), dtype, cuda)
+    bank = m2.img_embed(synthetic.scene_images(range(8), 224).cuda())
+    caps = [str(c) for c in z["caps"]]
+    zt = m1.img_txt_fusion(bank[:4], bank[:4], caps, train=False, return_raw=True)
+    e_z = np.abs(zt.last_hidden_state[:, 0].cpu().numpy() - z["z_t_cls"]).max()
+    out = m2.img_txt_fusion(zt, bank[4:8], caps, train=True)
+    assert out.shape == (4, 4) and out.dtype == torch.float32
+    e = np.abs(out.cpu().numpy() - z["logits"]).max()
+    print(f"\n[bxb224 {dtype}] z_t cls {e_z:.3e}  logits {e:.3e} (sigma {z['logits'].std():.3f})")
+    assert e_z < TOK_TOL[dtype] and e < LOGIT_TOL["bxb224"][dtype]
+    m2.train()
+    with pytest.raises(NotImplementedError, match="forward only"):
+        m2.img_txt_fusion(zt, bank[4:8], caps)
+    m2.eval()
 
 
 def test_state_dict_roundtrip_and_cpu_refusal(cuda):

@@ -17,7 +17,7 @@ ATOL = 2e-5
 def tiny():
     z, g, v, sd2, sd1 = H.tiny_setup()
     with torch.no_grad():
-        feats = O.img_embed(sd2, synthetic.images(range(14), v.image_size))
+        feats = O.img_embed(sd2, H.fixture_images(z, range(14), v.image_size))
     return z, g, v, sd2, sd1, feats
 
 
@@ -96,3 +96,38 @@ def test_full224(tag):
     np.testing.assert_allclose(torch.stack([t[1] for t in taps]).numpy(), z["taps1"], atol=2e-4)
     np.testing.assert_allclose(logits.numpy(), z["logits"], atol=1e-4)
     assert (torch.argsort(logits, descending=True).numpy() == z["order"]).all()
+
+
+def test_rank224_and_bxb224():
+    """The oracle at the benchmark geometry against the reference's own loops on STRUCTURED images (rank224.npz: one
+    K=50 FashionIQ-style query incl. the joined caption, one CIRR subset) and its B x B training-mode surface in eval
+    mode with padding masks inside the batch (bxb224.npz, blip_stage2.py:65-99)."""
+    z, b = H.load("rank224.npz"), H.load("bxb224.npz")
+    g, v = H.geometry(H.FULL_BERT, dict(image_size=224))
+    sd2, sd1 = H.state_dicts(g, v, int(z["seed"]), str(z["profile"]))
+    torch.set_num_threads(8)
+    q = 0
+    rows = [int(z["f50_refs"][q])] + [int(i) for i in z["f50_cand"][q]] + [int(i) for i in z["c100_groups"][0]] + [int(z["c100_refs"][0])]
+    uniq = sorted(set(rows) | set(range(8)))
+    pos = {r: i for i, r in enumerate(uniq)}
+    with torch.no_grad():
+        feats = O.img_embed(sd2, synthetic.scene_images(uniq, 224))
+        np.testing.assert_allclose(feats[[pos[i] for i in range(8)]][:, :3, :8].numpy(), z["bank_slice"][:8], atol=1e-4)
+        # FashionIQ-style K = 50
+        ids, mask = H.tokenize([H.fiq_caption(z["f50_caps"][q])])
+        zt = O.stage1_z_t(sd1, feats[pos[rows[0]]][None], ids, mask)
+        logits = O.img_txt_fusion_val(sd2, zt, feats[[pos[i] for i in rows[1:51]]], ids, mask)
+        np.testing.assert_allclose(logits.numpy(), z["f50_logits"][q], atol=2e-4)
+        # CIRR subset of query 0
+        ids, mask = H.tokenize([str(z["c100_caps"][0])])
+        zt = O.stage1_z_t(sd1, feats[pos[rows[-1]]][None], ids, mask)
+        glog = O.img_txt_fusion_val(sd2, zt, feats[[pos[i] for i in rows[51:56]]], ids, mask)
+        np.testing.assert_allclose(glog.numpy(), z["c100_group_logits"][0], atol=2e-4)
+        # B x B: row i = (caption i, z_t i) against the B candidates
+        ids, mask = H.tokenize([str(c) for c in b["caps"]])
+        assert (mask == 0).any()
+        bank = feats[[pos[i] for i in range(8)]]
+        zt = O.stage1_z_t(sd1, bank[:4], ids, mask)
+        np.testing.assert_allclose(zt[:, 0].numpy(), b["z_t_cls"], atol=1e-4)
+        out = torch.stack([O.img_txt_fusion_val(sd2, zt[i:i + 1], bank[4:8], ids[i:i + 1], mask[i:i + 1]) for i in range(4)])
+    np.testing.assert_allclose(out.numpy(), b["logits"], atol=2e-4)

@@ -1,0 +1,97 @@
+"""Aggregates rocprofv3 PMC passes of ONE bench command (each pass = `--kernel-trace --pmc <counters>` only, program
+directly after `--`) into per-kernel averages -> profiles/<name>.json.
+
+  python tools/pmc_summary.py profiles/r2_pmc_summary.json gpurun_out/r2_pmc_sq gpurun_out/r2_pmc_fetch gpurun_out/r2_pmc_write
+
+Units and the gfx950 corrections follow /opt/skills/guides/MI355X_MICROARCH.md:
+  * FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE reports half the bytes of wide coalesced reads on gfx950 -> doubled;
+    Infinity-Cache hits are counted (fabric-side counters).
+  * GRBM_GUI_ACTIVE is summed over the 8 XCDs: effective clock = GRBM_GUI_ACTIVE / 8 / kernel duration.
+  * SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD summed over the chip: MFMA-pipe utilisation =
+    SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE / 8).
+  * SQ_WAVE_CYCLES / SQ_BUSY_CYCLES count quad-cycles.
+Durations come from the Start/End timestamps of the same (profiled) dispatches: they are a few % longer than in an
+un-profiled run (the guide: never compare a profiled arm with an un-profiled one)."""
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def canonical(name: str):
+    """rocprofv3 prints some instantiations mangled and some through a lossy demangler: map both to bench.py's names."""
+    if "cir" not in name:
+        return None
+    t = "_Float16" if ("DF16_" in name or "IDhL" in name) else "__bf16"
+    m = re.search(r"gemm256_kernelI(DF16b|DF16_|Dh)Lb([01])ELb([01])E", name)
+    if m:
+        return f"cir::gemm256_kernel<{t},{'true' if m.group(2) == '1' else 'false'},{'true' if m.group(3) == '1' else 'false'}>"
+    if "gemm256_kernel<" in name:                         # lossy demangle keeps only the last bool: (out32, res) in {(1,1), (1,0)}
+        return f"cir::gemm256_kernel<{t},true,{'true' if 'true>' in name else 'false'}>"
+    m = re.search(r"gemm_kernelI(DF16b|DF16_|Dh)Lb([01])E", name)
+    if m:
+        return f"cir::gemm_kernel<{t},{'true' if m.group(2) == '1' else 'false'}>"
+    if "gemm_kernel<" in name:
+        return f"cir::gemm_kernel<{t},true>"
+    for short in ("attn_shared_kernel", "attn_stream_kernel", "layernorm_kernel", "embed_ln_kernel", "patchify_kernel", "vit_assemble_kernel",
+                  "gather_rows_kernel", "topk_desc_kernel", "small_linear_kernel"):
+        if short in name:
+            masked = ""
+            if short.startswith("attn"):
+                mm = re.search(short + r"I(DF16b|DF16_|Dh)Lb([01])E", name)
+                masked = ("<masked>" if (mm and mm.group(2) == "1") or ("true>" in name and not mm) else "<unmasked>")
+            return f"cir::{short}{masked}"
+    return "cir::other"
+
+
+def main():
+    out, dirs = sys.argv[1], sys.argv[2:]
+    ker = {}
+    passes = {}
+    for d in dirs:
+        files = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)
+        seen = set()
+        for f in files:
+            for r in csv.DictReader(open(f)):
+                k = canonical(r["Kernel_Name"])
+                if k is None:
+                    continue
+                e = ker.setdefault(k, {"counters": {}, "dur_ns": {}, "n": {}})
+                c = r["Counter_Name"]
+                seen.add(c)
+                e["counters"][c] = e["counters"].get(c, 0.0) + float(r["Counter_Value"])
+                e["n"][c] = e["n"].get(c, 0) + 1
+                e["dur_ns"][c] = e["dur_ns"].get(c, 0.0) + (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        passes[d] = sorted(seen)
+    res = {"source": "rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "
+                     "(one pass per counter group; all launches of the run incl. warm-up and the instrumented steps)",
+           "passes": passes, "by_kernel": {}}
+    for k, e in sorted(ker.items()):
+        avg = {c: e["counters"][c] / e["n"][c] for c in e["counters"]}
+        dur_us = {c: e["dur_ns"][c] / e["n"][c] / 1e3 for c in e["counters"]}
+        row = {"launches_per_pass": max(e["n"].values()), "avg_us_profiled": round(sum(dur_us.values()) / len(dur_us), 2),
+               "counters_per_launch": {c: round(v, 1) for c, v in avg.items()}}
+        if "GRBM_GUI_ACTIVE" in avg:
+            cyc = avg["GRBM_GUI_ACTIVE"] / 8.0
+            row["effective_clock_ghz"] = round(cyc / (dur_us["GRBM_GUI_ACTIVE"] * 1e3), 3)
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in avg:
+                row["mfma_pipe_utilisation"] = round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * cyc), 4)
+            if "SQ_BUSY_CYCLES" in avg:
+                row["sq_busy_quad_cycles_per_gpu_cycle"] = round(avg["SQ_BUSY_CYCLES"] / cyc, 3)
+        if "FETCH_SIZE" in avg or "WRITE_SIZE" in avg:
+            fb = 2.0 * avg.get("FETCH_SIZE", 0.0) * 1024.0
+            wb = avg.get("WRITE_SIZE", 0.0) * 1024.0
+            row["fetch_bytes_per_launch_corrected_x2"] = round(fb)
+            row["write_bytes_per_launch"] = round(wb)
+            row["hbm_bytes_per_launch"] = round(fb + wb)
+            du = dur_us.get("FETCH_SIZE", dur_us.get("WRITE_SIZE"))
+            row["hbm_side_tb_per_s"] = round((fb + wb) / (du * 1e-6) / 1e12, 3)
+        res["by_kernel"][k] = row
+    json.dump(res, open(out, "w"), indent=1)
+    for k, row in res["by_kernel"].items():
+        print(k, json.dumps({a: b for a, b in row.items() if a != "counters_per_launch"}))
+
+
+if __name__ == "__main__":
+    main()
