@@ -95,12 +95,31 @@ __device__ __forceinline__ void softmax_tile(Softmax& st, f32x16& s, float sl, c
         for (int i = 0; i < 16; ++i) { st.o[0][i] *= alpha; st.o[1][i] *= alpha; }
         st.m_run = m_new;
     }
-    float psum = 0.f;
+    float psum;
+    if constexpr (MASKED) {
+        psum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const float p = MASKED ? __builtin_amdgcn_exp2f(sv[i] - st.m_run) : __builtin_amdgcn_exp2f(fmaf(sv[i], sl, -st.m_run));
-        sv[i] = p;
-        psum += p;
+        for (int i = 0; i < 16; ++i) {
+            const float p = __builtin_amdgcn_exp2f(sv[i] - st.m_run);
+            sv[i] = p;
+            psum += p;
+        }
+    } else {
+        // exponent arguments and the row sum as packed fp32 (v_pk_fma_f32 / v_pk_add_f32: two values per issue slot) -
+        // the ViT kernel is bound by VALU issue, not by the matrix pipe
+        const f32x2 sl2 = {sl, sl}, m2 = {-st.m_run, -st.m_run};
+        f32x2 acc2 = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            const f32x2 arg = __builtin_elementwise_fma(f32x2{sv[i], sv[i + 1]}, sl2, m2);
+            f32x2 p;
+            p.x = __builtin_amdgcn_exp2f(arg.x);
+            p.y = __builtin_amdgcn_exp2f(arg.y);
+            sv[i] = p.x;
+            sv[i + 1] = p.y;
+            acc2 += p;
+        }
+        psum = acc2.x + acc2.y;
     }
     psum += __shfl_xor(psum, 32, 64);
     st.l_run += psum;
@@ -111,15 +130,18 @@ __device__ __forceinline__ void softmax_tile(Softmax& st, f32x16& s, float sl, c
 }
 
 // O^T += V_tile^T * P^T with V row-major in LDS at `vt` (128-byte rows, 64-byte halves swapped on rows with
-// bit 1 set so that the 4-row transposed reads of a 32-lane half hit 64 distinct banks)
+// bit 1 set so that the 4-row transposed reads of a 32-lane half hit 64 distinct banks).  `voff[dt]` = this lane's
+// byte offset inside a tile for dh-tile dt (tile-invariant: computed once per wave, see pv_lane_offsets); the two
+// key halves and the two 8-row blocks of a read pair are immediate offsets.
 template <typename T>
-__device__ __forceinline__ void pv_tile(Softmax& st, const char* vt, int tr_lane_off, const typename Elem<T>::x8 (&pf)[2]) {
+__device__ __forceinline__ void pv_tile(Softmax& st, const char* vt, const int (&voff)[2], const typename Elem<T>::x8 (&pf)[2]) {
     using X8 = typename Elem<T>::x8;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
+        const char* base0 = vt + voff[dt];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            const char* base = vt + (16 * s2) * 128 + ((tr_lane_off & 0x7f) ^ (dt * 64)) + (tr_lane_off & ~0x7f);
+            const char* base = base0 + (16 * s2) * 128;
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + 8 * 128));
             s16x8 both;
@@ -128,6 +150,10 @@ __device__ __forceinline__ void pv_tile(Softmax& st, const char* vt, int tr_lane
             st.o[dt] = Elem<T>::mfma32(__builtin_bit_cast(X8, both), pf[s2], st.o[dt]);
         }
     }
+}
+__device__ __forceinline__ void pv_lane_offsets(int tr_lane_off, int (&voff)[2]) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) voff[dt] = ((tr_lane_off & 0x7f) ^ (dt * 64)) + (tr_lane_off & ~0x7f);
 }
 
 // this lane's address inside a 4-key x 16-dh transposed-read block (without the dh-tile term):
@@ -216,7 +242,13 @@ __global__ __launch_bounds__(1024) void attn_shared_kernel(const AttnArgs a, int
     }
     __syncthreads();
 
-    const int tr_off = tr_lane_offset(lane);
+    int voff[2];
+    pv_lane_offsets(tr_lane_offset(lane), voff);
+    // K fragment addresses: row (key0 + r), chunk (2*sx + hh) ^ ((row >> 1) & 7); key0 is a multiple of 32, so the swizzle
+    // term depends on the lane only - four tile-invariant byte offsets per lane, one add per tile
+    int koff[4];
+#pragma unroll
+    for (int sx = 0; sx < 4; ++sx) koff[sx] = r * 128 + (((2 * sx + hh) ^ ((r >> 1) & 7)) << 4);
     const float sl = a.scale * kLog2e;
     const int nkt = (a.Lk + 31) >> 5;
     for (int qt = wave; qt < a.nqt; qt += nwaves) {
@@ -228,22 +260,21 @@ __global__ __launch_bounds__(1024) void attn_shared_kernel(const AttnArgs a, int
         }
         Softmax st;
         st.init();
-        for (int kt = 0; kt < nkt; ++kt) {
+        const char* kt_base = Ks;
+        const char* vt_base = Vs;
+        for (int kt = 0; kt < nkt; ++kt, kt_base += 32 * 128, vt_base += 32 * 128) {
             const int key0 = kt * 32;
-            const int row = key0 + r;
-            const char* krow = Ks + row * 128;
-            const int ksw = (row >> 1) & 7;
             f32x16 s;
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[i] = 0.f;
 #pragma unroll
             for (int sx = 0; sx < 4; ++sx) {
-                const X8 kf = *reinterpret_cast<const X8*>(krow + (((2 * sx + hh) ^ ksw) << 4));
+                const X8 kf = *reinterpret_cast<const X8*>(kt_base + koff[sx]);
                 s = Elem<T>::mfma32(kf, qf[sx], s);
             }
             X8 pf[2];
             softmax_tile<T, MASKED>(st, s, sl, mp, key0, hh, a.Lk, pf);
-            pv_tile<T>(st, Vs + key0 * 128, tr_off, pf);
+            pv_tile<T>(st, vt_base, voff, pf);
         }
         if (q0 + r < a.Lq) {
             T* op = reinterpret_cast<T*>(a.out) + b1 * a.o_s1 + b0 * a.o_s0 + (int64_t)(q0 + r) * a.o_rs + h * 64 + 4 * hh;
@@ -284,7 +315,8 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const AttnArgs a) {
     for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const X8*>(qp + 16 * s);
 
     char* vl = smem + wave * 4096;
-    const int tr_off = tr_lane_offset(lane);
+    int voff[2];
+    pv_lane_offsets(tr_lane_offset(lane), voff);
     const float sl = a.scale * kLog2e;
     const int nkt = (a.Lk + 31) >> 5;
     // V staging: lane covers 16-byte chunks c = lane + 64 i -> row c>>3, chunk c&7 (rows clamped: probability 0 there)
@@ -324,7 +356,7 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const AttnArgs a) {
         softmax_tile<T, MASKED>(st, s, sl, mp, key0, hh, a.Lk, pf);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        pv_tile<T>(st, vl, tr_off, pf);
+        pv_tile<T>(st, vl, voff, pf);
         __builtin_amdgcn_wave_barrier();  // keep the next tile's LDS writes behind these reads
     }
     if (q0 + r < a.Lq) {

@@ -228,3 +228,59 @@ def test_gather_patchify_assemble_topk_guard_bands(ops):
     torch.cuda.synchronize()
     torch.testing.assert_close(dst.view(101, 2), x.float() @ w.float().T, atol=1e-3, rtol=1e-4)
     assert _flat_intact(buf, 202, torch.float32, slack=256)
+
+
+# ------------------------------------------------------------------------------------------------ attention, many workgroups
+@pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "fp16"])
+@pytest.mark.parametrize("masked", [False, True], ids=["nomask", "mask"])
+@pytest.mark.parametrize("lq,lk", [(197, 197), (40, 33), (224, 256), (500, 200), (33, 70), (64, 8)])
+def test_attention_many_workgroups(ops, dtype, masked, lq, lk):
+    """More workgroups than fit the chip at once (720 > 2 x 256 slots), ragged Lq / Lk, with and without a key mask:
+    against fp32 torch, output between canaries, and bit-identical to the streamed kernel's tile arithmetic
+    (cir_set_tuning forces it: both kernels share the tile update, only the K/V delivery differs)."""
+    from candidate_reranking_cir_amd import lib
+    b1, b0, h = 30, 2, 12
+    d = h * 64
+    g = torch.Generator(device="cpu").manual_seed(lq * 131 + lk)
+    q = torch.randn((b1, b0, lq, d), generator=g).to(dtype).cuda()
+    k = torch.randn((b1, b0, lk, d), generator=g).to(dtype).cuda()
+    v = torch.randn((b1, b0, lk, d), generator=g).to(dtype).cuda()
+    mask = None
+    if masked:
+        valid = torch.randint(1, lk + 1, (b1, b0), generator=g)
+        mask = ((torch.arange(lk)[None, None] >= valid[..., None]).float() * -10000.0).cuda()
+    guard = Guarded(lq, d, dtype, pr=3, pc=32, batch=b1 * b0)
+    out = guard.big.view(b1, b0, lq + 6, d + 64)[:, :, 3:3 + lq, 32:32 + d]
+    ops.attention(q, k, v, out, 0.125, mask)
+    torch.cuda.synchronize()
+    guard.assert_intact(f"attention {lq}x{lk}")
+    s = torch.einsum("abqhd,abkhd->abhqk", q.float().view(b1, b0, lq, h, 64), k.float().view(b1, b0, lk, h, 64)) * 0.125
+    if mask is not None:
+        s = s + mask[:, :, None, None, :]
+    ref = torch.einsum("abhqk,abkhd->abqhd", torch.softmax(s, -1), v.float().view(b1, b0, lk, h, 64)).reshape(b1, b0, lq, d)
+    torch.testing.assert_close(out.float(), ref, atol=2e-2 if dtype == torch.bfloat16 else 4e-3, rtol=0)
+    lib.set_tuning(lib.TUNE_ATTN_SHARED_MAX, -1)
+    try:
+        out2 = torch.empty((b1, b0, lq, d), dtype=dtype, device="cuda")
+        ops.attention(q, k, v, out2, 0.125, mask)
+        torch.cuda.synchronize()
+    finally:
+        lib.set_tuning(lib.TUNE_ATTN_SHARED_MAX, 0)
+    assert torch.equal(out2, out)
+
+
+def test_attention_kv_bank_many_workgroups(ops):
+    """kv_index with more workgroups than CU slots."""
+    t, l, nk, h, rows = 300, 40, 37, 2, 5
+    d = h * 64
+    g = torch.Generator(device="cpu").manual_seed(5)
+    q = torch.randn((t, 2, l, d), generator=g).bfloat16().cuda()
+    bank = torch.randn((rows, nk, 4, d), generator=g).bfloat16().cuda()
+    idx = torch.randint(0, rows, (t,), generator=g).cuda()
+    k4, v4 = bank[:, :, 0::2].permute(0, 2, 1, 3), bank[:, :, 1::2].permute(0, 2, 1, 3)
+    out_a, out_b = torch.empty_like(q), torch.empty_like(q)
+    ops.attention(q, k4, v4, out_a, 0.125, kv_index=idx)           # 1200 workgroups, 2 query tiles, 64 padded keys
+    gth = bank[idx]
+    ops.attention(q, gth[:, :, 0::2].permute(0, 2, 1, 3), gth[:, :, 1::2].permute(0, 2, 1, 3), out_b, 0.125)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b)

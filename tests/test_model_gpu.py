@@ -414,6 +414,27 @@ def test_img_txt_fusion_bxb_matches_reference(cuda, dtype):
     m2.eval()
 
 
+@pytest.mark.parametrize("dtype", [BF, HF], ids=["bf16", "fp16"])
+def test_vit_large_width(cuda, dtype):
+    """`vit='large'` (blip.py:203-209: width 1024, 16 heads, mlp 4096) is accepted by the factories: its widths go
+    through every kernel on the ViT path (1024-column LayerNorm, N = 3072 / 1024 / 4096 GEMMs, 16-head attention).
+    Checked at 3 of the 24 blocks against the fp32 oracle (no reference golden: the oracle is pinned on ViT-B)."""
+    from candidate_reranking_cir_amd import config, weights
+    from candidate_reranking_cir_amd.engine import VitEngine
+    from oracle import cir_oracle as O
+    v = config.VitGeometry(image_size=224, width=1024, depth=3, num_heads=16)
+    spec = {k: sh for k, sh in weights.nlvr_param_spec(config.BertGeometry(encoder_width=1024), v).items() if k.startswith("visual_encoder.")}
+    sd = weights.synth_state_dict(spec, 5, "test")
+    imgs = synthetic.scene_images(range(3), 224)
+    eng = VitEngine({k: t.cuda() for k, t in sd.items()}, v, dtype, cuda)
+    y32, y16 = eng.forward(imgs.cuda(), want32=True)
+    with torch.no_grad():
+        ref = O.vit_forward(sd, imgs, n_heads=16)
+    err = (y32.cpu() - ref).abs().max().item()
+    print(f"\n[vit-large width {dtype}] max|err| {err:.3e}")
+    assert y32.shape == (3, 197, 1024) and err < TOK_TOL[dtype]
+
+
 def test_state_dict_roundtrip_and_cpu_refusal(cuda):
     from candidate_reranking_cir_amd.blip_stage2 import blip_stage2
     z = H.load("tiny_loop.npz")

@@ -15,14 +15,15 @@ def timeit(fn, reps=20):
 
 d = 768
 # ViT: B images, N=197, packed qkv
-for B, N in [(808, 197), (202, 197), (64, 577), (404, 577)]:
+for B, N in [(1696, 197), (808, 197), (202, 197), (64, 577), (404, 577)]:
     qkv = torch.randn((B, N, 3, d), device="cuda").bfloat16()
     out = torch.empty((B, N, d), device="cuda", dtype=torch.bfloat16)
-    for cap in (608, 256):           # K/V of a head shared through LDS up to this many keys (256 = streamed for N=577)
+    for name, cap in (("shared", 608), ("stream", 32)):
         lib.set_tuning(lib.TUNE_ATTN_SHARED_MAX, cap)
         us = timeit(lambda: ops.attention(qkv[:, :, 0].unsqueeze(1), qkv[:, :, 1].unsqueeze(1), qkv[:, :, 2].unsqueeze(1), out.unsqueeze(1), 0.125))
         fl = 4.0 * B * 12 * N * N * 64
-        print(f"vit    B={B:4d} N={N} shared<={cap}: {us:8.1f} us  {fl/us/1e6:7.1f} TF/s")
+        gb = B * N * 4 * d * 2 / 1e9
+        print(f"vit    B={B:4d} N={N} {name:15s}: {us:8.1f} us  {fl/us/1e6:7.1f} TF/s  {gb/us*1e3:6.2f} TB/s (q,k,v,out once)", flush=True)
 lib.set_tuning(lib.TUNE_ATTN_SHARED_MAX, 0)
 T, L, N = 1600, 32, 197
 qb = torch.randn((2, T, L, d), device="cuda").bfloat16()
