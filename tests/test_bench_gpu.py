@@ -52,3 +52,14 @@ def test_two_rank_dry_run_on_one_gpu():
     # 6 queries, skip rate 0.34: skipped queries score only their 5 subset members, and only scored pairs count
     assert d["config"]["triplets_per_step_rank0"] in (5 + 2 * 105, 2 * 5 + 105, 3 * 105, 15)
     assert r.stdout.count('{"metric"') == 1          # rank 0 alone prints the line
+
+
+def test_bank_mode_line():
+    """SURVEY 8(f)-1 regime (`--mode bank`): candidates drawn from a resident index bank with cached K/V."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "bank", "--queries", "2", "--k", "20", "--index-size", "64",
+                        "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["value"] > 0 and "index-bank reuse" in d["metric"] and d["config"]["index_size"] == 64
