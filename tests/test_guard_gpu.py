@@ -36,8 +36,7 @@ class Guarded:
         self.dtype, self.pr, self.pc, self.rows, self.cols = dtype, pr, pc, rows, cols
         shape = (rows + 2 * pr, cols + 2 * pc) if batch is None else (batch, rows + 2 * pr, cols + 2 * pc)
         self.big = torch.empty(shape, dtype=dtype, device="cuda")
-        self.big.view(_INT[dtype]).fill_(CANARY[dtype] if CANARY[dtype] < 2 ** 15 or dtype != torch.bfloat16 and dtype != torch.float16
-                                         else CANARY[dtype])
+        self.big.view(_INT[dtype]).fill_(CANARY[dtype])
         self.view = self.big[..., pr:pr + rows, pc:pc + cols]
 
     def fill_view(self, src):
@@ -155,7 +154,7 @@ def test_attention_guard_bands(ops, dtype, lq, lk):
     k = torch.randn((b1, b0, lk, d), generator=g).to(dtype).cuda()
     v = torch.randn((b1, b0, lk, d), generator=g).to(dtype).cuda()
     guard = Guarded(lq, d, dtype, pr=3, pc=32, batch=b1 * b0)
-    out = guard.view.view(b1, b0, lq, d) if False else guard.big.view(b1, b0, lq + 6, d + 64)[:, :, 3:3 + lq, 32:32 + d]
+    out = guard.big.view(b1, b0, lq + 6, d + 64)[:, :, 3:3 + lq, 32:32 + d]
     ops.attention(q, k, v, out, 0.125)
     torch.cuda.synchronize()
     torch.testing.assert_close(out.float(), _attn_ref(q, k, v, 0.125), atol=2e-2 if dtype == torch.bfloat16 else 4e-3, rtol=0)

@@ -435,6 +435,47 @@ def test_vit_large_width(cuda, dtype):
     assert y32.shape == (3, 197, 1024) and err < TOK_TOL[dtype]
 
 
+def test_edge_cases_k1_all_skipped_empty_and_long_caption(tiny):
+    """Edges the reference's loop handles explicitly: K == 1 (its `unsqueeze` special case, validate_stage2.py:247-250),
+    a dataset whose every row is skipped, an empty shard, B = 1 in the B x B surface, and a caption longer than the
+    512-row position table (the reference raises on the position_ids slice; here an IndexError before any launch)."""
+    from candidate_reranking_cir_amd import validate_stage2 as V
+    from oracle import cir_oracle as O
+    z, g, v, m2, m1, dt = tiny
+    imgs = H.fixture_images(z, range(14), v.image_size)
+    bank = V.extract_index_features(imgs, m2)
+    caps = [str(c) for c in z["cirr_caps"]][:3]
+    # K = 1 against the oracle
+    ds = V.RelativeValSet(ref_index=np.array([0, 5, 9]), cand_index=np.array([[3], [7], [1]]), labels=np.ones((3, 1), dtype=bool), captions=caps)
+    out = V.generate_val_predictions(m2, m1, ds, bank, query_batch=2).cpu()
+    assert out.shape == (3, 1)
+    sd2, sd1 = H.state_dicts(g, v, int(z["seed"]), str(z["profile"]))
+    with torch.no_grad():
+        feats = O.img_embed(sd2, imgs)
+        for q in range(3):
+            ids, mask = H.tokenize([caps[q]])
+            zt = O.stage1_z_t(sd1, feats[ds.ref_index[q]][None], ids, mask)
+            ref = O.img_txt_fusion_val(sd2, zt, feats[ds.cand_index[q]], ids, mask)
+            assert abs(out[q, 0].item() - ref[0].item()) < (3e-2 if dt == BF else 4e-3)
+    # every row skipped, no subset: nothing is launched, the matrix is the fill value
+    ds0 = V.RelativeValSet(ref_index=np.array([0, 1]), cand_index=np.array([[2, 3], [4, 5]]), labels=np.zeros((2, 2), dtype=bool), captions=caps[:2])
+    out0 = V.generate_val_predictions(m2, m1, ds0, bank)
+    assert out0.shape == (2, 2) and bool((out0 == np.float32(-99999.99)).all())
+    # an empty shard of a real dataset
+    oute = V.generate_val_predictions(m2, m1, ds, bank, rows=[])
+    assert oute.shape == (0, 1)
+    # B = 1 through the B x B surface == the K = 1 validation call
+    feats32 = m2.img_embed(imgs[:2].cuda())
+    zt = m1.img_txt_fusion(feats32[:1], None, caps[:1], train=False, return_raw=True)
+    bb = m2.img_txt_fusion(zt, feats32[1:2], caps[:1])
+    assert bb.shape == (1, 1) and torch.equal(bb[0], m2.img_txt_fusion_val(zt, feats32[1:2], caps[:1]))
+    # caption longer than the position table
+    from candidate_reranking_cir_amd.blip_stage2 import encode_text
+    long_ids = torch.full((1, g.max_position_embeddings + 1), 1000, dtype=torch.int64)
+    with pytest.raises(IndexError, match="position-embedding table"):
+        m1.z_t(feats32[:1], *encode_text(m1.tokenizer, {"input_ids": long_ids, "attention_mask": torch.ones_like(long_ids)}, "cuda"))
+
+
 def test_state_dict_roundtrip_and_cpu_refusal(cuda):
     from candidate_reranking_cir_amd.blip_stage2 import blip_stage2
     z = H.load("tiny_loop.npz")
