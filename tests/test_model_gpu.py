@@ -33,7 +33,7 @@ LOGIT_TOL = {                       # absolute, per fixture (logit sigma over ca
     "rank224": {BF: 8e-3, HF: 2e-3},            # [0.14]  (= tol_unit the fixture's label margins were cut with)
     "bxb224": {BF: 6e-3, HF: 1.5e-3},           # [0.135]
 }
-REL_TOL = {BF: 0.25, HF: 0.04}      # tiny geometry: |error| <= REL_TOL * sigma(reference logits of that row) [sigma 0.08..0.17]
+REL_TOL = {BF: 0.10, HF: 0.015}     # tiny geometry: |error| <= REL_TOL * sigma(reference logits of that row) [sigma 0.08..0.2; measured 0.039 / 0.006]
 
 
 @pytest.fixture(scope="module")
@@ -218,7 +218,7 @@ def test_unfolded_merge_matches_folded(cuda):
         outs.append(m2.img_txt_fusion_val(zt, feats[1:], cap).cpu().numpy())
     d = np.abs(outs[0] - outs[1]).max()
     print(f"\n[fold vs unfold] max|d| {d:.3e} (logit sigma {outs[1].std():.3f})")
-    assert d < 0.25 * outs[1].std()                       # the two schedules round Wm*W0 differently (bf16)
+    assert d < 0.05 * outs[1].std()                       # the two schedules round Wm*W0 differently (bf16); measured 0.016 sigma
 
 
 # ------------------------------------------------------------------------------------------------ reference geometry
