@@ -235,6 +235,9 @@ def main():
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--tokens", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--stream-dtype", default="auto", choices=["auto", "f16", "f32"],
+                    help="storage of the residual stream: auto (fp16 with bf16 operands, fp32 with fp16 operands), f16 or f32; "
+                         "sums are formed in fp32 and rounded once per sublayer either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="pixels", choices=["pixels", "bank"],
                     help="pixels: headline metric (every candidate encoded from pixels); bank: SURVEY 8(f)-1 real-dataset regime, "
@@ -272,8 +275,10 @@ def main():
     m2.load_state_dict(weights.synth_state_dict(weights.nlvr_param_spec(g, v), 0, "test"))
     m1 = BLIP_Retrieval(med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer())
     m1.load_state_dict(weights.synth_state_dict(weights.retrieval_param_spec(g, v), 1, "test"))
-    m2 = m2.to(dev).eval().set_compute_dtype(dt)
-    m1 = m1.to(dev).eval().set_compute_dtype(dt)
+    sdt = {"auto": None, "f16": torch.float16, "f32": torch.float32}[args.stream_dtype]
+    m2 = m2.to(dev).eval().set_compute_dtype(dt).set_stream_dtype(sdt)
+    m1 = m1.to(dev).eval().set_compute_dtype(dt).set_stream_dtype(sdt)
+    args.stream_dtype = "f16" if m2.stream_dtype == torch.float16 else "f32"        # what the run actually used
     m2.engines(); m1.engines()
 
     q_n, k, ns = args.queries, args.k, args.subset
@@ -397,7 +402,8 @@ def main():
         all_tf = gemm_flop / (gemm_ms * 1e-3) / 1e12
         traffic, traffic_src = None, None    # HBM bytes per launch of the dominant kernel: offline PMC passes of this same command
         tpath = os.path.join(ROOT, "profiles", "r2_pmc_summary.json")
-        if os.path.exists(tpath) and q_n == 16 and k == 100 and ns == 5 and args.skip_rate == 0 and args.image_size == 224 and args.dtype == "bf16":
+        if (os.path.exists(tpath) and q_n == 16 and k == 100 and ns == 5 and args.skip_rate == 0 and args.image_size == 224
+                and args.dtype == "bf16" and json.load(open(tpath)).get("residual_stream", "f32") == args.stream_dtype):
             tj = json.load(open(tpath))
             ent = tj.get("by_kernel", {}).get(dom_name)
             if ent:
@@ -411,7 +417,7 @@ def main():
                                    f"{args.tokens}-token captions, {q_n} queries x ({k} candidates + {ns} subset members) per step per GPU, "
                                    f"skip rate {args.skip_rate:g}, random-init weights",
                        "queries_per_step_per_gpu": q_n, "k": k, "subset": ns, "skip_rate": args.skip_rate, "image_size": args.image_size,
-                       "tokens": args.tokens, "triplets_per_step_rank0": n_cand,
+                       "tokens": args.tokens, "triplets_per_step_rank0": n_cand, "residual_stream": args.stream_dtype,
                        "parallelism": f"queries sharded over {world} GPU(s) (balanced_order blocks), all-gather of scores+indices"},
             "algorithmic_gflop_per_triplet": round(alg_per_triplet, 2),
             "executed_gflop_per_triplet": round((gemm_flop + attn_flop) / 1e9 / n_cand, 2),

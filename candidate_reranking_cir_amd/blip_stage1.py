@@ -47,8 +47,8 @@ class BLIP_Retrieval(_EngineHost):
                 raise RuntimeError("BLIP_Retrieval runs on an MI355X only: move the model to 'cuda' (no CPU path)")
             sd = self.state_dict()
             f32 = lambda k: sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()
-            self._engines = (MedEngine(sd, self.bert_geometry, self.compute_dtype, dev),
-                             VitEngine(sd, self.vit_geometry, self.compute_dtype, dev),
+            self._engines = (MedEngine(sd, self.bert_geometry, self.compute_dtype, dev, stream_dtype=self.stream_dtype),
+                             VitEngine(sd, self.vit_geometry, self.compute_dtype, dev, stream_dtype=self.stream_dtype),
                              dict(vw=f32("vision_proj.weight"), vb=f32("vision_proj.bias"), tw=f32("text_proj.weight"), tb=f32("text_proj.bias")))
         return self._engines
 

@@ -16,6 +16,8 @@
 //   * Workgroup -> tile mapping is XCD-aware (blocks that share an XCD's L2 walk neighbouring
 //     tiles of one row panel, so the A panel is fetched from HBM once per XCD).
 
+#include <type_traits>
+
 #include "gemm_args.hpp"
 
 namespace cir {
@@ -24,8 +26,11 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int kTileBytes = BM * BK * 2;  // 16 KiB per operand tile
 
 
-template <typename T, bool OUT_F32>
+// OUT: 0 = C in the operand type T, 1 = fp32 C, 2 = fp16 C (the 16-bit residual stream).  The residual is fp32 for
+// OUT 0 / 1 and fp16 for OUT 2 (element type of the stream it is part of); the sum is formed in fp32 and rounded once.
+template <typename T, int OUT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
+    constexpr bool OUT_F32 = OUT == 1;
     using X8 = typename Elem<T>::x8;
     __shared__ __attribute__((aligned(16))) char smem[4 * kTileBytes];  // [buf][A|W]
 
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) bias[q] = 0.f;
     }
-    const float* R = a.R ? a.R + z * a.sR : nullptr;
+    const bool has_res = a.R != nullptr;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int64_t m = m0 + wm * 64 + mi * 16 + r15;
@@ -145,12 +150,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) v[q] = fmaxf(v[q], 0.f);
         }
-        if (R != nullptr) {
-            const float4* rp = reinterpret_cast<const float4*>(R + m * a.ldr + nb);
+        if (has_res) {
+            if constexpr (OUT == 2) {
+                typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+                const h8* rp = reinterpret_cast<const h8*>(reinterpret_cast<const _Float16*>(a.R) + z * a.sR + m * a.ldr + nb);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 r4 = rp[q];
-                v[q * 4 + 0] += r4.x; v[q * 4 + 1] += r4.y; v[q * 4 + 2] += r4.z; v[q * 4 + 3] += r4.w;
+                for (int q = 0; q < 2; ++q) {
+                    const h8 r8 = rp[q];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[q * 8 + e] += (float)r8[e];
+                }
+            } else {
+                const float4* rp = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.R) + z * a.sR + m * a.ldr + nb);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 r4 = rp[q];
+                    v[q * 4 + 0] += r4.x; v[q * 4 + 1] += r4.y; v[q * 4 + 2] += r4.z; v[q * 4 + 3] += r4.w;
+                }
             }
         }
         if constexpr (OUT_F32) {
@@ -158,14 +174,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) cp[q] = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
         } else {
-            u32x4* cp = reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.C) + z * a.sC + m * a.ldc + nb);
+            using CT = typename std::conditional<OUT == 2, _Float16, T>::type;
+            u32x4* cp = reinterpret_cast<u32x4*>(reinterpret_cast<CT*>(a.C) + z * a.sC + m * a.ldc + nb);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 u32x4 o;
-                o.x = pack2<T>(v[q * 8 + 0], v[q * 8 + 1]);
-                o.y = pack2<T>(v[q * 8 + 2], v[q * 8 + 3]);
-                o.z = pack2<T>(v[q * 8 + 4], v[q * 8 + 5]);
-                o.w = pack2<T>(v[q * 8 + 6], v[q * 8 + 7]);
+                o.x = pack2<CT>(v[q * 8 + 0], v[q * 8 + 1]);
+                o.y = pack2<CT>(v[q * 8 + 2], v[q * 8 + 3]);
+                o.z = pack2<CT>(v[q * 8 + 4], v[q * 8 + 5]);
+                o.w = pack2<CT>(v[q * 8 + 6], v[q * 8 + 7]);
                 cp[q] = o;
             }
         }
@@ -175,22 +192,25 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
 }  // namespace cir
 
 extern "C" int cir_gemm_bias_act(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW,
-                                 const float* bias, int64_t strideBias, const float* residual, int64_t ldr, int64_t strideR,
-                                 void* C, int64_t ldc, int64_t strideC, int64_t M, int N, int K, int batch, int act,
-                                 int in_dtype, int out_dtype, void* stream) {
+                                 const float* bias, int64_t strideBias, const void* residual, int res_dtype, int64_t ldr,
+                                 int64_t strideR, void* C, int64_t ldc, int64_t strideC, int64_t M, int N, int K, int batch,
+                                 int act, int in_dtype, int out_dtype, void* stream) {
     using namespace cir;
     CIR_CHECK_PTR(A); CIR_CHECK_PTR(W); CIR_CHECK_PTR(C);
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return CIR_EINVAL;
     if (K % BK != 0 || N % 16 != 0) return CIR_ESHAPE;
     if (in_dtype != CIR_BF16 && in_dtype != CIR_F16) return CIR_EDTYPE;
-    if (out_dtype != in_dtype && out_dtype != CIR_F32) return CIR_EDTYPE;
+    if (out_dtype != in_dtype && out_dtype != CIR_F32 && out_dtype != CIR_F16) return CIR_EDTYPE;
     if (act < CIR_ACT_NONE || act > CIR_ACT_RELU) return CIR_EINVAL;
+    // residual: fp32 (with any C) or fp16 (only as part of an fp16 C: the 16-bit residual stream)
+    if (residual && res_dtype != CIR_F32 && !(res_dtype == CIR_F16 && out_dtype == CIR_F16)) return CIR_EDTYPE;
     const int64_t out_elems_per16 = out_dtype == CIR_F32 ? 4 : 8;
     if (!cir_aligned16(A) || !cir_aligned16(W) || !cir_aligned16(C) || lda % 8 || ldw % 8 || strideA % 8 || strideW % 8 ||
         ldc % out_elems_per16 || strideC % out_elems_per16)
         return CIR_EALIGN;
     if (bias && (!cir_aligned16(bias) || strideBias % 4)) return CIR_EALIGN;
-    if (residual && (!cir_aligned16(residual) || ldr % 4 || strideR % 4)) return CIR_EALIGN;
+    const int64_t res_elems_per16 = res_dtype == CIR_F32 ? 4 : 8;
+    if (residual && (!cir_aligned16(residual) || ldr % res_elems_per16 || strideR % res_elems_per16)) return CIR_EALIGN;
 
     GemmArgs a;
     a.A = A; a.lda = lda; a.sA = strideA;
@@ -204,26 +224,29 @@ extern "C" int cir_gemm_bias_act(const void* A, int64_t lda, int64_t strideA, co
     const int64_t nblk = (int64_t)a.tiles_m * a.tiles_n * batch;
     if (nblk > 0x7fffffff) return CIR_ESHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const bool f32out = out_dtype == CIR_F32;
+    // epilogue kind: 1 = fp32 C (fp32 residual), 2 = fp16 stream C with an fp16 residual or from bf16 operands,
+    // 0 = C in the operand type (an fp32 residual is then served by the 128 x 128 kernel only)
+    const bool stream16 = out_dtype == CIR_F16 && (in_dtype != CIR_F16 || (residual && res_dtype == CIR_F16));
+    const int out_kind = out_dtype == CIR_F32 ? 1 : (stream16 ? 2 : 0);
     // Tile choice: the 256x256 8-phase kernel needs about a full wave of workgroups (256 CUs) to pay;
     // small problems keep the 128x128 kernel (more, smaller tiles).  cir_set_tuning(CIR_TUNE_GEMM_TILE, 128|256) forces one.
     const int64_t nblk256 = ((M + 255) / 256) * ((N + 255) / 256) * batch;
-    // (the 256 kernel adds the residual in its fp32 row layout: linear fp32-out epilogues only; 32-bit operand offsets)
+    // (the 256 kernel adds the residual in the row layout of its fp32-layout epilogues: linear epilogues only; 32-bit operand offsets)
     bool use256 = N >= 256 && nblk256 >= 192;
-    const bool can256 = !(residual && (act != CIR_ACT_NONE || !f32out)) && K % 128 == 0 && lda < (1 << 21) && ldw < (1 << 21);   // K-tile pairs; tile-relative 32-bit offsets
+    const bool can256 = !(residual && (act != CIR_ACT_NONE || out_kind == 0)) && K % 128 == 0 && lda < (1 << 21) && ldw < (1 << 21);   // K-tile pairs; tile-relative 32-bit offsets
     if (g_tune[CIR_TUNE_GEMM_TILE] == 128) use256 = false;
     else if (g_tune[CIR_TUNE_GEMM_TILE] == 256) use256 = true;
     if (use256 && can256) {
-        launch_gemm256(a, in_dtype, f32out, s);
+        launch_gemm256(a, in_dtype, out_kind, s);
         CIR_LAUNCH_RESULT();
     }
     dim3 grid((unsigned)nblk), block(256);
-    if (in_dtype == CIR_BF16) {
-        if (f32out) hipLaunchKernelGGL((gemm_kernel<__bf16, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm_kernel<__bf16, false>), grid, block, 0, s, a);
-    } else {
-        if (f32out) hipLaunchKernelGGL((gemm_kernel<_Float16, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm_kernel<_Float16, false>), grid, block, 0, s, a);
-    }
+#define CIR_LAUNCH128(TT) \
+    do { if (out_kind == 1) hipLaunchKernelGGL((gemm_kernel<TT, 1>), grid, block, 0, s, a); \
+         else if (out_kind == 2) hipLaunchKernelGGL((gemm_kernel<TT, 2>), grid, block, 0, s, a); \
+         else hipLaunchKernelGGL((gemm_kernel<TT, 0>), grid, block, 0, s, a); } while (0)
+    if (in_dtype == CIR_BF16) CIR_LAUNCH128(__bf16);
+    else CIR_LAUNCH128(_Float16);
+#undef CIR_LAUNCH128
     CIR_LAUNCH_RESULT();
 }

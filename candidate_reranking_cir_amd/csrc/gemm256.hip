@@ -52,8 +52,12 @@ constexpr int T256 = 256;
 constexpr int kHalf = 16384;       // one half-tile: 128 rows x 64 k x 2 B
 constexpr int kDbuf = 4 * kHalf;   // A0 A1 B0 B1
 
-template <typename T, bool OUT_F32, bool HAS_RES>
+// ST = element type of C and R when the fp32-layout epilogue is used (OUT_F32): float (the fp32 residual stream) or
+// _Float16 (the 16-bit residual stream: acc + bias (+ act) + residual are summed in fp32 and rounded ONCE, on the store).
+template <typename T, bool OUT_F32, bool HAS_RES, typename ST = float>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
+    constexpr bool S16 = !__is_same(ST, float);
+    static_assert(!S16 || OUT_F32, "a 16-bit stream output uses the fp32-layout epilogue");
     using X8 = typename Elem<T>::x8;
     __shared__ __attribute__((aligned(16))) char smem[2 * kDbuf + 8 * 1024 + 4 * 4096];   // two K-tiles + a 1-KiB bias slot per wave + epilogue staging for waves 4-7
 
@@ -336,15 +340,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         // fp32 residual, fetched in the SAME row-contiguous layout the stores use (1 KiB = 4 rows x 256 B per
         // instruction, whole lines) RD passes ahead; loading it in the accumulator layout (16 rows x 32-byte pieces
         // per instruction) costs ~8 us of address processing per tile.
-        constexpr int RD = 2;                                   // residual passes in flight
-        [[maybe_unused]] float4 rres[RD][4];
+        constexpr int RD = S16 ? 4 : 2;                         // residual passes in flight (same registers: 16-bit rows are half as wide)
+        using RV = typename RowVec<ST>::type;                   // four elements of a row: float4 / four halves in a u32x2
+        [[maybe_unused]] RV rres[RD][4];
 #define LOAD_RES(PS)                                                                                                         \
         if constexpr (HAS_RES) {                                                                                             \
             const int prow_ = ((PS) / (NPASS / 2)) * 128 + wr * 64 + ((PS) % (NPASS / 2)) * ROWS;                            \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                  \
                 const int64_t m = cm0 + prow_ + j * (64 / LPR) + rr;                                                         \
                 rres[(PS) % RD][j] = (full || (m < a.M && ncol + 4 <= a.N))                                                  \
-                    ? *reinterpret_cast<const float4*>(a.R + cz * a.sR + m * a.ldr + ncol) : make_float4(0.f, 0.f, 0.f, 0.f); \
+                    ? *reinterpret_cast<const RV*>(reinterpret_cast<const ST*>(a.R) + cz * a.sR + m * a.ldr + ncol) : RowVec<ST>::zero(); \
             }                                                                                                                \
         }
         _Pragma("unroll") for (int p = 0; p < RD; ++p) { LOAD_RES(p) }
@@ -431,8 +436,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         f32x4 o = __builtin_bit_cast(f32x4, dd[j]);
-                        const float4 r = rres[ps % RD][j];
-                        o += f32x4{r.x, r.y, r.z, r.w};
+                        o += RowVec<ST>::to_f32(rres[ps % RD][j]);
                         dd[j] = __builtin_bit_cast(u32x4, o);
                     }
                 }
@@ -440,7 +444,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                 for (int j = 0; j < 4; ++j) {
                     const int64_t m = cm0 + prow + j * (64 / LPR) + rr;
                     if (full || (m < a.M && ncol + (OUT_F32 ? 4 : 8) <= a.N)) {
-                        if constexpr (OUT_F32) *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(a.C) + cz * a.sC + m * a.ldc + ncol) = dd[j];
+                        if constexpr (S16) {            // the one rounding of the 16-bit stream: 4 elements = 8 bytes per lane, whole lines per instruction
+                            const f32x4 o = __builtin_bit_cast(f32x4, dd[j]);
+                            u32x2 pk;
+                            pk.x = pack2<ST>(o[0], o[1]);
+                            pk.y = pack2<ST>(o[2], o[3]);
+                            *reinterpret_cast<u32x2*>(reinterpret_cast<ST*>(a.C) + cz * a.sC + m * a.ldc + ncol) = pk;
+                        } else if constexpr (OUT_F32) *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(a.C) + cz * a.sC + m * a.ldc + ncol) = dd[j];
                         else *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.C) + cz * a.sC + m * a.ldc + ncol) = dd[j];
                     }
                 }
@@ -499,7 +509,8 @@ static int persistent_grid() {
     return cus;
 }
 
-void launch_gemm256(const GemmArgs& a_in, int in_dtype, bool f32out, hipStream_t s) {
+void launch_gemm256(const GemmArgs& a_in, int in_dtype, int out_kind, hipStream_t s) {
+    // out_kind: 0 = 16-bit in the operand type (fast 4-pass epilogue), 1 = fp32 C (and R), 2 = fp16 stream C (and R)
     GemmArgs a = a_in;
     a.tiles_m = (int)((a.M + T256 - 1) / T256);
     a.tiles_n = (a.N + T256 - 1) / T256;
@@ -520,12 +531,14 @@ void launch_gemm256(const GemmArgs& a_in, int in_dtype, bool f32out, hipStream_t
     const int64_t g = persistent_grid();
     dim3 grid((unsigned)(ntiles < g ? ntiles : g)), block(512);
     const bool res = a.R != nullptr;
-#define CIR_LAUNCH256(TT, F32, RES) hipLaunchKernelGGL((gemm256_kernel<TT, F32, RES>), grid, block, 0, s, a)
+#define CIR_LAUNCH256(...) hipLaunchKernelGGL((gemm256_kernel<__VA_ARGS__>), grid, block, 0, s, a)
     if (in_dtype == CIR_BF16) {
-        if (f32out) { if (res) CIR_LAUNCH256(__bf16, true, true); else CIR_LAUNCH256(__bf16, true, false); }
+        if (out_kind == 1) { if (res) CIR_LAUNCH256(__bf16, true, true); else CIR_LAUNCH256(__bf16, true, false); }
+        else if (out_kind == 2) { if (res) CIR_LAUNCH256(__bf16, true, true, _Float16); else CIR_LAUNCH256(__bf16, true, false, _Float16); }
         else CIR_LAUNCH256(__bf16, false, false);
     } else {
-        if (f32out) { if (res) CIR_LAUNCH256(_Float16, true, true); else CIR_LAUNCH256(_Float16, true, false); }
+        if (out_kind == 1) { if (res) CIR_LAUNCH256(_Float16, true, true); else CIR_LAUNCH256(_Float16, true, false); }
+        else if (out_kind == 2) { if (res) CIR_LAUNCH256(_Float16, true, true, _Float16); else CIR_LAUNCH256(_Float16, true, false, _Float16); }
         else CIR_LAUNCH256(_Float16, false, false);
     }
 #undef CIR_LAUNCH256

@@ -43,7 +43,9 @@ __global__ __launch_bounds__(256) void patchify_kernel(const TI* img, TO* out, i
 }
 
 // ---- x[b][0] = cls + pos[0]; x[b][1+i] = proj[b*P+i] + pos[1+i] (float4 per thread) ----------------------
-__global__ __launch_bounds__(256) void vit_assemble_kernel(const float* proj, const float* cls, const float* pos, float* x,
+// S = element type of proj and x: float (fp32 residual stream) or _Float16 (16-bit stream); cls / pos are fp32 parameters
+template <typename S>
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const S* proj, const float* cls, const float* pos, S* x,
                                                            int B, int P, int D) {
     const int d4 = D / 4;
     const int64_t total = (int64_t)B * (P + 1) * d4;
@@ -54,9 +56,24 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(const float* proj, co
     const int tok = (int)(row % (P + 1));
     const int64_t b = row / (P + 1);
     const float4 pe = reinterpret_cast<const float4*>(pos + (int64_t)tok * D)[c];
-    const float4 v = tok == 0 ? reinterpret_cast<const float4*>(cls)[c]
-                              : reinterpret_cast<const float4*>(proj + (b * P + tok - 1) * D)[c];
-    reinterpret_cast<float4*>(x + row * D)[c] = make_float4(v.x + pe.x, v.y + pe.y, v.z + pe.z, v.w + pe.w);
+    float4 v;
+    if (tok == 0) {
+        v = reinterpret_cast<const float4*>(cls)[c];
+    } else if constexpr (__is_same(S, float)) {
+        v = reinterpret_cast<const float4*>(proj + (b * P + tok - 1) * D)[c];
+    } else {
+        const f16x4 h = reinterpret_cast<const f16x4*>(proj + (b * P + tok - 1) * D)[c];
+        v = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    }
+    const float4 o = make_float4(v.x + pe.x, v.y + pe.y, v.z + pe.z, v.w + pe.w);
+    if constexpr (__is_same(S, float)) {
+        reinterpret_cast<float4*>(x + row * D)[c] = o;
+    } else {
+        u32x2 pk;
+        pk.x = pack2<_Float16>(o.x, o.y);
+        pk.y = pack2<_Float16>(o.z, o.w);
+        reinterpret_cast<u32x2*>(x + row * D)[c] = pk;
+    }
 }
 
 // ---- y[m][n] = x[m] . W[n] + bias[n], N <= 8, one wave per row ---------------------------------------------
@@ -266,15 +283,20 @@ extern "C" int cir_patchify(const void* image, int img_dtype, void* patches, int
     CIR_LAUNCH_RESULT();
 }
 
-extern "C" int cir_vit_assemble(const float* proj, const float* cls, const float* pos, float* x, int B, int P, int D,
+extern "C" int cir_vit_assemble(const void* proj, const float* cls, const float* pos, void* x, int stream_dtype, int B, int P, int D,
                                 void* stream) {
     CIR_CHECK_PTR(proj); CIR_CHECK_PTR(cls); CIR_CHECK_PTR(pos); CIR_CHECK_PTR(x);
     if (B <= 0 || P <= 0 || D <= 0) return CIR_EINVAL;
-    if (D % 4) return CIR_ESHAPE;
+    if (D % 8) return CIR_ESHAPE;
+    if (stream_dtype != CIR_F32 && stream_dtype != CIR_F16) return CIR_EDTYPE;
     if (!cir_aligned16(proj) || !cir_aligned16(cls) || !cir_aligned16(pos) || !cir_aligned16(x)) return CIR_EALIGN;
     const int64_t total = (int64_t)B * (P + 1) * (D / 4);
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
-    hipLaunchKernelGGL(cir::vit_assemble_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), proj, cls, pos, x, B, P, D);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (stream_dtype == CIR_F32)
+        hipLaunchKernelGGL(cir::vit_assemble_kernel<float>, grid, block, 0, s, reinterpret_cast<const float*>(proj), cls, pos, reinterpret_cast<float*>(x), B, P, D);
+    else
+        hipLaunchKernelGGL(cir::vit_assemble_kernel<_Float16>, grid, block, 0, s, reinterpret_cast<const _Float16*>(proj), cls, pos, reinterpret_cast<_Float16*>(x), B, P, D);
     CIR_LAUNCH_RESULT();
 }
 

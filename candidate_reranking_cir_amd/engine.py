@@ -3,8 +3,10 @@
 Each engine packs a reference-layout fp32 state dict once (16-bit weight matrices, fused QKV /
 K|V concatenations, folded merge weights; fp32 biases and LayerNorm affines) and then issues a
 fixed sequence of libcirrank launches per forward.  Precision plan: GEMM operands and attention
-tiles are 16-bit (bf16 or fp16), every accumulation, softmax, LayerNorm and the residual stream
-are fp32.
+tiles are 16-bit (bf16 or fp16); every accumulation, the softmax and the LayerNorm statistics are
+fp32; the RESIDUAL STREAM (x + sublayer(x), and the LayerNorm outputs that feed one) is stored in
+`stream_dtype`: fp16 by default (sum formed in fp32, rounded once per sublayer to 11 bits - an eighth
+of the bf16 operand rounding that every GEMM input gets anyway) or fp32.
 
 Reference arithmetic being scheduled (cited per method): vit.py:180-194, med.py:348-398 / 685-821,
 nlvr_encoder.py:414-476 / 777-908, blip_stage2.py:101-136.
@@ -29,6 +31,21 @@ def _f32(t: torch.Tensor, device) -> torch.Tensor:
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+def _auto_stream(dtype: torch.dtype, stream_dtype: Optional[torch.dtype]) -> torch.dtype:
+    """Residual-stream storage: explicit, or fp16 with bf16 operands / fp32 with fp16 operands."""
+    if stream_dtype is not None:
+        return stream_dtype
+    return torch.float16 if dtype == torch.bfloat16 else torch.float32
+
+
+def _ln(x, gamma, beta, eps, dt, sdt, residual=None, need_stream=True):
+    """LayerNorm -> (stream copy in `sdt` or None, operand copy in `dt`).  One tensor serves as both when dt == sdt."""
+    if dt == sdt and need_stream:
+        y, _ = ops.layernorm(x, gamma, beta, eps, residual=residual, want32=True, dtype16=None, stream_dtype=sdt)
+        return y, y
+    return ops.layernorm(x, gamma, beta, eps, residual=residual, want32=need_stream, dtype16=dt, stream_dtype=sdt)
+
+
 def additive_self_mask(attention_mask: torch.Tensor) -> torch.Tensor:
     """(R, L) ones/zeros -> fp32 additive key mask (1 - m) * -10000 (nlvr_encoder.py:773-774)."""
     return ((1.0 - attention_mask.to(torch.float32)) * -10000.0).contiguous()
@@ -43,9 +60,10 @@ def additive_encoder_mask(attention_mask: torch.Tensor) -> torch.Tensor:
 class VitEngine:
     """ViT-B/16 patch encoder (vit.py:113-194 + timm PatchEmbed) as 7 launches per block."""
 
-    def __init__(self, sd: SD, geo: VitGeometry, dtype: torch.dtype, device, prefix: str = "visual_encoder."):
+    def __init__(self, sd: SD, geo: VitGeometry, dtype: torch.dtype, device, prefix: str = "visual_encoder.",
+                 stream_dtype: Optional[torch.dtype] = None):
         geo.validate()
-        self.geo, self.dtype, self.device = geo, dtype, device
+        self.geo, self.dtype, self.device, self.stream_dtype = geo, dtype, device, _auto_stream(dtype, stream_dtype)
         d = geo.width
         p = prefix
         self.w_patch = _w16(sd[p + "patch_embed.proj.weight"].reshape(d, -1), dtype, device)
@@ -78,20 +96,21 @@ class VitEngine:
         if image.dtype not in (torch.float32, dt):
             image = image.float()
         scale = 64 ** -0.5                                                     # vit.py:50
+        sdt = self.stream_dtype
         patches = ops.patchify(image, geo.patch_size, dt)                      # PatchEmbed im2col
-        proj = ops.gemm(patches, self.w_patch, self.b_patch, out_dtype=torch.float32)
-        x = ops.vit_assemble(proj, self.cls, self.pos, bsz).view(bsz * n, d)   # vit.py:184-187
+        proj = ops.gemm(patches, self.w_patch, self.b_patch, out_dtype=sdt)
+        x = ops.vit_assemble(proj, self.cls, self.pos, bsz).view(bsz * n, d)   # vit.py:184-187 (residual stream, sdt)
         ctx = torch.empty((bsz, n, d), dtype=dt, device=x.device)
         for blk in self.blocks:
-            _, xb = ops.layernorm(x, blk["g1"], blk["b1"], geo.layer_norm_eps, want32=False, dtype16=dt)
+            _, xb = _ln(x, blk["g1"], blk["b1"], geo.layer_norm_eps, dt, sdt, need_stream=False)
             qkv = ops.gemm(xb, blk["wqkv"], blk["bqkv"]).view(bsz, n, 3, d)    # vit.py:72
             ops.attention(qkv[:, :, 0].unsqueeze(1), qkv[:, :, 1].unsqueeze(1), qkv[:, :, 2].unsqueeze(1),
                           ctx.unsqueeze(1), scale)                             # vit.py:73-83
-            ops.gemm(ctx.view(bsz * n, d), blk["wo"], blk["bo"], residual=x, out_dtype=torch.float32, out=x)  # :84,:108
-            _, xb = ops.layernorm(x, blk["g2"], blk["b2"], geo.layer_norm_eps, want32=False, dtype16=dt)
+            ops.gemm(ctx.view(bsz * n, d), blk["wo"], blk["bo"], residual=x, out_dtype=sdt, out=x)  # :84,:108
+            _, xb = _ln(x, blk["g2"], blk["b2"], geo.layer_norm_eps, dt, sdt, need_stream=False)
             f = ops.gemm(xb, blk["w1"], blk["c1"], act=ops.ACT_GELU)           # vit.py:36-37
-            ops.gemm(f, blk["w2"], blk["c2"], residual=x, out_dtype=torch.float32, out=x)  # vit.py:39, :109
-        y32, y16 = ops.layernorm(x, self.gf, self.bf, geo.layer_norm_eps, want32=want32, dtype16=dt)  # vit.py:192
+            ops.gemm(f, blk["w2"], blk["c2"], residual=x, out_dtype=sdt, out=x)  # vit.py:39, :109
+        y32, y16 = ops.layernorm(x, self.gf, self.bf, geo.layer_norm_eps, want32=want32, dtype16=dt, stream_dtype=torch.float32)  # vit.py:192
         return (y32.view(bsz, n, d) if want32 else None), y16.view(bsz, n, d)
 
 
@@ -103,9 +122,10 @@ def _cat(sd: SD, keys, suffix: str) -> torch.Tensor:
 class MedEngine:
     """Stage-I BERT/MED text encoder with image cross-attention (med.py:348-398, 685-821) -> z_t."""
 
-    def __init__(self, sd: SD, geo: BertGeometry, dtype: torch.dtype, device, prefix: str = "text_encoder."):
+    def __init__(self, sd: SD, geo: BertGeometry, dtype: torch.dtype, device, prefix: str = "text_encoder.",
+                 stream_dtype: Optional[torch.dtype] = None):
         geo.validate()
-        self.geo, self.dtype, self.device = geo, dtype, device
+        self.geo, self.dtype, self.device, self.stream_dtype = geo, dtype, device, _auto_stream(dtype, stream_dtype)
         e = prefix + "embeddings."
         self.word, self.posemb = _f32(sd[e + "word_embeddings.weight"], device), _f32(sd[e + "position_embeddings.weight"], device)
         self.ge, self.be = _f32(sd[e + "LayerNorm.weight"], device), _f32(sd[e + "LayerNorm.bias"], device)
@@ -130,30 +150,31 @@ class MedEngine:
     def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, enc16: torch.Tensor,
                 enc_mask: Optional[torch.Tensor] = None):
         """ids/mask (Q, L), image tokens (Q, N, Dv) 16-bit -> last hidden state (Q, L, D): (fp32, 16-bit)."""
-        geo, dt = self.geo, self.dtype
+        geo, dt, sdt = self.geo, self.dtype, self.stream_dtype
         q_n, l = input_ids.shape
         d, n = geo.hidden_size, enc16.shape[1]
         r = q_n * l
         eps, scale = geo.layer_norm_eps, 64 ** -0.5
-        h32, h16 = ops.embed_layernorm(input_ids, self.word, self.posemb, self.ge, self.be, eps, dt)  # med.py:87-110
-        h32, h16 = h32.view(r, d), h16.view(r, d)
+        hs, h16 = ops.embed_layernorm(input_ids, self.word, self.posemb, self.ge, self.be, eps, dt, stream_dtype=sdt)  # med.py:87-110
+        hs, h16 = hs.view(r, d), h16.view(r, d)
         smask = additive_self_mask(attention_mask).view(q_n, 1, l)
         emask = additive_encoder_mask(enc_mask).view(q_n, 1, n) if enc_mask is not None else None
         enc2 = enc16.reshape(q_n * n, enc16.shape[2])
-        ctx = torch.empty((q_n, 1, l, d), dtype=dt, device=h32.device)
+        ctx = torch.empty((q_n, 1, l, d), dtype=dt, device=hs.device)
         for ly in self.layers:
             qkv = ops.gemm(h16, ly["wqkv"], ly["bqkv"]).view(q_n, 1, l, 3 * d)
             ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], ctx, scale, smask)       # med.py:158-240
-            t = ops.gemm(ctx.view(r, d), ly["wo"], ly["bo"], residual=h32, out_dtype=torch.float32)
-            a32, a16 = ops.layernorm(t, ly["g1"], ly["b1"], eps, dtype16=dt)                           # med.py:250-253
+            t = ops.gemm(ctx.view(r, d), ly["wo"], ly["bo"], residual=hs, out_dtype=sdt)
+            a_s, a16 = _ln(t, ly["g1"], ly["b1"], eps, dt, sdt)                                        # med.py:250-253
             qc = ops.gemm(a16, ly["wq"], ly["bq"]).view(q_n, 1, l, d)
             kv = ops.gemm(enc2, ly["wkv"], ly["bkv"]).view(q_n, 1, n, 2 * d)
             ops.attention(qc, kv[..., :d], kv[..., d:], ctx, scale, emask)                             # med.py:361-376
-            t = ops.gemm(ctx.view(r, d), ly["wco"], ly["bco"], residual=a32, out_dtype=torch.float32)
-            c32, c16 = ops.layernorm(t, ly["g2"], ly["b2"], eps, dtype16=dt)
+            t = ops.gemm(ctx.view(r, d), ly["wco"], ly["bco"], residual=a_s, out_dtype=sdt)
+            c_s, c16 = _ln(t, ly["g2"], ly["b2"], eps, dt, sdt)
             f = ops.gemm(c16, ly["w1"], ly["c1"], act=ops.ACT_GELU)                                    # med.py:319-322
-            t = ops.gemm(f, ly["w2"], ly["c2"], residual=c32, out_dtype=torch.float32)
-            h32, h16 = ops.layernorm(t, ly["g3"], ly["b3"], eps, dtype16=dt)                           # med.py:331-335
+            t = ops.gemm(f, ly["w2"], ly["c2"], residual=c_s, out_dtype=sdt)
+            hs, h16 = _ln(t, ly["g3"], ly["b3"], eps, dt, sdt)                                         # med.py:331-335
+        h32 = hs if hs.dtype == torch.float32 else ops.gather_rows(hs, None, torch.float32)            # API: fp32 last_hidden_state
         return h32.view(q_n, l, d), h16.view(q_n, l, d)
 
 
@@ -171,9 +192,10 @@ class NlvrEngine:
     Layer 0's self-attention block is candidate-independent and runs once per QUERY.
     """
 
-    def __init__(self, sd: SD, geo: BertGeometry, dtype: torch.dtype, device, prefix: str = "text_encoder.", fold_merge: bool = True):
+    def __init__(self, sd: SD, geo: BertGeometry, dtype: torch.dtype, device, prefix: str = "text_encoder.", fold_merge: bool = True,
+                 stream_dtype: Optional[torch.dtype] = None):
         geo.validate()
-        self.geo, self.dtype, self.device, self.fold_merge = geo, dtype, device, fold_merge
+        self.geo, self.dtype, self.device, self.fold_merge, self.stream_dtype = geo, dtype, device, fold_merge, _auto_stream(dtype, stream_dtype)
         self.trim_last = True   # last layer: per-token work on the CLS rows only (results identical for the rows that are used)
         self.kv_chunk = 0       # candidates per K|V + cross-attention chunk (0 = all at once; attribute, for A/B runs)
         e = prefix + "embeddings."
@@ -231,13 +253,13 @@ class NlvrEngine:
     # ---------------------------------------------------------------------------------------------
     def _self_block(self, ly, h32, h16, items, l, smask):
         """Twin self-attention + LayerNormA/B on (2, items*L, D) hidden states (nlvr_encoder.py:427-433, 262-264)."""
-        d, dt, eps = self.geo.hidden_size, self.dtype, self.geo.layer_norm_eps
+        d, dt, sdt, eps = self.geo.hidden_size, self.dtype, self.stream_dtype, self.geo.layer_norm_eps
         r = items * l
         qkv = ops.gemm(h16, ly["wqkv"], ly["bqkv"]).view(2, items, l, 3 * d)
         ctx = torch.empty((2, items, l, d), dtype=dt, device=h32.device)
         ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], ctx, 64 ** -0.5, smask.unsqueeze(0).expand(2, items, l))
-        t = ops.gemm(ctx.view(2, r, d), ly["wo"], ly["bo"], residual=h32, out_dtype=torch.float32)
-        return ops.layernorm(t, ly["g1"], ly["b1"], eps, dtype16=dt)
+        t = ops.gemm(ctx.view(2, r, d), ly["wo"], ly["bo"], residual=h32, out_dtype=sdt)
+        return _ln(t, ly["g1"], ly["b1"], eps, dt, sdt)
 
     @torch.no_grad()
     def build_kv_bank(self, bank16: torch.Tensor, chunk: int = 512) -> list:
@@ -263,7 +285,7 @@ class NlvrEngine:
         query each candidate belongs to -> logits (T, 2) fp32 (column 0 is the score).
         With `kv_bank` (from build_kv_bank) and `cand_rows` (T,) int64 bank rows, the per-candidate K|V GEMM is
         skipped and cross-attention reads K/V straight from the bank (cand16 is not used)."""
-        geo, dt = self.geo, self.dtype
+        geo, dt, sdt = self.geo, self.dtype, self.stream_dtype
         q_n, l = input_ids.shape
         if kv_bank is not None:
             cand_rows = cand_rows.to(torch.int64).contiguous()
@@ -276,13 +298,14 @@ class NlvrEngine:
         if tuple(z_t32.shape) != tuple(emb32.shape):
             raise AssertionError("left and right inputs shall be the same shape")                         # nlvr_encoder.py:891
         hq32 = torch.stack([z_t32.reshape(q_n * l, d).float(), emb32.view(q_n * l, d)])                   # (2, Q*L, D): [z_t, emb] :892
-        hq16 = ops.gather_rows(hq32.view(2 * q_n * l, d), None, dt).view(2, q_n * l, d)
+        hq_s = hq32 if sdt == torch.float32 else ops.gather_rows(hq32.view(2 * q_n * l, d), None, sdt).view(2, q_n * l, d)
+        hq16 = hq_s if dt == sdt else ops.gather_rows(hq32.view(2 * q_n * l, d), None, dt).view(2, q_n * l, d)
         smask_q = additive_self_mask(attention_mask)                                                     # (Q, L)
         # layer 0 self-attention block depends only on (z_t, caption): once per query, then expand to candidates
-        a32q, _ = self._self_block(self.layers[0], hq32, hq16, q_n, l, smask_q)
+        a_sq, a16q = self._self_block(self.layers[0], hq_s, hq16, q_n, l, smask_q)
         both = torch.cat([qidx, qidx + q_n])                                                              # rows of (2*Q, L*D)
-        a32 = ops.gather_rows(a32q.view(2 * q_n, l * d), both, torch.float32).view(2, r, d)
-        a16 = ops.gather_rows(a32q.view(2 * q_n, l * d), both, dt).view(2, r, d)
+        a32 = ops.gather_rows(a_sq.view(2 * q_n, l * d), both, sdt).view(2, r, d)
+        a16 = a32 if dt == sdt else ops.gather_rows(a16q.view(2 * q_n, l * d), both, dt).view(2, r, d)
         smask = ops.gather_rows(_pad8(smask_q), qidx, torch.float32)[:, :l]                             # (T, L) view
         emask = additive_encoder_mask(cand_mask).view(t_n, 1, n).expand(t_n, 2, n) if cand_mask is not None else None
         cand2 = cand16.reshape(t_n * n, cand16.shape[2]) if kv_bank is None else None
@@ -299,8 +322,8 @@ class NlvrEngine:
                 qkv = ops.gemm(h16, ly["wqkv"], ly["bqkv"]).view(2, t_n, l, 3 * d)
                 ctx = torch.empty((2, t_n, 1, d), dtype=dt, device=h32.device)
                 ops.attention(qkv[:, :, :1, :d], qkv[..., d:2 * d], qkv[..., 2 * d:], ctx, scale, smask.unsqueeze(0).expand(2, t_n, l))
-                t = ops.gemm(ctx.view(2, t_n, d), ly["wo"], ly["bo"], residual=h32.view(2, t_n, l, d)[:, :, 0, :], out_dtype=torch.float32)
-                a32, a16 = ops.layernorm(t, ly["g1"], ly["b1"], eps, dtype16=dt)
+                t = ops.gemm(ctx.view(2, t_n, d), ly["wo"], ly["bo"], residual=h32.view(2, t_n, l, d)[:, :, 0, :], out_dtype=sdt)
+                a32, a16 = _ln(t, ly["g1"], ly["b1"], eps, dt, sdt)
             elif i > 0:
                 a32, a16 = self._self_block(ly, h32, h16, t_n, l, smask)
             qc = ops.gemm(a16, ly["wq"], ly["bq"]).view(2, t_n, lq, d).permute(1, 0, 2, 3)              # (T, 2, Lq, D) view
@@ -321,17 +344,17 @@ class NlvrEngine:
             if "wd" in ly:                                                                                # unfolded merge_layer
                 dd = torch.empty((rq, 2, d), dtype=dt, device=cc.device)
                 ops.gemm(ccl.view(rq, 2, d).permute(1, 0, 2), ly["wd"], ly["bd"], out=dd.permute(1, 0, 2))
-                m = ops.gemm(dd.view(rq, 2 * d), ly["wm"], ly["bm"], out_dtype=torch.float32)
+                m = ops.gemm(dd.view(rq, 2 * d), ly["wm"], ly["bm"], out_dtype=sdt)
             else:
-                m = ops.gemm(ccl.view(rq, 2 * d), ly["wm"], ly["bm"], out_dtype=torch.float32)           # :252-260
-            x32, x16 = ops.layernorm(m, ly["g2"], ly["b2"], eps, residual=a32, dtype16=dt)               # LayerNormA/B(m + att_b)
+                m = ops.gemm(ccl.view(rq, 2 * d), ly["wm"], ly["bm"], out_dtype=sdt)                     # :252-260
+            x32, x16 = _ln(m, ly["g2"], ly["b2"], eps, dt, sdt, residual=a32)                            # LayerNormA/B(m + att_b)
             f = ops.gemm(x16.view(2 * rq, d), ly["w1"], ly["c1"], act=ops.ACT_GELU)                       # shared FFN :469-476
-            t = ops.gemm(f, ly["w2"], ly["c2"], residual=x32.view(2 * rq, d), out_dtype=torch.float32)
-            h32, h16 = ops.layernorm(t, ly["g3"], ly["b3"], eps, dtype16=dt)
+            t = ops.gemm(f, ly["w2"], ly["c2"], residual=x32.view(2 * rq, d), out_dtype=sdt)
+            h32, h16 = _ln(t, ly["g3"], ly["b3"], eps, dt, sdt)
             h32, h16 = h32.view(2, rq, d), h16.view(2, rq, d)
             if taps is not None:
                 hv = h32.view(2, t_n, lq, d)
-                taps.append((hv[0, :, 0, :8].clone(), hv[1, :, 0, :8].clone()))
+                taps.append((hv[0, :, 0, :8].float(), hv[1, :, 0, :8].float()))
         l = 1 if (self.trim_last and last > 0) else l
         hid = h16.view(2, t_n, l, d)[:, :, 0, :].permute(1, 0, 2).reshape(t_n, 2 * d)                     # cat(CLS_0, CLS_1) :906-908
         y = ops.gemm(hid, self.wc0, self.bc0, act=ops.ACT_RELU)                                           # blip_stage2.py:50-52

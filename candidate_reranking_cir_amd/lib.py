@@ -22,18 +22,18 @@ SIGNATURES = {
     "cir_strerror": (c_char_p, [c_int]),
     "cir_set_tuning": (c_int, [c_int, c_int]),
     "cir_gemm_bias_act": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
-                                  c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                  c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                   c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "cir_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+    "cir_layernorm": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
                               c_int64, c_int64, c_int, c_int, c_float, c_int, c_void_p]),
     "cir_attention": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
                               c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                               c_void_p, c_int64, c_int64, c_int64,
                               c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
-    "cir_embed_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+    "cir_embed_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                     c_int64, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "cir_patchify": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "cir_vit_assemble": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "cir_vit_assemble": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "cir_small_linear": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "cir_gather_rows": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_void_p]),
     "cir_topk_desc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -20,20 +20,25 @@ PROFILE_GEMM = None
 PROFILE_ATTN = None
 
 
-def gemm_kernel_name(m: int, n: int, k: int, nb: int, has_residual: bool, act: int, out32: bool, in_dtype: torch.dtype, tile: int = 0) -> str:
+def gemm_kernel_name(m: int, n: int, k: int, nb: int, has_residual: bool, act: int, out_dtype, in_dtype: torch.dtype, tile: int = 0,
+                     res_dtype=None) -> str:
     """Which kernel instantiation cir_gemm_bias_act launches for a shape (mirror of the dispatch in csrc/gemm.hip; for
-    reporting only - the library decides)."""
+    reporting only - the library decides).  `out_dtype`: torch dtype (or True / False = fp32 / operand type)."""
+    if isinstance(out_dtype, bool):
+        out_dtype = torch.float32 if out_dtype else in_dtype
     t = "__bf16" if in_dtype == torch.bfloat16 else "_Float16"
+    stream16 = out_dtype == torch.float16 and (in_dtype != torch.float16 or (has_residual and res_dtype == torch.float16))
+    kind = 1 if out_dtype == torch.float32 else (2 if stream16 else 0)
     nblk256 = -(-m // 256) * -(-n // 256) * nb
     use256 = n >= 256 and nblk256 >= 192
-    can256 = not (has_residual and (act != ACT_NONE or not out32)) and k % 128 == 0
+    can256 = not (has_residual and (act != ACT_NONE or kind == 0)) and k % 128 == 0
     if tile == 128:
         use256 = False
     elif tile == 256:
         use256 = True
     if use256 and can256:
-        return f"cir::gemm256_kernel<{t},{'true' if out32 else 'false'},{'true' if has_residual else 'false'}>"
-    return f"cir::gemm_kernel<{t},{'true' if out32 else 'false'}>"
+        return f"cir::gemm256_kernel<{t},{'true' if kind else 'false'},{'true' if has_residual else 'false'}{',_Float16' if kind == 2 else ''}>"
+    return f"cir::gemm_kernel<{t},{kind}>"
 
 
 def _stream() -> int:
@@ -53,7 +58,8 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          act: int = ACT_NONE, out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = act(a @ w.T + bias) (+ residual).  a (M,K) or (B,M,K) 16-bit with contiguous rows (any
-    row stride); w (N,K) / (B,N,K); bias fp32 (N) / (B,N); residual fp32 like out; out 16-bit or fp32."""
+    row stride); w (N,K) / (B,N,K); bias fp32 (N) / (B,N); out in a.dtype (operand copy), fp32 or fp16 (residual
+    stream, also from bf16 operands); residual shaped like out: fp32 (with any out) or fp16 (with an fp16 out)."""
     _need_cuda(a, w, bias, residual, out)
     batched = a.dim() == 3
     if not batched:
@@ -75,51 +81,58 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     ldr = sr = 0
     if residual is not None:
         r3 = residual if residual.dim() == 3 else residual.unsqueeze(0)
-        assert r3.dtype == torch.float32 and r3.shape == (nb, m, n) and r3.stride(2) == 1
+        assert r3.shape == (nb, m, n) and r3.stride(2) == 1
+        assert r3.dtype == torch.float32 or (r3.dtype == torch.float16 and out_dtype == torch.float16), "residual: fp32, or fp16 with an fp16 out"
         ldr, sr = r3.stride(1), r3.stride(0)
     if PROFILE_GEMM is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     code = _lib.load().cir_gemm_bias_act(
         a3.data_ptr(), a3.stride(1), a3.stride(0), w3.data_ptr(), w3.stride(1), w3.stride(0),
-        _ptr(bias), sb, _ptr(residual), ldr, sr, o3.data_ptr(), o3.stride(1), o3.stride(0),
-        m, n, k, nb, act, _DT[a.dtype], _DT[out_dtype], _stream())
+        _ptr(bias), sb, _ptr(residual), _DT[residual.dtype] if residual is not None else CIR_F32, ldr, sr,
+        o3.data_ptr(), o3.stride(1), o3.stride(0), m, n, k, nb, act, _DT[a.dtype], _DT[out_dtype], _stream())
     if PROFILE_GEMM is not None:
         ev1.record()
         alg_bytes = nb * ((m * k + n * k) * a.element_size() + m * n * o3.element_size()
-                          + (m * n * 4 if residual is not None else 0) + (n * 4 if bias is not None else 0))
+                          + (m * n * residual.element_size() if residual is not None else 0) + (n * 4 if bias is not None else 0))
         PROFILE_GEMM.append((2.0 * nb * m * n * k, ev0, ev1, float(alg_bytes),
-                             gemm_kernel_name(m, n, k, nb, residual is not None, act, out_dtype == torch.float32, a.dtype)))
+                             gemm_kernel_name(m, n, k, nb, residual is not None, act, out_dtype, a.dtype,
+                                              res_dtype=residual.dtype if residual is not None else None)))
     _lib.check(code, "cir_gemm_bias_act")
     return out
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, residual: Optional[torch.Tensor] = None,
               out32: Optional[torch.Tensor] = None, out16: Optional[torch.Tensor] = None, want32: bool = True,
-              dtype16: Optional[torch.dtype] = torch.bfloat16):
-    """LayerNorm over the last dim of fp32 x (rows, cols) or (B, rows, cols) [+ residual]; returns
-    (y32 or None, y16 or None).  gamma/beta (cols) or (B, cols); x/residual may be batch-broadcast
-    (stride 0) views.  `dtype16=None` skips the 16-bit copy."""
+              dtype16: Optional[torch.dtype] = torch.bfloat16, stream_dtype: Optional[torch.dtype] = None):
+    """LayerNorm over the last dim of x (rows, cols) or (B, rows, cols) [+ residual]; x / residual are residual-stream
+    tensors (fp32 or fp16, same dtype).  Returns (y_stream or None, y16 or None): `y_stream` (kept name `out32`) is the
+    copy that feeds the next residual, in `stream_dtype` (default: x.dtype); `y16` the 16-bit operand copy in `dtype16`.
+    gamma/beta (cols) or (B, cols); x/residual may be batch-broadcast (stride 0) views.  `dtype16=None` skips the operand
+    copy, `want32=False` the stream copy."""
     _need_cuda(x, gamma, beta, residual)
     x3 = x if x.dim() == 3 else x.unsqueeze(0)
     nb = max(x3.shape[0], gamma.shape[0] if gamma.dim() == 2 else 1, (residual.shape[0] if residual is not None and residual.dim() == 3 else 1))
     rows, cols = x3.shape[1], x3.shape[2]
-    assert x3.dtype == torch.float32 and x3.stride(2) == 1 and x3.stride(1) == cols
+    assert x3.dtype in (torch.float32, torch.float16) and x3.stride(2) == 1 and x3.stride(1) == cols
+    stream_dtype = stream_dtype or (out32.dtype if out32 is not None else x3.dtype)
+    assert stream_dtype in (torch.float32, torch.float16)
     shape = (nb, rows, cols) if (x.dim() == 3 or nb > 1) else (rows, cols)
     if out32 is None and want32:
-        out32 = torch.empty(shape, dtype=torch.float32, device=x.device)
+        out32 = torch.empty(shape, dtype=stream_dtype, device=x.device)
     if out16 is None and dtype16 is not None:
         out16 = torch.empty(shape, dtype=dtype16, device=x.device)
     sx = x3.stride(0) if x3.shape[0] > 1 else 0
     sr = 0
     if residual is not None:
         r3 = residual if residual.dim() == 3 else residual.unsqueeze(0)
-        assert r3.dtype == torch.float32 and r3.stride(2) == 1 and r3.stride(1) == cols
+        assert r3.dtype == x3.dtype and r3.stride(2) == 1 and r3.stride(1) == cols
         sr = r3.stride(0) if r3.shape[0] > 1 else 0
     sg = gamma.stride(0) if gamma.dim() == 2 else 0
     d16 = _DT[out16.dtype] if out16 is not None else CIR_BF16
-    code = _lib.load().cir_layernorm(x3.data_ptr(), sx, _ptr(residual), sr, gamma.data_ptr(), beta.data_ptr(), sg,
-                                     _ptr(out32), _ptr(out16), rows * cols, rows, cols, nb, float(eps), d16, _stream())
+    code = _lib.load().cir_layernorm(x3.data_ptr(), _DT[x3.dtype], sx, _ptr(residual), sr, gamma.data_ptr(), beta.data_ptr(), sg,
+                                     _ptr(out32), _DT[out32.dtype] if out32 is not None else CIR_F32, _ptr(out16), rows * cols, rows, cols, nb,
+                                     float(eps), d16, _stream())
     _lib.check(code, "cir_layernorm")
     return out32, out16
 
@@ -158,18 +171,18 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
 
 
 def embed_layernorm(ids: torch.Tensor, word: torch.Tensor, pos: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
-                    eps: float, dtype16: torch.dtype = torch.bfloat16):
-    """BERT embeddings: LayerNorm(word[ids] + pos[:L]); ids (R, L) int64 -> (y32, y16) of shape (R, L, cols)."""
+                    eps: float, dtype16: torch.dtype = torch.bfloat16, stream_dtype: torch.dtype = torch.float32):
+    """BERT embeddings: LayerNorm(word[ids] + pos[:L]); ids (R, L) int64 -> (y_stream, y16) of shape (R, L, cols)."""
     _need_cuda(ids, word, pos, gamma, beta)
     r, l = ids.shape
     cols = word.shape[1]
     if l > pos.shape[0]:      # the reference raises too (position_ids[:, :L] indexes a (max_position_embeddings,) table)
         raise IndexError(f"caption of {l} tokens exceeds the {pos.shape[0]}-row position-embedding table")
     ids = ids.contiguous()
-    y32 = torch.empty((r, l, cols), dtype=torch.float32, device=ids.device)
+    y32 = torch.empty((r, l, cols), dtype=stream_dtype, device=ids.device)
     y16 = torch.empty((r, l, cols), dtype=dtype16, device=ids.device)
     code = _lib.load().cir_embed_layernorm(ids.data_ptr(), word.data_ptr(), pos.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                           y32.data_ptr(), y16.data_ptr(), r * l, l, cols, word.shape[0], float(eps),
+                                           y32.data_ptr(), _DT[stream_dtype], y16.data_ptr(), r * l, l, cols, word.shape[0], float(eps),
                                            _DT[dtype16], _stream())
     _lib.check(code, "cir_embed_layernorm")
     return y32, y16
@@ -187,12 +200,13 @@ def patchify(image: torch.Tensor, patch: int, dtype16: torch.dtype = torch.bfloa
 
 
 def vit_assemble(proj: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, batch: int) -> torch.Tensor:
-    """proj (B*P, D) fp32, cls (D), pos (P+1, D) -> x (B, P+1, D) fp32."""
+    """proj (B*P, D) in the stream dtype (fp32 / fp16), cls (D), pos (P+1, D) fp32 -> x (B, P+1, D) in proj.dtype."""
     _need_cuda(proj, cls, pos)
+    assert proj.dtype in (torch.float32, torch.float16) and proj.is_contiguous()
     p = proj.shape[0] // batch
     d = proj.shape[1]
-    x = torch.empty((batch, p + 1, d), dtype=torch.float32, device=proj.device)
-    code = _lib.load().cir_vit_assemble(proj.data_ptr(), cls.data_ptr(), pos.data_ptr(), x.data_ptr(), batch, p, d, _stream())
+    x = torch.empty((batch, p + 1, d), dtype=proj.dtype, device=proj.device)
+    code = _lib.load().cir_vit_assemble(proj.data_ptr(), cls.data_ptr(), pos.data_ptr(), x.data_ptr(), _DT[proj.dtype], batch, p, d, _stream())
     _lib.check(code, "cir_vit_assemble")
     return x
 

@@ -16,7 +16,9 @@
  *     work is enqueued on it and nowhere else;
  *   - leading dimensions / strides are in ELEMENTS of the tensor they describe;
  *   - dtype codes: CIR_BF16 / CIR_F16 for 16-bit activations and weights (fp32 accumulate
- *     everywhere), CIR_F32 for fp32 tensors;
+ *     everywhere), CIR_F32 for fp32 tensors; the RESIDUAL STREAM (every x + sublayer(x) and the
+ *     LayerNorm outputs that feed one) is either fp32 or fp16 ("stream dtype": CIR_F32 / CIR_F16),
+ *     independently of the operand type - sums are formed in fp32 and rounded once on the store;
  *   - return 0 on success, a negative CIR_E* code for an argument error detected before launch,
  *     or a positive hipError_t from the launch.  Nothing throws or aborts across the ABI.
  *   - functions are re-entrant and may be called from any host thread.
@@ -30,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CIR_ABI_VERSION 4
+#define CIR_ABI_VERSION 5
 
 enum { CIR_BF16 = 0, CIR_F16 = 1, CIR_F32 = 2 };
 enum { CIR_ACT_NONE = 0, CIR_ACT_GELU = 1, CIR_ACT_RELU = 2 };
@@ -62,8 +64,9 @@ int cir_set_tuning(int knob, int value);
 /*
  * C[b] = act(A[b] * W[b]^T + bias[b]) (+ residual[b]),   b = 0..batch-1
  *   A (M,K) 16-bit row-major (lda), W (N,K) 16-bit row-major "torch Linear" layout (ldw),
- *   bias fp32 (N) or NULL, residual fp32 (M,N) (ldr) or NULL (added after the activation),
- *   C (M,N) 16-bit (in_dtype) or fp32 (out_dtype = CIR_F32), ldc.  C may alias residual.
+ *   bias fp32 (N) or NULL, residual (M,N) (ldr) or NULL (added after the activation),
+ *   C (M,N) (ldc): out_dtype = in_dtype (operand copy), CIR_F32 or CIR_F16 (residual stream; also from
+ *   bf16 operands).  res_dtype: CIR_F32 (with any C) or CIR_F16 (only with an fp16 C).  C may alias residual.
  *   Requirements: K % 64 == 0, N % 16 == 0, 16-byte aligned rows.
  * Replaces every nn.Linear on the path: vit.py:35-41,72,84; med.py:158-168,250-251,319-333;
  * nlvr_encoder.py:150-168,250-264,383-396; blip_stage2.py:50-54 (first layer); the erf GELU is
@@ -72,21 +75,22 @@ int cir_set_tuning(int knob, int value);
 int cir_gemm_bias_act(const void* A, int64_t lda, int64_t strideA,
                       const void* W, int64_t ldw, int64_t strideW,
                       const float* bias, int64_t strideBias,
-                      const float* residual, int64_t ldr, int64_t strideR,
+                      const void* residual, int res_dtype, int64_t ldr, int64_t strideR,
                       void* C, int64_t ldc, int64_t strideC,
                       int64_t M, int N, int K, int batch,
                       int act, int in_dtype, int out_dtype, void* stream);
 
 /*
  * y[b] = LayerNorm(x[b] (+ residual[b]); gamma[b], beta[b], eps) over the last dimension.
- *   x, residual fp32 (rows, cols); gamma/beta fp32 (cols); y32 fp32 and/or y16 16-bit outputs
- *   (either may be NULL).  cols % 4 == 0, cols <= 1024.  Strides select the per-batch slice
- *   (stride 0 = shared).  Replaces nn.LayerNorm at vit.py:107-110,192 (eps 1e-6) and
- *   med.py:253 / nlvr_encoder.py:252-264,395 (eps 1e-12), including the twin LayerNormA/B.
+ *   x, residual (rows, cols) in x_dtype (CIR_F32 or CIR_F16: the residual stream); gamma/beta fp32 (cols);
+ *   outputs: y_stream in y_stream_dtype (CIR_F32 / CIR_F16: the copy that feeds the next residual) and/or
+ *   y16 (16-bit operand copy in dtype16); either may be NULL.  fp32 statistics.  cols % 4 == 0, cols <= 1024.
+ *   Strides select the per-batch slice (stride 0 = shared).  Replaces nn.LayerNorm at vit.py:107-110,192
+ *   (eps 1e-6) and med.py:253 / nlvr_encoder.py:252-264,395 (eps 1e-12), including the twin LayerNormA/B.
  */
-int cir_layernorm(const float* x, int64_t strideX, const float* residual, int64_t strideR,
+int cir_layernorm(const void* x, int x_dtype, int64_t strideX, const void* residual, int64_t strideR,
                   const float* gamma, const float* beta, int64_t strideG,
-                  float* y32, void* y16, int64_t strideY,
+                  void* y_stream, int y_stream_dtype, void* y16, int64_t strideY,
                   int64_t rows, int cols, int batch, float eps, int dtype16, void* stream);
 
 /*
@@ -109,10 +113,11 @@ int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t q_rs,
 
 /*
  * BertEmbeddings.forward (nlvr_encoder.py:68-91, med.py:87-110):
- *   y[r] = LayerNorm(word[ids[r]] + pos[r % L]) for r < rows; fp32 tables, outputs as cir_layernorm.
+ *   y[r] = LayerNorm(word[ids[r]] + pos[r % L]) for r < rows; fp32 tables, outputs as cir_layernorm
+ *   (y_stream in CIR_F32 / CIR_F16, y16 in dtype16).
  */
 int cir_embed_layernorm(const int64_t* ids, const float* word, const float* pos,
-                        const float* gamma, const float* beta, float* y32, void* y16,
+                        const float* gamma, const float* beta, void* y_stream, int y_stream_dtype, void* y16,
                         int64_t rows, int L, int cols, int vocab, float eps, int dtype16, void* stream);
 
 /*
@@ -125,9 +130,10 @@ int cir_patchify(const void* image, int img_dtype, void* patches, int dtype16,
 
 /*
  * Token assembly (vit.py:184-187): x[b][0] = cls + pos[0]; x[b][1+i] = proj[b*P+i] + pos[1+i].
- *   proj fp32 (B*P, D) (patch-embed GEMM output incl. bias), cls (D), pos (P+1, D) fp32 -> x fp32.
+ *   proj (B*P, D) (patch-embed GEMM output incl. bias) and x in stream_dtype (CIR_F32 / CIR_F16),
+ *   cls (D), pos (P+1, D) fp32 parameters.  D % 8 == 0.
  */
-int cir_vit_assemble(const float* proj, const float* cls, const float* pos, float* x,
+int cir_vit_assemble(const void* proj, const float* cls, const float* pos, void* x, int stream_dtype,
                      int B, int P, int D, void* stream);
 
 /*

@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_symbol():
     cdll = lib.load()
     for name in _declared():
         assert hasattr(cdll, name), name
-    assert cdll.cir_version() == 4
+    assert cdll.cir_version() == 5
     assert b"aligned" in cdll.cir_strerror(-3)
 
 
@@ -59,10 +59,10 @@ def test_argument_validation_happens_before_any_launch():
     P = 0x10000          # 16-byte aligned fake device address
     BF16, F16, F32 = 0, 1, 2
     gemm = c.cir_gemm_bias_act
-    ok_args = [P, 64, 0, P, 64, 0, None, 0, None, 0, 0, P, 16, 0, 4, 16, 64, 1, 0, BF16, BF16, None]
+    ok_args = [P, 64, 0, P, 64, 0, None, 0, None, F32, 0, 0, P, 16, 0, 4, 16, 64, 1, 0, BF16, BF16, None]
 
     def call(**over):
-        names = ["A", "lda", "sA", "W", "ldw", "sW", "bias", "sB", "res", "ldr", "sR", "C", "ldc", "sC", "M", "N", "K", "batch",
+        names = ["A", "lda", "sA", "W", "ldw", "sW", "bias", "sB", "res", "res_dtype", "ldr", "sR", "C", "ldc", "sC", "M", "N", "K", "batch",
                  "act", "in_dtype", "out_dtype", "stream"]
         a = dict(zip(names, ok_args))
         a.update(over)
@@ -72,12 +72,18 @@ def test_argument_validation_happens_before_any_launch():
     assert call(act=7) == EINVAL
     assert call(K=60) == ESHAPE and call(N=17) == ESHAPE
     assert call(A=P + 2) == EALIGN and call(lda=60) == EALIGN and call(bias=P + 4) == EALIGN and call(res=P + 8, ldr=16) == EALIGN
-    assert call(in_dtype=F32) == EDTYPE and call(in_dtype=BF16, out_dtype=F16) == EDTYPE
+    assert call(in_dtype=F32) == EDTYPE and call(out_dtype=7) == EDTYPE
+    # residual stream: an fp16 residual only as part of an fp16 C; a bf16 residual never
+    assert call(res=P, res_dtype=F16, ldr=16, out_dtype=F32) == EDTYPE and call(res=P, res_dtype=BF16, ldr=16) == EDTYPE
+    assert call(res=P, res_dtype=F16, ldr=12, out_dtype=F16) == EALIGN
     # LayerNorm / attention / top-k: the same contract
-    assert c.cir_layernorm(None, 0, None, 0, P, P, 0, P, None, 0, 4, 64, 1, 1e-6, BF16, None) == EINVAL
-    assert c.cir_layernorm(P, 0, None, 0, P, P, 0, None, None, 0, 4, 64, 1, 1e-6, BF16, None) == EINVAL      # no output at all
-    assert c.cir_layernorm(P, 0, None, 0, P, P, 0, P, None, 0, 4, 2048, 1, 1e-6, BF16, None) == ESHAPE       # cols > 1024
-    assert c.cir_layernorm(P, 0, None, 0, P, P, 0, P, None, 0, 4, 64, 1, 1e-6, F32, None) == EDTYPE
+    assert c.cir_layernorm(None, F32, 0, None, 0, P, P, 0, P, F32, None, 0, 4, 64, 1, 1e-6, BF16, None) == EINVAL
+    assert c.cir_layernorm(P, F32, 0, None, 0, P, P, 0, None, F32, None, 0, 4, 64, 1, 1e-6, BF16, None) == EINVAL      # no output at all
+    assert c.cir_layernorm(P, F32, 0, None, 0, P, P, 0, P, F32, None, 0, 4, 2048, 1, 1e-6, BF16, None) == ESHAPE       # cols > 1024
+    assert c.cir_layernorm(P, F32, 0, None, 0, P, P, 0, P, F32, None, 0, 4, 64, 1, 1e-6, F32, None) == EDTYPE
+    assert c.cir_layernorm(P, BF16, 0, None, 0, P, P, 0, P, F32, None, 0, 4, 64, 1, 1e-6, BF16, None) == EDTYPE        # stream is fp32 or fp16
+    assert c.cir_layernorm(P, F16, 0, None, 0, P, P, 0, P, BF16, None, 0, 4, 64, 1, 1e-6, BF16, None) == EDTYPE
+    assert c.cir_vit_assemble(P, P, P, P, BF16, 1, 4, 64, None) == EDTYPE and c.cir_vit_assemble(P, P, P, P, F16, 1, 4, 60, None) == ESHAPE
     att = [P, 64, 64, 64, P, 64, 64, 64, P, 64, 64, 64, None, 0, 0, None, P, 64, 64, 64, 1, 1, 1, 4, 4, 0.125, BF16, None]
     # (the valid argument list itself is never passed: it would launch)
     bad = list(att); bad[0] = None

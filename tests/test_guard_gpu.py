@@ -17,7 +17,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 DTYPES = [torch.bfloat16, torch.float16]
-CANARY = {torch.float32: 0x7FC0DEAD, torch.bfloat16: 0x7FC1, torch.float16: 0x7E01, torch.int64: 0x7EADBEEF7EADBEEF}
+CANARY = {torch.float32: 0x7FC0DEAD, torch.bfloat16: 0x7FC1, torch.float16: 0x7E01, torch.int64: 0x7EADBEEF7EADBEEF}   # NaN patterns
 _INT = {torch.float32: torch.int32, torch.bfloat16: torch.int16, torch.float16: torch.int16, torch.int64: torch.int64}
 
 
@@ -62,7 +62,7 @@ BIG_SHAPES = [(79588, 768, 768), (79588, 2304, 768), (79588, 3072, 768), (79588,
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "fp16"])
 @pytest.mark.parametrize("m,n,k", BIG_SHAPES)
-@pytest.mark.parametrize("variant", ["out16", "out32", "out32_res", "out32_res_alias"])
+@pytest.mark.parametrize("variant", ["out16", "out32", "out32_res", "out32_res_alias", "stream16", "stream16_res", "stream16_res_alias"])
 def test_persistent_gemm_exact_with_guard_bands(ops, dtype, m, n, k, variant):
     """> 256 tiles of 256 x 256 (e.g. 311 x 3 for the ViT proj shape of a 404-image chunk): every workgroup of the
     persistent kernel processes 3+ tiles.  Exact integers; output inside canaries (ragged M edge, ragged N for the
@@ -73,19 +73,19 @@ def test_persistent_gemm_exact_with_guard_bands(ops, dtype, m, n, k, variant):
     w = _ints((n, k), -3, 3, dtype, seed=n + k + 1)
     bias = _ints((n,), -5, 5, torch.float32, seed=3)
     ref = a.float() @ w.float().T + bias               # exact: |sum| <= 9 * 3072 + 5 < 2^24
-    out_dtype = dtype if variant == "out16" else torch.float32
+    out_dtype = dtype if variant == "out16" else (torch.float16 if variant.startswith("stream16") else torch.float32)
     guard = Guarded(m, n, out_dtype)
     res = None
-    if variant == "out32_res":
-        res = _ints((m, n), -7, 7, torch.float32, seed=5)
-        ref = ref + res
-    elif variant == "out32_res_alias":
-        res = guard.fill_view(_ints((m, n), -7, 7, torch.float32, seed=6))
-        ref = ref + res
+    if variant in ("out32_res", "stream16_res"):
+        res = _ints((m, n), -7, 7, out_dtype, seed=5)
+        ref = ref + res.float()
+    elif variant in ("out32_res_alias", "stream16_res_alias"):
+        res = guard.fill_view(_ints((m, n), -7, 7, out_dtype, seed=6))
+        ref = ref + res.float()
     out = ops.gemm(a, w, bias, residual=res, out_dtype=out_dtype, out=guard.view)
     torch.cuda.synchronize()
-    if variant == "out16":
-        assert torch.equal(out, ref.to(dtype))          # exact fp32 sum, one RNE rounding on both sides
+    if variant == "out16" or variant.startswith("stream16"):
+        assert torch.equal(out, ref.to(out_dtype))      # exact fp32 sum (+ bias + residual), ONE RNE rounding on both sides
     else:
         assert torch.equal(out, ref)
     guard.assert_intact(f"gemm {variant} {m}x{n}x{k}")
@@ -117,13 +117,13 @@ def test_small_gemm_guard_bands(ops, tile, m, n, k):
     from candidate_reranking_cir_amd import lib
     lib.set_tuning(lib.TUNE_GEMM_TILE, tile)
     try:
-        for out_dtype, with_res in ((torch.bfloat16, False), (torch.float32, False), (torch.float32, True)):
+        for out_dtype, with_res in ((torch.bfloat16, False), (torch.float32, False), (torch.float32, True), (torch.float16, False), (torch.float16, True)):
             a = _ints((m, k), -3, 3, torch.bfloat16, seed=1)
             w = _ints((n, k), -3, 3, torch.bfloat16, seed=2)
             bias = _ints((n,), -5, 5, torch.float32, seed=3)
             guard = Guarded(m, n, out_dtype)
-            res = guard.fill_view(_ints((m, n), -7, 7, torch.float32, seed=4)) if with_res else None
-            ref = a.float() @ w.float().T + bias + (res if with_res else 0)
+            res = guard.fill_view(_ints((m, n), -7, 7, out_dtype, seed=4)) if with_res else None
+            ref = a.float() @ w.float().T + bias + (res.float() if with_res else 0)
             out = ops.gemm(a, w, bias, residual=res, out_dtype=out_dtype, out=guard.view)
             torch.cuda.synchronize()
             assert torch.equal(out.float(), ref.to(out_dtype).float())
@@ -173,19 +173,23 @@ def _flat_intact(buf, n_elems, dtype, slack=4096):
     return bool((bits[:slack] == CANARY[dtype]).all()) and bool((bits[slack + n_elems:] == CANARY[dtype]).all())
 
 
+@pytest.mark.parametrize("sdt", [torch.float32, torch.float16], ids=["stream32", "stream16"])
 @pytest.mark.parametrize("rows,cols", [(1, 768), (203, 768), (5, 64), (77, 1024), (1001, 128)])
-def test_layernorm_guard_bands(ops, rows, cols):
+def test_layernorm_guard_bands(ops, rows, cols, sdt):
     g = torch.Generator(device="cpu").manual_seed(rows)
-    x = torch.randn((rows, cols), generator=g).cuda()
-    res = torch.randn((rows, cols), generator=g).cuda()
+    x = torch.randn((rows, cols), generator=g).to(sdt).cuda()
+    res = torch.randn((rows, cols), generator=g).to(sdt).cuda()
     gam, bet = torch.randn((cols,), generator=g).cuda(), torch.randn((cols,), generator=g).cuda()
-    b32, y32 = _flat_guard(rows * cols, torch.float32)
+    b32, y32 = _flat_guard(rows * cols, sdt)
     b16, y16 = _flat_guard(rows * cols, torch.bfloat16)
     ops.layernorm(x, gam, bet, 1e-6, residual=res, out32=y32.view(rows, cols), out16=y16.view(rows, cols))
     torch.cuda.synchronize()
-    ref = F.layer_norm(x + res, (cols,), gam, bet, 1e-6)
-    torch.testing.assert_close(y32.view(rows, cols), ref, atol=2e-5, rtol=1e-5)
-    assert _flat_intact(b32, rows * cols, torch.float32) and _flat_intact(b16, rows * cols, torch.bfloat16)
+    ref = F.layer_norm(x.float() + res.float(), (cols,), gam, bet, 1e-6)
+    if sdt == torch.float32:
+        torch.testing.assert_close(y32.view(rows, cols), ref, atol=2e-5, rtol=1e-5)
+    else:
+        torch.testing.assert_close(y32.view(rows, cols).float(), ref, atol=1e-3, rtol=1e-3)          # <= 1 ulp of fp16
+    assert _flat_intact(b32, rows * cols, sdt) and _flat_intact(b16, rows * cols, torch.bfloat16)
 
 
 def test_gather_patchify_assemble_topk_guard_bands(ops):
@@ -209,7 +213,7 @@ def test_gather_patchify_assemble_topk_guard_bands(ops):
     # vit_assemble: (3, 17, 128)
     proj, cls, pos = torch.randn((48, 128), device="cuda"), torch.randn((128,), device="cuda"), torch.randn((17, 128), device="cuda")
     buf, dst = _flat_guard(3 * 17 * 128, torch.float32)
-    lib.check(c.cir_vit_assemble(proj.data_ptr(), cls.data_ptr(), pos.data_ptr(), dst.data_ptr(), 3, 16, 128, stream), "assemble")
+    lib.check(c.cir_vit_assemble(proj.data_ptr(), cls.data_ptr(), pos.data_ptr(), dst.data_ptr(), lib.CIR_F32, 3, 16, 128, stream), "assemble")
     torch.cuda.synchronize()
     assert torch.equal(dst.view(3, 17, 128), torch.cat([cls.expand(3, 1, 128), proj.view(3, 16, 128)], 1) + pos[None])
     assert _flat_intact(buf, 3 * 17 * 128, torch.float32)

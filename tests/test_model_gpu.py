@@ -476,6 +476,32 @@ def test_edge_cases_k1_all_skipped_empty_and_long_caption(tiny):
         m1.z_t(feats32[:1], *encode_text(m1.tokenizer, {"input_ids": long_ids, "attention_mask": torch.ones_like(long_ids)}, "cuda"))
 
 
+@pytest.mark.parametrize("dtype", [BF, HF], ids=["bf16", "fp16"])
+def test_residual_stream_fp32_mode(cuda, dtype):
+    """The residual stream is stored in fp16 with bf16 operands and in fp32 with fp16 operands by default (sum in fp32, one
+    rounding per sublayer); `set_stream_dtype` overrides.  With bf16 operands both modes meet the same bounds against the
+    reference; with fp16 operands the fp16 stream costs about 2x on the logits and 4x on the tokens (bounds scaled here)."""
+    z = H.load("full224.npz")
+    g, v = H.geometry(H.FULL_BERT, dict(image_size=224))
+    m2, m1 = build_models(g, v, int(z["seed"]), str(z["profile"]), dtype, cuda)
+    assert m2.stream_dtype == (torch.float16 if dtype == BF else torch.float32)
+    k = int(z["k"])
+    cap = [synthetic.caption_text(0, 30)]
+    outs = {}
+    for sdt in (torch.float16, torch.float32):
+        m2.set_stream_dtype(sdt); m1.set_stream_dtype(sdt)
+        feats = m2.img_embed(synthetic.images(range(k + 1), 224).cuda())
+        zt = m1.img_txt_fusion(feats[:1], None, cap, train=False, return_raw=True)
+        outs[sdt] = m2.img_txt_fusion_val(zt, feats[1:], cap).cpu().numpy()
+        e_vit = np.abs(feats[:, :4, :16].cpu().numpy() - z["vit_slice"]).max()
+        e_log = np.abs(outs[sdt] - z["logits"]).max()
+        print(f"\n[stream {sdt} / operands {dtype}] vit {e_vit:.3e} logits {e_log:.3e}")
+        loose = 2.5 if (dtype == HF and sdt == torch.float16) else 1.0
+        assert e_vit < TOK_TOL[dtype] * loose and e_log < LOGIT_TOL["full224"][dtype] * loose
+    assert np.abs(outs[torch.float16] - outs[torch.float32]).max() < LOGIT_TOL["full224"][dtype]
+    m2.set_stream_dtype(None); m1.set_stream_dtype(None)
+
+
 def test_state_dict_roundtrip_and_cpu_refusal(cuda):
     from candidate_reranking_cir_amd.blip_stage2 import blip_stage2
     z = H.load("tiny_loop.npz")

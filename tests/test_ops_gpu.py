@@ -313,3 +313,60 @@ def test_attention_kv_bank_index(ops):
     ops.attention(q, g[:, :, 0::2].permute(0, 2, 1, 3), g[:, :, 1::2].permute(0, 2, 1, 3), out_b, 0.125)
     torch.cuda.synchronize()
     assert torch.equal(out_a, out_b)
+
+
+# ------------------------------------------------------------------------------------------------ 16-bit residual stream
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_stream16_epilogue(ops, gemm_tile, dtype):
+    """fp16 residual stream: C (and R) fp16 from bf16 or fp16 operands; acc + bias + residual summed in fp32, rounded once."""
+    m, n, k = 333, 256, 256
+    a, w = _rand((m, k), dtype, seed=1), _rand((n, k), dtype, 0.1, seed=2)
+    bias = _rand((n,), torch.float32, seed=3)
+    res = _rand((m, n), torch.float16, 2.0, seed=4)
+    ref = a.float() @ w.float().T + bias
+    out = ops.gemm(a, w, bias, out_dtype=torch.float16)
+    torch.testing.assert_close(out.float(), ref.half().float(), atol=2e-3, rtol=1e-3)
+    out = ops.gemm(a, w, bias, residual=res, out_dtype=torch.float16)
+    torch.cuda.synchronize()
+    assert out.dtype == torch.float16
+    torch.testing.assert_close(out.float(), (ref + res.float()).half().float(), atol=4e-3, rtol=1e-3)     # <= 1 ulp of the fp16 sum
+    x = res.clone()
+    ops.gemm(a, w, bias, residual=x, out_dtype=torch.float16, out=x)                                     # in place (ViT blocks)
+    torch.cuda.synchronize()
+    assert torch.equal(x, out)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm_stream16(ops, dtype):
+    rows, cols = 203, 768
+    x = (_rand((rows, cols), torch.float32, 2.0, seed=1) + 0.5).half()
+    res = _rand((rows, cols), torch.float32, seed=2).half()
+    g, b = _rand((cols,), torch.float32, seed=3), _rand((cols,), torch.float32, seed=4)
+    ref = F.layer_norm(x.float() + res.float(), (cols,), g, b, 1e-12)
+    ys, y16 = ops.layernorm(x, g, b, 1e-12, residual=res, dtype16=dtype)
+    torch.cuda.synchronize()
+    assert ys.dtype == torch.float16 and y16.dtype == dtype
+    torch.testing.assert_close(ys.float(), ref.half().float(), atol=1e-3, rtol=1e-3)
+    torch.testing.assert_close(y16.float(), ref.to(dtype).float(), atol=1e-3, rtol=8e-3 if dtype == torch.bfloat16 else 1e-3)
+    y32, _ = ops.layernorm(x, g, b, 1e-12, residual=res, dtype16=None, stream_dtype=torch.float32)      # fp16 in, fp32 out
+    torch.testing.assert_close(y32, ref, atol=2e-5, rtol=1e-5)
+    yh, _ = ops.layernorm(x.float(), g, b, 1e-12, residual=res.float(), dtype16=None, stream_dtype=torch.float16)   # fp32 in, fp16 out
+    torch.testing.assert_close(yh.float(), ref.half().float(), atol=1e-3, rtol=1e-3)
+
+
+def test_vit_assemble_and_embed_stream16(ops):
+    b, p, d = 3, 16, 128
+    proj, cls, pos = _rand((b * p, d), torch.float16, seed=1), _rand((d,), torch.float32, seed=2), _rand((p + 1, d), torch.float32, seed=3)
+    x = ops.vit_assemble(proj, cls, pos, b)
+    ref = (torch.cat([cls.expand(b, 1, d), proj.float().view(b, p, d)], 1) + pos[None]).half()
+    torch.cuda.synchronize()
+    assert x.dtype == torch.float16 and torch.equal(x, ref)
+    vocab, cols, r, l = 1000, 768, 7, 13
+    word, posw = _rand((vocab, cols), torch.float32, seed=1), _rand((512, cols), torch.float32, seed=2)
+    g, be = _rand((cols,), torch.float32, seed=3), _rand((cols,), torch.float32, seed=4)
+    ids = torch.randint(0, vocab, (r, l), generator=torch.Generator().manual_seed(0)).cuda()
+    refe = F.layer_norm(word[ids] + posw[:l][None], (cols,), g, be, 1e-12)
+    ys, y16 = ops.embed_layernorm(ids, word, posw, g, be, 1e-12, stream_dtype=torch.float16)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(ys.float(), refe.half().float(), atol=1e-3, rtol=1e-3)
+    torch.testing.assert_close(y16.float(), refe.bfloat16().float(), atol=1e-3, rtol=8e-3)

@@ -7,13 +7,14 @@
 # library has initialised the GPU before the program starts).
 set -u
 TAG=${1:-r2}
+export STREAM_DTYPE=${STREAM_DTYPE:-f16}   # bench.py --stream-dtype of every profiled command (f16 = the bf16 default)
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o run -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_stats_bench.json 2> $OUT/${TAG}_stats.err
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmc_sq -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_pmc_sq.json 2> $OUT/${TAG}_pmc_sq.err
-rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_fetch -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_pmc_fetch.json 2> $OUT/${TAG}_pmc_fetch.err
-rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_write -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_pmc_write.json 2> $OUT/${TAG}_pmc_write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o run -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --stream-dtype $STREAM_DTYPE > $OUT/${TAG}_stats_bench.json 2> $OUT/${TAG}_stats.err
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmc_sq -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --stream-dtype $STREAM_DTYPE > $OUT/${TAG}_pmc_sq.json 2> $OUT/${TAG}_pmc_sq.err
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_fetch -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --stream-dtype $STREAM_DTYPE > $OUT/${TAG}_pmc_fetch.json 2> $OUT/${TAG}_pmc_fetch.err
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_write -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --stream-dtype $STREAM_DTYPE > $OUT/${TAG}_pmc_write.json 2> $OUT/${TAG}_pmc_write.err
 cd $ROOT
 # keep what travels back small: the per-dispatch kernel traces are not needed (the counter CSVs carry timestamps)
 find $OUT/${TAG}_stats $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write -name "*kernel_trace.csv" -delete

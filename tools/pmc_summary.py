@@ -15,6 +15,7 @@ un-profiled run (the guide: never compare a profiled arm with an un-profiled one
 import csv
 import glob
 import json
+import os
 import re
 import sys
 
@@ -23,17 +24,20 @@ def canonical(name: str):
     """rocprofv3 prints some instantiations mangled and some through a lossy demangler: map both to bench.py's names."""
     if "cir" not in name:
         return None
-    t = "_Float16" if ("DF16_" in name or "IDhL" in name) else "__bf16"
-    m = re.search(r"gemm256_kernelI(DF16b|DF16_|Dh)Lb([01])ELb([01])E", name)
+    m = re.search(r"gemm256_kernelI(DF16b|DF16_|Dh)Lb([01])ELb([01])E(f|DF16_|Dh)?E", name)
     if m:
-        return f"cir::gemm256_kernel<{t},{'true' if m.group(2) == '1' else 'false'},{'true' if m.group(3) == '1' else 'false'}>"
-    if "gemm256_kernel<" in name:                         # lossy demangle keeps only the last bool: (out32, res) in {(1,1), (1,0)}
-        return f"cir::gemm256_kernel<{t},true,{'true' if 'true>' in name else 'false'}>"
-    m = re.search(r"gemm_kernelI(DF16b|DF16_|Dh)Lb([01])E", name)
+        t = "__bf16" if m.group(1) == "DF16b" else "_Float16"
+        st = ",_Float16" if m.group(4) in ("DF16_", "Dh") else ""
+        return f"cir::gemm256_kernel<{t},{'true' if m.group(2) == '1' else 'false'},{'true' if m.group(3) == '1' else 'false'}{st}>"
+    if "gemm256_kernel<" in name:                         # lossy demangle: keeps the trailing template arguments only
+        st = ",_Float16" if "_Float16>" in name else ""
+        res = "true" if re.search(r"true(, *[_A-Za-z0-9]+)?>", name) else "false"
+        return f"cir::gemm256_kernel<?,true,{res}{st}>"
+    m = re.search(r"gemm_kernelI(DF16b|DF16_|Dh)Li([012])E", name)
     if m:
-        return f"cir::gemm_kernel<{t},{'true' if m.group(2) == '1' else 'false'}>"
+        return f"cir::gemm_kernel<{'__bf16' if m.group(1) == 'DF16b' else '_Float16'},{m.group(2)}>"
     if "gemm_kernel<" in name:
-        return f"cir::gemm_kernel<{t},true>"
+        return "cir::gemm_kernel<?>"
     for short in ("attn_shared_kernel", "attn_stream_kernel", "layernorm_kernel", "embed_ln_kernel", "patchify_kernel", "vit_assemble_kernel",
                   "gather_rows_kernel", "topk_desc_kernel", "small_linear_kernel"):
         if short in name:
@@ -64,7 +68,8 @@ def main():
                 e["n"][c] = e["n"].get(c, 0) + 1
                 e["dur_ns"][c] = e["dur_ns"].get(c, 0.0) + (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         passes[d] = sorted(seen)
-    res = {"source": "rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "
+    res = {"residual_stream": os.environ.get("STREAM_DTYPE", "f16"),   # bench.py --stream-dtype of the profiled command
+           "source": "rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "
                      "(one pass per counter group; all launches of the run incl. warm-up and the instrumented steps)",
            "passes": passes, "by_kernel": {}}
     for k, e in sorted(ker.items()):
