@@ -30,6 +30,8 @@
 //     phases to land.  A K-tile pair takes ~4400 cycles against 4096 cycles of MFMA issue.
 // Operand layout, swizzle and the swapped MFMA orientation are those of gemm.hip.
 
+#include <type_traits>
+
 #include "gemm_args.hpp"
 
 namespace cir {
@@ -52,12 +54,16 @@ constexpr int T256 = 256;
 constexpr int kHalf = 16384;       // one half-tile: 128 rows x 64 k x 2 B
 constexpr int kDbuf = 4 * kHalf;   // A0 A1 B0 B1
 
-// ST = element type of C and R when the fp32-layout epilogue is used (OUT_F32): float (the fp32 residual stream) or
-// _Float16 (the 16-bit residual stream: acc + bias (+ act) + residual are summed in fp32 and rounded ONCE, on the store).
+// Epilogues: OUT_F32 = fp32 C (and fp32 R) through an fp32 staging tile (8 passes); otherwise the 4-pass 16-bit epilogue with
+// C in the operand type T (ST = float: no residual) or in the 16-bit residual-stream type ST (_Float16; also from bf16
+// operands), whose residual R (type ST) is added AFTER the transposition to whole rows: acc + bias (+ act) is rounded to ST,
+// the residual is added to it in fp32 and the sum is rounded again.  (An fp32-staged variant with a single rounding was
+// built first: 495 us instead of 432 us on the ViT proj shape - its 8 passes each wait on the LDS round trip.)
 template <typename T, bool OUT_F32, bool HAS_RES, typename ST = float>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
-    constexpr bool S16 = !__is_same(ST, float);
-    static_assert(!S16 || OUT_F32, "a 16-bit stream output uses the fp32-layout epilogue");
+    constexpr bool FAST16 = !__is_same(ST, float);        // 16-bit residual-stream output (and residual)
+    static_assert(!(FAST16 && OUT_F32), "the stream type is written by the 16-bit epilogue");
+    using OT = typename std::conditional<FAST16, ST, T>::type;   // element type the 16-bit epilogue packs to
     using X8 = typename Elem<T>::x8;
     __shared__ __attribute__((aligned(16))) char smem[2 * kDbuf + 8 * 1024 + 4 * 4096];   // two K-tiles + a 1-KiB bias slot per wave + epilogue staging for waves 4-7
 
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
 #define WAIT_ABB() WAIT_N(2)
 #define WAIT_A1() WAIT_N(6)
 
-    static_assert(!HAS_RES || OUT_F32, "the residual is added in the fp32 row layout of the epilogue");
+    static_assert(!HAS_RES || OUT_F32 || FAST16, "the residual is added in a row layout of the epilogue");
 
     // bias of the tile arrives by LDS-DMA into a private 1-KiB slot per wave (no VGPR-destination loads on the
     // tile boundary: the compiler would answer those with vmcnt(0), which also waits for the previous tile's stores)
@@ -340,16 +346,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         // fp32 residual, fetched in the SAME row-contiguous layout the stores use (1 KiB = 4 rows x 256 B per
         // instruction, whole lines) RD passes ahead; loading it in the accumulator layout (16 rows x 32-byte pieces
         // per instruction) costs ~8 us of address processing per tile.
-        constexpr int RD = S16 ? 4 : 2;                         // residual passes in flight (same registers: 16-bit rows are half as wide)
-        using RV = typename RowVec<ST>::type;                   // four elements of a row: float4 / four halves in a u32x2
+        constexpr int RD = 2;                                   // residual passes in flight
+        // what one lane holds of a residual row: float4 in the fp32 layout, eight halves (u32x4) in the 16-bit layout
+        using RV = typename std::conditional<FAST16, u32x4, float4>::type;
+        constexpr int REL = FAST16 ? 8 : 4;                     // elements per lane and row
         [[maybe_unused]] RV rres[RD][4];
 #define LOAD_RES(PS)                                                                                                         \
         if constexpr (HAS_RES) {                                                                                             \
             const int prow_ = ((PS) / (NPASS / 2)) * 128 + wr * 64 + ((PS) % (NPASS / 2)) * ROWS;                            \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                  \
                 const int64_t m = cm0 + prow_ + j * (64 / LPR) + rr;                                                         \
-                rres[(PS) % RD][j] = (full || (m < a.M && ncol + 4 <= a.N))                                                  \
-                    ? *reinterpret_cast<const RV*>(reinterpret_cast<const ST*>(a.R) + cz * a.sR + m * a.ldr + ncol) : RowVec<ST>::zero(); \
+                rres[(PS) % RD][j] = (full || (m < a.M && ncol + REL <= a.N))                                                \
+                    ? *reinterpret_cast<const RV*>(reinterpret_cast<const ST*>(a.R) + cz * a.sR + m * a.ldr + ncol) : RV{};  \
             }                                                                                                                \
         }
         _Pragma("unroll") for (int p = 0; p < RD; ++p) { LOAD_RES(p) }
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                         wd[nh * 2 + 1] = __builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]});                           \
                     } else {                                                                                                 \
                         u32x4 o;                                                                                             \
-                        o.x = pack2<T>(v[0], v[1]); o.y = pack2<T>(v[2], v[3]); o.z = pack2<T>(v[4], v[5]); o.w = pack2<T>(v[6], v[7]); \
+                        o.x = pack2<OT>(v[0], v[1]); o.y = pack2<OT>(v[2], v[3]); o.z = pack2<OT>(v[4], v[5]); o.w = pack2<OT>(v[6], v[7]); \
                         wd[sub * 2 + nh] = o;                                                                                \
                     }                                                                                                        \
                 }                                                                                                            \
@@ -432,11 +440,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) :: "memory");
                 const int prow = (ps / (NPASS / 2)) * 128 + wr * 64 + (ps % (NPASS / 2)) * ROWS;   // first row of this pass in the tile
                 u32x4 dd[4] = {d0, d1, d2, d3};
-                if constexpr (HAS_RES) {
+                if constexpr (HAS_RES && FAST16) {
+                    typedef __attribute__((ext_vector_type(8))) ST st8;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const st8 cv = __builtin_bit_cast(st8, dd[j]), rv = __builtin_bit_cast(st8, rres[ps % RD][j]);
+                        u32x4 o;
+                        o[0] = pack2<ST>((float)cv[0] + (float)rv[0], (float)cv[1] + (float)rv[1]);
+                        o[1] = pack2<ST>((float)cv[2] + (float)rv[2], (float)cv[3] + (float)rv[3]);
+                        o[2] = pack2<ST>((float)cv[4] + (float)rv[4], (float)cv[5] + (float)rv[5]);
+                        o[3] = pack2<ST>((float)cv[6] + (float)rv[6], (float)cv[7] + (float)rv[7]);
+                        dd[j] = o;
+                    }
+                } else if constexpr (HAS_RES) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         f32x4 o = __builtin_bit_cast(f32x4, dd[j]);
-                        o += RowVec<ST>::to_f32(rres[ps % RD][j]);
+                        const float4 r = rres[ps % RD][j];
+                        o += f32x4{r.x, r.y, r.z, r.w};
                         dd[j] = __builtin_bit_cast(u32x4, o);
                     }
                 }
@@ -444,14 +465,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                 for (int j = 0; j < 4; ++j) {
                     const int64_t m = cm0 + prow + j * (64 / LPR) + rr;
                     if (full || (m < a.M && ncol + (OUT_F32 ? 4 : 8) <= a.N)) {
-                        if constexpr (S16) {            // the one rounding of the 16-bit stream: 4 elements = 8 bytes per lane, whole lines per instruction
-                            const f32x4 o = __builtin_bit_cast(f32x4, dd[j]);
-                            u32x2 pk;
-                            pk.x = pack2<ST>(o[0], o[1]);
-                            pk.y = pack2<ST>(o[2], o[3]);
-                            *reinterpret_cast<u32x2*>(reinterpret_cast<ST*>(a.C) + cz * a.sC + m * a.ldc + ncol) = pk;
-                        } else if constexpr (OUT_F32) *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(a.C) + cz * a.sC + m * a.ldc + ncol) = dd[j];
-                        else *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(a.C) + cz * a.sC + m * a.ldc + ncol) = dd[j];
+                        if constexpr (OUT_F32) *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(a.C) + cz * a.sC + m * a.ldc + ncol) = dd[j];
+                        else *reinterpret_cast<u32x4*>(reinterpret_cast<OT*>(a.C) + cz * a.sC + m * a.ldc + ncol) = dd[j];
                     }
                 }
                 if (ps + RD < NPASS) { LOAD_RES(ps + RD) }
@@ -510,7 +525,7 @@ static int persistent_grid() {
 }
 
 void launch_gemm256(const GemmArgs& a_in, int in_dtype, int out_kind, hipStream_t s) {
-    // out_kind: 0 = 16-bit in the operand type (fast 4-pass epilogue), 1 = fp32 C (and R), 2 = fp16 stream C (and R)
+    // out_kind: 0 = 16-bit C in the operand type, 1 = fp32 C (and R), 2 = fp16 residual-stream C (and R)
     GemmArgs a = a_in;
     a.tiles_m = (int)((a.M + T256 - 1) / T256);
     a.tiles_n = (a.N + T256 - 1) / T256;
@@ -534,11 +549,11 @@ void launch_gemm256(const GemmArgs& a_in, int in_dtype, int out_kind, hipStream_
 #define CIR_LAUNCH256(...) hipLaunchKernelGGL((gemm256_kernel<__VA_ARGS__>), grid, block, 0, s, a)
     if (in_dtype == CIR_BF16) {
         if (out_kind == 1) { if (res) CIR_LAUNCH256(__bf16, true, true); else CIR_LAUNCH256(__bf16, true, false); }
-        else if (out_kind == 2) { if (res) CIR_LAUNCH256(__bf16, true, true, _Float16); else CIR_LAUNCH256(__bf16, true, false, _Float16); }
+        else if (out_kind == 2) { if (res) CIR_LAUNCH256(__bf16, false, true, _Float16); else CIR_LAUNCH256(__bf16, false, false, _Float16); }
         else CIR_LAUNCH256(__bf16, false, false);
     } else {
         if (out_kind == 1) { if (res) CIR_LAUNCH256(_Float16, true, true); else CIR_LAUNCH256(_Float16, true, false); }
-        else if (out_kind == 2) { if (res) CIR_LAUNCH256(_Float16, true, true, _Float16); else CIR_LAUNCH256(_Float16, true, false, _Float16); }
+        else if (out_kind == 2) { if (res) CIR_LAUNCH256(_Float16, false, true, _Float16); else CIR_LAUNCH256(_Float16, false, false, _Float16); }
         else CIR_LAUNCH256(_Float16, false, false);
     }
 #undef CIR_LAUNCH256

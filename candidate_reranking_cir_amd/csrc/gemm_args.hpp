@@ -14,25 +14,6 @@ struct GemmArgs {
     int group_w;   // gemm256: tiles are walked in column groups of this many n-panels (weights stay L2-resident)
 };
 
-// four consecutive elements of a row of C / R in the fp32-layout epilogues
-template <typename ST> struct RowVec;
-template <> struct RowVec<float> {
-    using type = float4;
-    static __device__ __forceinline__ float4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-    static __device__ __forceinline__ f32x4 to_f32(const float4& r) { return f32x4{r.x, r.y, r.z, r.w}; }
-};
-template <> struct RowVec<_Float16> {
-    using type = u32x2;
-    static __device__ __forceinline__ u32x2 zero() { return u32x2{0u, 0u}; }
-    static __device__ __forceinline__ f32x4 to_f32(const u32x2& r) {
-        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
-        const unsigned a = r[0], b = r[1];   // (indexing, not .x / .y: hipcc 7.2 folds bit_cast(r.y) of a vector reference onto r.x)
-        const h2 lo = __builtin_bit_cast(h2, a);
-        const h2 hi = __builtin_bit_cast(h2, b);
-        return f32x4{(float)lo[0], (float)lo[1], (float)hi[0], (float)hi[1]};
-    }
-};
-
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 

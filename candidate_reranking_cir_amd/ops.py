@@ -37,7 +37,7 @@ def gemm_kernel_name(m: int, n: int, k: int, nb: int, has_residual: bool, act: i
     elif tile == 256:
         use256 = True
     if use256 and can256:
-        return f"cir::gemm256_kernel<{t},{'true' if kind else 'false'},{'true' if has_residual else 'false'}{',_Float16' if kind == 2 else ''}>"
+        return f"cir::gemm256_kernel<{t},{'true' if kind == 1 else 'false'},{'true' if has_residual else 'false'}{',_Float16' if kind == 2 else ''}>"
     return f"cir::gemm_kernel<{t},{kind}>"
 
 

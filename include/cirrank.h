@@ -18,7 +18,8 @@
  *   - dtype codes: CIR_BF16 / CIR_F16 for 16-bit activations and weights (fp32 accumulate
  *     everywhere), CIR_F32 for fp32 tensors; the RESIDUAL STREAM (every x + sublayer(x) and the
  *     LayerNorm outputs that feed one) is either fp32 or fp16 ("stream dtype": CIR_F32 / CIR_F16),
- *     independently of the operand type - sums are formed in fp32 and rounded once on the store;
+ *     independently of the operand type - sums are formed in fp32 and rounded on the store (the large-tile
+ *     GEMM rounds its result to the stream type before adding an fp16 residual: two roundings there);
  *   - return 0 on success, a negative CIR_E* code for an argument error detected before launch,
  *     or a positive hipError_t from the launch.  Nothing throws or aborts across the ABI.
  *   - functions are re-entrant and may be called from any host thread.

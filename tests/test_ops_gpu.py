@@ -318,7 +318,8 @@ def test_attention_kv_bank_index(ops):
 # ------------------------------------------------------------------------------------------------ 16-bit residual stream
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_stream16_epilogue(ops, gemm_tile, dtype):
-    """fp16 residual stream: C (and R) fp16 from bf16 or fp16 operands; acc + bias + residual summed in fp32, rounded once."""
+    """fp16 residual stream: C (and R) fp16 from bf16 or fp16 operands; the residual is added in fp32 (128-tile kernel: one
+    rounding; 256-tile kernel: on the fp16-rounded GEMM result, two roundings)."""
     m, n, k = 333, 256, 256
     a, w = _rand((m, k), dtype, seed=1), _rand((n, k), dtype, 0.1, seed=2)
     bias = _rand((n,), torch.float32, seed=3)
@@ -329,7 +330,7 @@ def test_gemm_stream16_epilogue(ops, gemm_tile, dtype):
     out = ops.gemm(a, w, bias, residual=res, out_dtype=torch.float16)
     torch.cuda.synchronize()
     assert out.dtype == torch.float16
-    torch.testing.assert_close(out.float(), (ref + res.float()).half().float(), atol=4e-3, rtol=1e-3)     # <= 1 ulp of the fp16 sum
+    torch.testing.assert_close(out.float(), (ref + res.float()).half().float(), atol=4e-3, rtol=1.5e-3)   # <= 1-2 ulp of the fp16 sum
     x = res.clone()
     ops.gemm(a, w, bias, residual=x, out_dtype=torch.float16, out=x)                                     # in place (ViT blocks)
     torch.cuda.synchronize()

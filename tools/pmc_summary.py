@@ -38,7 +38,7 @@ def canonical(name: str):
         return f"cir::gemm_kernel<{'__bf16' if m.group(1) == 'DF16b' else '_Float16'},{m.group(2)}>"
     if "gemm_kernel<" in name:
         return "cir::gemm_kernel<?>"
-    for short in ("attn_shared_kernel", "attn_stream_kernel", "layernorm_kernel", "embed_ln_kernel", "patchify_kernel", "vit_assemble_kernel",
+    for short in ("attn_shared_kernel", "attn_stream_kernel", "layernorm_h16_kernel", "layernorm_kernel", "embed_ln_kernel", "patchify_kernel", "vit_assemble_kernel",
                   "gather_rows_kernel", "topk_desc_kernel", "small_linear_kernel"):
         if short in name:
             masked = ""
