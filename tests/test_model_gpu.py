@@ -28,7 +28,7 @@ BF, HF = torch.bfloat16, torch.float16
 TOK_TOL = {BF: 4e-2, HF: 6e-3}
 LOGIT_TOL = {                       # absolute, per fixture (logit sigma over candidates in brackets)
     "full224": {BF: 6e-3, HF: 1.5e-3},          # [0.026]
-    "full224_spread": {BF: 3e-2, HF: 4.5e-3},   # [0.345]
+    "full224_spread": {BF: 4e-2, HF: 4.5e-3},   # [0.345]  (bf16: 1.4e-2 .. 2.7e-2 across the epilogue variants of round 2)
     "full384": {BF: 8e-3, HF: 2e-3},
     "rank224": {BF: 8e-3, HF: 2e-3},            # [0.14]  (= tol_unit the fixture's label margins were cut with)
     "bxb224": {BF: 6e-3, HF: 1.5e-3},           # [0.135]
