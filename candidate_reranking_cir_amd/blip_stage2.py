@@ -7,7 +7,8 @@ same 723 keys/shapes) so the reference's validate/test scripts can construct and
 (validate_stage2.py:352-362, 118, 254, 268; cirr_test_submission_stage2.py:157, 168; utils.py:51).
 Forward arithmetic runs in libcirrank's HIP kernels (`engine.NlvrEngine`, `engine.VitEngine`);
 parameters stay fp32 `nn.Parameter`s (what `load_state_dict` fills) and are packed to 16-bit on
-first use.  Inference only: no autograd graph is built.
+first use (`set_compute_dtype`: bf16 or fp16 operands; `set_stream_dtype`: storage of the residual
+stream).  Inference only: no autograd graph is built.
 """
 from __future__ import annotations
 
