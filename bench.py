@@ -269,6 +269,10 @@ def main():
     from candidate_reranking_cir_amd.blip_stage2 import BLIP_NLVR
     from candidate_reranking_cir_amd.validate_stage2 import SKIP_FILL
 
+    if os.environ.get("CIR_TUNE"):                                      # A/B runs only: "knob=value,knob=value" -> cir_set_tuning
+        from candidate_reranking_cir_amd import lib as _lib
+        for kv in os.environ["CIR_TUNE"].split(","):
+            _lib.set_tuning(*(int(x) for x in kv.split("=")))
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     g, v = config.BertGeometry(), config.VitGeometry(image_size=args.image_size)
     m2 = BLIP_NLVR(med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer())

@@ -30,6 +30,7 @@
 //     phases to land.  A K-tile pair takes ~4400 cycles against 4096 cycles of MFMA issue.
 // Operand layout, swizzle and the swapped MFMA orientation are those of gemm.hip.
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "gemm_args.hpp"
@@ -40,14 +41,44 @@ namespace cir {
 // Diagnostic build only: s_memtime stamps of workgroup 0 / wave 0 (and wave 4) at tile-phase boundaries, written to a
 // buffer of their own that no other code reads (MI355X guide: in-kernel stamps).  Never part of the shipped library.
 __device__ unsigned long long g_stamps[2][64][8];
+__device__ unsigned long long g_blk[512][4];   // per workgroup: s_memtime / s_memrealtime at entry and exit (wave 0)
+#define STAMP_BLK(O)                                                                                        \
+    if (wave == 0 && lane == 0 && blockIdx.x < 512) {                                                       \
+        unsigned long long t_, r_;                                                                          \
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_) :: "memory"); \
+        g_blk[blockIdx.x][O] = t_; g_blk[blockIdx.x][(O) + 1] = r_;                                         \
+    }
 #define STAMP(SLOT)                                                                                         \
     if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0 && tile_no < 64) {                        \
         unsigned long long t_;                                                                              \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                    \
         g_stamps[wave >> 2][tile_no][SLOT] = t_;                                                            \
     }
+__device__ unsigned long long g_pair[2][64][8];  // end of each K-tile pair of the main loop (workgroup 0, waves 0 / 4)
+#define STAMP_PAIR(SLOT)                                                                                    \
+    if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0 && tile_no < 64 && (SLOT) < 8) {          \
+        unsigned long long t_;                                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                    \
+        g_pair[wave >> 2][tile_no][SLOT] = t_;                                                              \
+    }
 #else
 #define STAMP(SLOT)
+#define STAMP_BLK(O)
+#define STAMP_PAIR(SLOT)
+#endif
+
+// Output stores: cache policy of the C lines (A/B switch CIR_STORE_POLICY: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1)
+#ifndef CIR_STORE_POLICY
+#define CIR_STORE_POLICY 1
+#endif
+#if CIR_STORE_POLICY == 0
+#define STORE_C(P, V) *(P) = (V);
+#elif CIR_STORE_POLICY == 1
+#define STORE_C(P, V) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(P), "v"(V) : "memory");
+#elif CIR_STORE_POLICY == 2
+#define STORE_C(P, V) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(P), "v"(V) : "memory");
+#else
+#define STORE_C(P, V) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(P), "v"(V) : "memory");
 #endif
 
 constexpr int T256 = 256;
@@ -116,7 +147,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         c.z = id / per_batch;
         id -= c.z * per_batch;
         // column groups of `group_w` weight panels: an XCD's 32 concurrent tiles then share few weight panels
-        // (resident in its 4 MiB L2) and stream the activation panels, each used by group_w tiles at once
+        // (resident in its 4 MiB L2) and stream the activation panels, each used by group_w tiles at once.
+        // (Measured and dropped, round 3: super-blocks of 8-32 m-tiles whose column groups are all walked before the next
+        // super-block - second pass over the activation rows on-die - and a last-to-first m order that starts on the rows
+        // the preceding kernel wrote last: no change of the benchmark step within 0.2 %; HBM reads are not what the loop waits for.)
         const int gsz = a.tiles_m * a.group_w;
         const int grp = id / gsz, rem = id - grp * gsz;
         const int first_n = grp * a.group_w;
@@ -217,8 +251,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
 // (`skip`) instead of stalling on its predecessor's stores.
 #define WAIT_N(N) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 #define WAIT_PRO(N) if (!skip) { WAIT_N(N) }
+#ifdef CIR_GEMM_STAMPS   // experiment (wrong results): drop the first pair's waits that stand behind the previous tile's stores
+#define WAIT_ABB() if (!(skip && (a.dbg & 0x800))) { WAIT_N(2) }
+#define WAIT_A1() if (!(skip && (a.dbg & 0x400))) { WAIT_N(6) }
+#else
 #define WAIT_ABB() WAIT_N(2)
 #define WAIT_A1() WAIT_N(6)
+#endif
 
     static_assert(!HAS_RES || OUT_F32 || FAST16, "the residual is added in a row layout of the epilogue");
 
@@ -233,6 +272,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     }
 
     int t = blockIdx.x;
+#ifdef CIR_GEMM_STAMPS
+    // experiment: de-phase the workgroups (their epilogue store bursts) by (blockIdx/8 mod 4) x (dbg & 0xff) sleeps of ~4 us
+    for (int i = 0, n = (a.dbg & 0xff) * ((blockIdx.x >> 3) & 3); i < n; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+    STAMP_BLK(0)
     adopt(coords(t));
     ISSUE_PROLOGUE()
     ISSUE_BIAS()
@@ -325,6 +369,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                 pa += 256;
                 pw += 256;
                 skip = false;
+                STAMP_PAIR(it - 1)
             }
             // last pair (the dispatcher sends only K % 128 == 0 here): its refills are the K-tiles past the end
             KTILE_D0(pa + 128, A_e0, W_e0)
@@ -463,10 +508,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int64_t m = cm0 + prow + j * (64 / LPR) + rr;
+                    int64_t m = cm0 + prow + j * (64 / LPR) + rr;
+#ifdef CIR_GEMM_STAMPS
+                    if (a.dbg & 0x200) m = blockIdx.x * 16 + (m & 15);   // experiment: every store of a workgroup into the same 16 rows (no HBM write stream)
+                    if ((a.dbg & 0x100) && dd[j][0] != 0x12345u) continue;   // experiment: no global stores (LDS + VALU part of the epilogue alone)
+#endif
                     if (full || (m < a.M && ncol + (OUT_F32 ? 4 : 8) <= a.N)) {
-                        if constexpr (OUT_F32) *reinterpret_cast<u32x4*>(reinterpret_cast<float*>(a.C) + cz * a.sC + m * a.ldc + ncol) = dd[j];
-                        else *reinterpret_cast<u32x4*>(reinterpret_cast<OT*>(a.C) + cz * a.sC + m * a.ldc + ncol) = dd[j];
+                        u32x4* cp;
+                        if constexpr (OUT_F32) cp = reinterpret_cast<u32x4*>(reinterpret_cast<float*>(a.C) + cz * a.sC + m * a.ldc + ncol);
+                        else cp = reinterpret_cast<u32x4*>(reinterpret_cast<OT*>(a.C) + cz * a.sC + m * a.ldc + ncol);
+                        STORE_C(cp, dd[j])
                     }
                 }
                 if (ps + RD < NPASS) { LOAD_RES(ps + RD) }
@@ -484,6 +535,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     }
     // the last tile's dead-slot refills are LDS-DMA writes: retire them before the workgroup gives its LDS back
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP_BLK(2)
 #undef ISSUE_BIAS
 #undef ISSUE_A
 #undef ISSUE_B
@@ -511,6 +563,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
 extern "C" int cir_debug_read_stamps(unsigned long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cir::g_stamps), sizeof(cir::g_stamps));
 }
+extern "C" int cir_debug_read_pairs(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cir::g_pair), sizeof(cir::g_pair));
+}
+extern "C" int cir_debug_read_blocks(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cir::g_blk), sizeof(cir::g_blk));
+}
 namespace cir {
 #endif
 
@@ -527,6 +585,10 @@ static int persistent_grid() {
 void launch_gemm256(const GemmArgs& a_in, int in_dtype, int out_kind, hipStream_t s) {
     // out_kind: 0 = 16-bit C in the operand type, 1 = fp32 C (and R), 2 = fp16 residual-stream C (and R)
     GemmArgs a = a_in;
+    a.dbg = 0;
+#ifdef CIR_GEMM_STAMPS
+    if (const char* e = getenv("CIR_DBG")) a.dbg = (int)strtol(e, nullptr, 0);
+#endif
     a.tiles_m = (int)((a.M + T256 - 1) / T256);
     a.tiles_n = (a.N + T256 - 1) / T256;
     const int64_t ntiles = (int64_t)a.tiles_m * a.tiles_n * a.batch;

@@ -11,6 +11,7 @@ struct GemmArgs {
     const void* R; int64_t ldr, sR;    // residual: fp32 or fp16 (the element type of C in the fp32-layout epilogues)
     void* C; int64_t ldc, sC;
     int64_t M; int N, K, batch, act, tiles_m, tiles_n;
+    int dbg;       // diagnostic (stamped) build only: experiment switches from the environment; 0 in the shipped library
     int group_w;   // gemm256: tiles are walked in column groups of this many n-panels (weights stay L2-resident)
 };
 
