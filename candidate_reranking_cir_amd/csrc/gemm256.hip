@@ -74,7 +74,7 @@ __device__ unsigned long long g_pair[2][64][8];  // end of each K-tile pair of t
 #if CIR_STORE_POLICY == 0
 #define STORE_C(P, V) *(P) = (V);
 #elif CIR_STORE_POLICY == 1
-#define STORE_C(P, V) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(P), "v"(V) : "memory");
+#define STORE_C(P, V) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(P), "v"(V) : "memory");   /* wait states: see the interior-tile stores */
 #elif CIR_STORE_POLICY == 2
 #define STORE_C(P, V) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(P), "v"(V) : "memory");
 #else
@@ -90,7 +90,9 @@ constexpr int kDbuf = 4 * kHalf;   // A0 A1 B0 B1
 // operands), whose residual R (type ST) is added AFTER the transposition to whole rows: acc + bias (+ act) is rounded to ST,
 // the residual is added to it in fp32 and the sum is rounded again.  (An fp32-staged variant with a single rounding was
 // built first: 495 us instead of 432 us on the ViT proj shape - its 8 passes each wait on the LDS round trip.)
-template <typename T, bool OUT_F32, bool HAS_RES, typename ST = float>
+// ACT: the activation as a compile-time constant (CIR_ACT_NONE / CIR_ACT_GELU: the two the path runs at scale), or -1 = read
+// a.act at run time (a branch and a register copy per 8 outputs; kept for the rarely used combinations).
+template <typename T, bool OUT_F32, bool HAS_RES, typename ST = float, int ACT = -1>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     constexpr bool FAST16 = !__is_same(ST, float);        // 16-bit residual-stream output (and residual)
     static_assert(!(FAST16 && OUT_F32), "the stream type is written by the 16-bit epilogue");
@@ -429,6 +431,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         {
             char* const stg = wave < 4 ? smem + kDbuf + kHalf + wave * 4096 : smem + 2 * kDbuf + 8 * 1024 + (wave - 4) * 4096;
             const unsigned stg_addr = (unsigned)(size_t)(lptr_t)(stg);
+            // 16-bit epilogue: tile-invariant lane addresses of the staging tile (write: row r15 (+16 by immediate), slot nh*4 + g;
+            // read: row rr (+8 j by immediate), slot sl - both XOR-swizzled with the row) and of the output row (bytes)
+            [[maybe_unused]] const unsigned st_w0 = stg_addr + r15 * 128 + (((0 + g) ^ (r15 & 7)) << 4);
+            [[maybe_unused]] const unsigned st_w1 = stg_addr + r15 * 128 + (((4 + g) ^ (r15 & 7)) << 4);
+            [[maybe_unused]] const unsigned st_rd = stg_addr + rr * 128 + ((sl ^ (rr & 7)) << 4);
+            [[maybe_unused]] const unsigned st_voff = (unsigned)((rr * a.ldc + wc * 64 + sl * 8) * (int64_t)sizeof(OT));
+            [[maybe_unused]] const char* const c_tile = reinterpret_cast<const char*>(a.C) + (cz * a.sC + (cm0 + wr * 64) * a.ldc + cn0) * (int64_t)sizeof(OT);
+            [[maybe_unused]] const int64_t c_row8 = a.ldc * 8 * (int64_t)sizeof(OT);
             u32x4 wd[4];                                            // one pass of packed outputs: [sub][nh] (16-bit) / [nh][half] (fp32)
             // activation + pack of pass `ps` into wd (pure VALU: overlaps the LDS round trip of the previous pass)
 #define PRODUCE(PS)                                                                                                          \
@@ -438,12 +448,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                     float v[8];                                                                                              \
                     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                         \
                         _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) v[ni * 4 + jj] = acc[(PS) / (NPASS / 2)][mi][nh][ni][jj]; \
-                    if (a.act == CIR_ACT_GELU) {                                                                             \
+                    const int act_ = ACT >= 0 ? ACT : a.act;                                                                 \
+                    if (act_ == CIR_ACT_GELU) {                                                                              \
                         _Pragma("unroll") for (int q = 0; q < 8; q += 2) {                                                   \
                             const f32x2 y = gelu_erf2(f32x2{v[q], v[q + 1]});                                                \
                             v[q] = y.x; v[q + 1] = y.y;                                                                      \
                         }                                                                                                    \
-                    } else if (a.act == CIR_ACT_RELU) {                                                                      \
+                    } else if (act_ == CIR_ACT_RELU) {                                                                       \
                         _Pragma("unroll") for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);                               \
                     }                                                                                                        \
                     if constexpr (OUT_F32) {                                                                                 \
@@ -458,11 +469,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
             }
             // registers -> LDS staging tile: slot = 16-byte chunk of the row, XOR-swizzled with the row
 #define WRITE_STAGE()                                                                                                        \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                  \
-                const int lrow = OUT_F32 ? r15 : (i >> 1) * 16 + r15;                                                        \
-                const int slot = OUT_F32 ? ((i >> 1) * 8 + g * 2 + (i & 1)) : ((i & 1) * 4 + g);                             \
-                const unsigned ad = stg_addr + lrow * ROWB + ((slot ^ (lrow & 7)) << 4);                                     \
-                asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(wd[i]) : "memory");                                      \
+            if constexpr (OUT_F32) {                                                                                         \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
+                    const int slot = (i >> 1) * 8 + g * 2 + (i & 1);                                                         \
+                    const unsigned ad = stg_addr + r15 * ROWB + ((slot ^ (r15 & 7)) << 4);                                   \
+                    asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(wd[i]) : "memory");                                  \
+                }                                                                                                            \
+            } else {   /* 16-bit rows: two lane addresses (weight half nh), the 16-row block `sub` is an immediate */        \
+                asm volatile("ds_write_b128 %0, %2\n\tds_write_b128 %1, %3\n\tds_write_b128 %0, %4 offset:2048\n\t"        \
+                             "ds_write_b128 %1, %5 offset:2048"                                                              \
+                             :: "v"(st_w0), "v"(st_w1), "v"(wd[0]), "v"(wd[1]), "v"(wd[2]), "v"(wd[3]) : "memory");          \
             }
             PRODUCE(0)
             WRITE_STAGE()
@@ -470,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
             for (int ps = 0; ps < NPASS; ++ps) {
                 // LDS -> registers, lanes along the row: instruction j covers 64/LPR rows x ROWB bytes = 1 KiB
                 u32x4 d0, d1, d2, d3;
-                {
+                if constexpr (OUT_F32) {
                     unsigned ra[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -480,6 +496,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                     asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7"
                                  : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
                                  : "v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]) : "memory");
+                } else {   // 8 lanes per 128-byte row: row j*8 + rr, so (row & 7) == rr and j is an immediate
+                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
+                                 "ds_read_b128 %3, %4 offset:3072"
+                                 : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(st_rd) : "memory");
                 }
                 if (ps + 1 < NPASS) { PRODUCE(ps + 1) }             // next pass's VALU work under the LDS latency
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) :: "memory");
@@ -506,6 +526,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                         dd[j] = __builtin_bit_cast(u32x4, o);
                     }
                 }
+                if (!OUT_F32 && !HAS_RES && full) {   // (with a residual the burst of scalar-base stores measured 3-8 % slower than the paced path below)
+                    // interior tile: wave-uniform row base (SGPR pair, scalar adds) + the lane's tile-invariant 32-bit byte offset
+                    // (one statement, closed by wait states: a store wider than 64 bits reads its data registers up to two cycles after
+                    //  issue, and the hazard recogniser does not see inline asm - the next VALU write could land in dd first)
+                    const char* const sb0 = c_tile + ((ps / (NPASS / 2)) * 16 + (ps % (NPASS / 2)) * (ROWS / 8)) * c_row8;
+                    const char* const sb1 = sb0 + c_row8;
+                    const char* const sb2 = sb1 + c_row8;
+                    const char* const sb3 = sb2 + c_row8;
+                    asm volatile("global_store_dwordx4 %0, %1, %5 nt\n\tglobal_store_dwordx4 %0, %2, %6 nt\n\t"
+                                 "global_store_dwordx4 %0, %3, %7 nt\n\tglobal_store_dwordx4 %0, %4, %8 nt\n\ts_nop 1"
+                                 :: "v"(st_voff), "v"(dd[0]), "v"(dd[1]), "v"(dd[2]), "v"(dd[3]), "s"(sb0), "s"(sb1), "s"(sb2), "s"(sb3) : "memory");
+                } else
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     int64_t m = cm0 + prow + j * (64 / LPR) + rr;
@@ -609,15 +641,18 @@ void launch_gemm256(const GemmArgs& a_in, int in_dtype, int out_kind, hipStream_
     dim3 grid((unsigned)(ntiles < g ? ntiles : g)), block(512);
     const bool res = a.R != nullptr;
 #define CIR_LAUNCH256(...) hipLaunchKernelGGL((gemm256_kernel<__VA_ARGS__>), grid, block, 0, s, a)
-    if (in_dtype == CIR_BF16) {
-        if (out_kind == 1) { if (res) CIR_LAUNCH256(__bf16, true, true); else CIR_LAUNCH256(__bf16, true, false); }
-        else if (out_kind == 2) { if (res) CIR_LAUNCH256(__bf16, false, true, _Float16); else CIR_LAUNCH256(__bf16, false, false, _Float16); }
-        else CIR_LAUNCH256(__bf16, false, false);
-    } else {
-        if (out_kind == 1) { if (res) CIR_LAUNCH256(_Float16, true, true); else CIR_LAUNCH256(_Float16, true, false); }
-        else if (out_kind == 2) { if (res) CIR_LAUNCH256(_Float16, false, true, _Float16); else CIR_LAUNCH256(_Float16, false, false, _Float16); }
-        else CIR_LAUNCH256(_Float16, false, false);
-    }
+    // the activation is a compile-time constant where the path runs at scale: operand-type C with none / GELU (QKV, K|V,
+    // cross-Q / fc1), residual-stream C with none (proj, fc2, merge); every other combination reads a.act at run time
+#define CIR_DISPATCH256(T)                                                                                                     \
+    if (out_kind == 1) { if (res) CIR_LAUNCH256(T, true, true); else CIR_LAUNCH256(T, true, false); }                          \
+    else if (out_kind == 2) {                                                                                                  \
+        if (a.act == CIR_ACT_NONE) { if (res) CIR_LAUNCH256(T, false, true, _Float16, CIR_ACT_NONE); else CIR_LAUNCH256(T, false, false, _Float16, CIR_ACT_NONE); } \
+        else { if (res) CIR_LAUNCH256(T, false, true, _Float16); else CIR_LAUNCH256(T, false, false, _Float16); }              \
+    } else if (a.act == CIR_ACT_NONE) CIR_LAUNCH256(T, false, false, float, CIR_ACT_NONE);                                    \
+    else if (a.act == CIR_ACT_GELU) CIR_LAUNCH256(T, false, false, float, CIR_ACT_GELU);                                      \
+    else CIR_LAUNCH256(T, false, false);
+    if (in_dtype == CIR_BF16) { CIR_DISPATCH256(__bf16) } else { CIR_DISPATCH256(_Float16) }
+#undef CIR_DISPATCH256
 #undef CIR_LAUNCH256
 }
 

@@ -37,7 +37,12 @@ def gemm_kernel_name(m: int, n: int, k: int, nb: int, has_residual: bool, act: i
     elif tile == 256:
         use256 = True
     if use256 and can256:
-        return f"cir::gemm256_kernel<{t},{'true' if kind == 1 else 'false'},{'true' if has_residual else 'false'}{',_Float16' if kind == 2 else ''}>"
+        name = f"cir::gemm256_kernel<{t},{'true' if kind == 1 else 'false'},{'true' if has_residual else 'false'}"
+        if kind == 2:       # fp16 residual-stream C: the activation is a template constant when there is none
+            return name + (",_Float16,0>" if act == ACT_NONE else ",_Float16>")
+        if kind == 0 and act in (ACT_NONE, ACT_GELU):
+            return name + f",float,{act}>"
+        return name + ">"
     return f"cir::gemm_kernel<{t},{kind}>"
 
 
