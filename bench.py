@@ -56,6 +56,16 @@ def algorithmic_gflop(n_tok: int, l: int, k: int):
     return dict(vit=vit / 1e9, fuse=fuse / 1e9, s1=s1 / 1e9, per_triplet=(vit + fuse + (vit + s1) / k) / 1e9)
 
 
+def csrc_sha16() -> str:
+    """Hash of the kernel sources (csrc/*.hip, *.hpp, the C header): ties an offline PMC summary to the build it measured."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "candidate_reranking_cir_amd", "csrc", "*.h*")) + [os.path.join(ROOT, "include", "cirrank.h")]):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def usable_cpus() -> int:
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -223,12 +233,103 @@ def bank_mode(args, m2, m1, dev, dt, rank, world):
                        "one_off_index_vit_s": round(t_vit, 3), "one_off_kv_bank_s": round(t_kv, 3)}}), flush=True)
 
 
+def loop_mode(args, m2, m1, dev, dt):
+    """The loop the reference actually has (validate_stage2.py:209-298, utils.py:43-55), timed end to end on a synthetic
+    CIRR-val-sized split; reported separately from the headline metric (the index images are encoded ONCE, so a triplet
+    here is fusion + stage-I / 105 only).  Legs:
+      index   extract_index_features over the whole index (images resident in HBM)
+      loop    generate_cirr_val_predictions (host batching, tokenised captions, skip rule, subset) + compute_cirr_val_metrics
+      direct  the same device work with every host-side tensor prebuilt (z_t + score per batch): what the loop costs the host
+      bank    the loop with the per-image cross-attention K/V bank
+      level1  img_txt_fusion_val called once per query like validate_stage2.py:254 (Level-1 drop-in), ms per query"""
+    import numpy as np
+    from candidate_reranking_cir_amd import ops, synthetic, validate_stage2 as V
+    q_n, k, ns, n_idx, qb = args.loop_queries, args.k, args.subset, args.index_size, args.query_batch
+    rng = np.random.default_rng(11)
+    gen = torch.Generator(device=dev).manual_seed(99)
+    images = torch.cat([torch.randn((min(256, n_idx - i), 3, args.image_size, args.image_size), generator=gen, device=dev).to(dt)
+                        for i in range(0, n_idx, 256)])
+    cand = np.stack([rng.permutation(n_idx)[:k] for _ in range(q_n)])
+    labels = np.zeros((q_n, k), dtype=bool)
+    has = rng.random(q_n) >= args.skip_rate
+    labels[np.arange(q_n)[has], np.minimum(rng.geometric(0.15, q_n) - 1, k - 1)[has]] = True
+    group = np.stack([rng.permutation(n_idx)[:ns] for _ in range(q_n)]) if ns else None
+    ids = torch.stack([synthetic.caption_ids(q, args.tokens) for q in range(q_n)])
+    ds = V.RelativeValSet(ref_index=rng.integers(0, n_idx, q_n), cand_index=cand, labels=labels, input_ids=ids,
+                          attention_mask=torch.ones_like(ids), group_index=group,
+                          target_index=(group[:, 0] if ns else None))
+    sync = torch.cuda.synchronize
+
+    def timed(fn, reps=1):
+        fn(); sync()                                                    # warm
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        sync()
+        return (time.perf_counter() - t0) / reps, out
+
+    t_index, bank = timed(lambda: V.extract_index_features(images, m2, batch_size=args.index_batch))
+    def loop(kv=None):
+        lg = V.generate_cirr_val_predictions(m2, m1, ds, bank, query_batch=qb, kv_bank=kv)
+        return (lg, V.compute_cirr_val_metrics(lg[0], lg[1], ds)) if ns else (lg, V.compute_fiq_val_metrics(lg, ds))
+    t_loop, (lg, metrics) = timed(loop)
+    # direct: identical batches, every index tensor already on the device
+    batches = []
+    act = [q for q in range(q_n) if has[q] or ns]
+    for s0 in range(0, len(act), qb):
+        qs = act[s0:s0 + qb]
+        rows, qidx = [], []
+        for j, q in enumerate(qs):
+            if has[q]:
+                rows.append(cand[q]); qidx += [j] * k
+            if ns:
+                rows.append(group[q]); qidx += [j] * ns
+        batches.append((ids[qs].to(dev), torch.ones((len(qs), args.tokens), dtype=torch.int64, device=dev),
+                        torch.as_tensor(ds.ref_index[qs], device=dev), torch.as_tensor(np.concatenate(rows), device=dev),
+                        torch.as_tensor(qidx, device=dev)))
+    def direct():
+        for bi, bm, br, bc, bq in batches:
+            z = m1.z_t(ops.gather_rows(bank, br), bi, bm)
+            out = m2.score(z.last_hidden_state, bi, bm, ops.gather_rows(bank, bc), bq)
+        return out
+    t_direct, _ = timed(direct)
+    t_kv0 = time.perf_counter(); kvb = m2.build_kv_bank(bank); sync(); t_kv = time.perf_counter() - t_kv0
+    t_bank, (lg_b, metrics_b) = timed(lambda: loop(kvb))
+    # Level 1: one img_txt_fusion_val call per query, the way the reference's loop drives the model
+    n1 = min(32, q_n)
+    def level1():
+        for q in range(n1):
+            enc = {"input_ids": ids[q:q + 1], "attention_mask": torch.ones((1, args.tokens), dtype=torch.int64)}
+            z = m1.img_txt_fusion(ops.gather_rows(bank, torch.as_tensor(ds.ref_index[q:q + 1], device=dev)), None, enc, train=False, return_raw=True)
+            out = m2.img_txt_fusion_val(z, ops.gather_rows(bank, torch.as_tensor(cand[q], device=dev)), enc)
+        return out
+    t_l1, _ = timed(level1)
+    n_trip = int(has.sum()) * k + q_n * ns
+    n_tok = (args.image_size // 16) ** 2 + 1
+    alg = algorithmic_gflop(n_tok, args.tokens, k)
+    print(json.dumps({
+        "metric": "query-candidate triplets scored/sec, scoring loop over a resident index (validate_stage2.py loop; not the headline metric)",
+        "value": round(n_trip / t_loop, 1), "unit": "triplets/s", "n_gpus": 1, "higher_is_better": True, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"CIRR-val-style split: {q_n} queries x ({k} candidates + {ns} subset members) from an index of {n_idx} images "
+                               f"({n_tok} tokens), skip rate {args.skip_rate:g}, query_batch {qb}", "residual_stream": args.stream_dtype},
+        "legs_s": {"extract_index_features": round(t_index, 4), "loop_plus_metrics": round(t_loop, 4), "direct_engine": round(t_direct, 4),
+                   "build_kv_bank_one_off": round(t_kv, 4), "loop_with_kv_bank": round(t_bank, 4)},
+        "index_images_per_s": round(n_idx / t_index, 1),
+        "loop_triplets_per_s": round(n_trip / t_loop, 1), "direct_triplets_per_s": round(n_trip / t_direct, 1),
+        "host_overhead_frac": round(1.0 - t_direct / t_loop, 4),
+        "kv_bank_loop_triplets_per_s": round(n_trip / t_bank, 1),
+        "level1_ms_per_query": round(t_l1 / n1 * 1e3, 3), "level1_triplets_per_s": round(n1 * k / t_l1, 1),
+        "fusion_tflops_loop": round(n_trip / t_loop * (alg["fuse"] + alg["s1"] / (k + ns)) / 1e3, 1),
+        "recall": [round(x, 3) for x in metrics], "recall_kv_bank": [round(x, 3) for x in metrics_b],
+        "logits_max_abs_diff_bank_vs_loop": float((lg[0] - lg_b[0]).abs().max()) if ns else float((lg - lg_b).abs().max())}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--queries", type=int, default=16, help="queries per step per GPU")
+    ap.add_argument("--queries", type=int, default=64, help="queries per step per GPU (one stage-II batch; the ViT runs in chunks of <= 2048 images)")
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--subset", type=int, default=5, help="CIRR subset members scored per query besides the K candidates (0: FashionIQ style)")
     ap.add_argument("--skip-rate", type=float, default=0.0, help="fraction of queries without a positive in their top-K (skip rule)")
@@ -239,7 +340,11 @@ def main():
                     help="storage of the residual stream: auto (fp16 with bf16 operands, fp32 with fp16 operands), f16 or f32; "
                          "sums are formed in fp32 and rounded once per sublayer either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="pixels", choices=["pixels", "bank"],
+    ap.add_argument("--no-precision-table", action="store_true", help="skip the short re-runs at the other operand / stream precisions")
+    ap.add_argument("--loop-queries", type=int, default=512, help="loop mode: queries of the synthetic split (CIRR val: 4181)")
+    ap.add_argument("--query-batch", type=int, default=16, help="loop mode: queries per stage-II batch")
+    ap.add_argument("--index-batch", type=int, default=256, help="loop mode: images per extract_index_features batch")
+    ap.add_argument("--mode", default="pixels", choices=["pixels", "bank", "loop"],
                     help="pixels: headline metric (every candidate encoded from pixels); bank: SURVEY 8(f)-1 real-dataset regime, "
                          "candidates drawn from a resident index bank with cached ViT tokens and cross-attention K/V")
     ap.add_argument("--index-size", type=int, default=2297, help="bank mode: number of index images (CIRR val: 2297)")
@@ -288,6 +393,12 @@ def main():
     q_n, k, ns = args.queries, args.k, args.subset
     if args.mode == "bank":
         return bank_mode(args, m2, m1, dev, dt, rank, world)
+    if args.mode == "loop":
+        if world != 1:
+            raise SystemExit("--mode loop is a single-GPU measurement")
+        if args.skip_rate == 0.0:
+            args.skip_rate = 0.006                                       # CIRR val: 0.6 % of the queries have no positive in the top-K
+        return loop_mode(args, m2, m1, dev, dt)
     # ---- the step's queries: a global list of world * q_n queries, `skip_rate` of them without a positive in their top-K;
     #      ranks take contiguous blocks of distributed.balanced_order (equal numbers of scored queries per rank) ------------
     rng = torch.Generator(device="cpu").manual_seed(4242)
@@ -390,6 +501,30 @@ def main():
     attn_ms = sum(r[1].elapsed_time(r[2]) for r in arecs)
     t1 = time.perf_counter(); step(); torch.cuda.synchronize(); step_ms = (time.perf_counter() - t1) * 1e3
 
+    # ---- the speed / precision trade in the same record: 3 timed steps at each other (operand, stream) precision ---------
+    precision = None
+    if world == 1 and not args.no_precision_table and not args.no_cpu_baseline:
+        precision = {f"{args.dtype}+{args.stream_dtype}_stream": round(total_cand * args.steps / elapsed, 1)}
+        for od, sd_ in (("bf16", "f32"), ("f16", "f32"), ("f16", "f16"), ("bf16", "f16")):
+            if (od, sd_) == (args.dtype, args.stream_dtype):
+                continue
+            odt, sdt_ = (torch.bfloat16 if od == "bf16" else torch.float16), (torch.float32 if sd_ == "f32" else torch.float16)
+            m2.set_compute_dtype(odt).set_stream_dtype(sdt_); m1.set_compute_dtype(odt).set_stream_dtype(sdt_)
+            images_v = images.to(odt)
+            def vstep():
+                toks = m2.img_embed16(images_v)
+                z = m1.z_t(toks[:q_n], ids, mask)
+                return m2.score(z.last_hidden_state, ids, mask, toks[q_n:], qidx)
+            vstep(); torch.cuda.synchronize()
+            tv = time.perf_counter()
+            for _ in range(3):
+                vstep()
+            torch.cuda.synchronize()
+            precision[f"{od}+{sd_}_stream"] = round(n_cand * 3 / (time.perf_counter() - tv), 1)
+            del images_v
+        precision["note"] = ("triplets/s of the same step at each operand / residual-stream precision (3 steps each; logits drift against the "
+                             "fp32 reference per combination: DESIGN.md section 2, tests/golden/outlier224.npz)")
+
     if rank == 0:
         n_tok = (args.image_size // 16) ** 2 + 1
         alg = algorithmic_gflop(n_tok, args.tokens, k)
@@ -404,15 +539,20 @@ def main():
         dom = by_kernel[dom_name]
         dom_tf = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
         all_tf = gemm_flop / (gemm_ms * 1e-3) / 1e12
-        traffic, traffic_src = None, None    # HBM bytes per launch of the dominant kernel: offline PMC passes of this same command
-        tpath = os.path.join(ROOT, "profiles", "r2_pmc_summary.json")
-        if (os.path.exists(tpath) and q_n == 16 and k == 100 and ns == 5 and args.skip_rate == 0 and args.image_size == 224
-                and args.dtype == "bf16" and json.load(open(tpath)).get("residual_stream", "f32") == args.stream_dtype):
+        # HBM bytes per launch of the dominant kernel: offline PMC passes of this same command (tools/collect_profiles.sh); the
+        # summary names the workload and the hash of the kernel sources it was measured on - any other build reports null
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r3_pmc_summary.json")
+        if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            ent = tj.get("by_kernel", {}).get(dom_name)
+            same = (tj.get("csrc_sha16") == csrc_sha16() and tj.get("queries") == q_n and tj.get("k") == k and tj.get("subset") == ns
+                    and tj.get("image_size") == args.image_size and tj.get("dtype") == args.dtype and args.skip_rate == 0
+                    and tj.get("residual_stream") == args.stream_dtype)
+            ent = tj.get("by_kernel", {}).get(dom_name) if same else None
             if ent:
                 traffic = round(ent["hbm_bytes_per_launch"])
-                traffic_src = "profiles/r2_pmc_summary.json: offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (not this run)"
+                traffic_src = ("profiles/r3_pmc_summary.json: offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these "
+                               "kernel sources (csrc_sha16 matches; not this run)")
         line = {
             "metric": "query-candidate triplets scored/sec at K=100", "value": round(value, 2), "unit": "triplets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -439,6 +579,8 @@ def main():
                          "peak_definition": "256 CU x 2.4 GHz x 4096 flop/clk/CU dense bf16/f16 MFMA (MI355X_MICROARCH.md)"},
             "device": dict(device_info(), **clocks.summary()),
         }
+        if precision is not None:
+            line["precision_table"] = precision
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(usable_cpus(), k + ns)
         print(json.dumps(line), flush=True)
