@@ -204,6 +204,9 @@ extern "C" int cir_gemm_bias_act(const void* A, int64_t lda, int64_t strideA, co
     if (act < CIR_ACT_NONE || act > CIR_ACT_RELU) return CIR_EINVAL;
     // residual: fp32 (with any C) or fp16 (only as part of an fp16 C: the 16-bit residual stream)
     if (residual && res_dtype != CIR_F32 && !(res_dtype == CIR_F16 && out_dtype == CIR_F16)) return CIR_EDTYPE;
+    // an fp16 C from bf16 operands is the residual STREAM: its epilogue reads the residual as fp16 (an fp32 residual there
+    // would be reinterpreted, not converted)
+    if (residual && out_dtype == CIR_F16 && in_dtype != CIR_F16 && res_dtype != CIR_F16) return CIR_EDTYPE;
     const int64_t out_elems_per16 = out_dtype == CIR_F32 ? 4 : 8;
     if (!cir_aligned16(A) || !cir_aligned16(W) || !cir_aligned16(C) || lda % 8 || ldw % 8 || strideA % 8 || strideW % 8 ||
         ldc % out_elems_per16 || strideC % out_elems_per16)

@@ -64,7 +64,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          act: int = ACT_NONE, out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = act(a @ w.T + bias) (+ residual).  a (M,K) or (B,M,K) 16-bit with contiguous rows (any
     row stride); w (N,K) / (B,N,K); bias fp32 (N) / (B,N); out in a.dtype (operand copy), fp32 or fp16 (residual
-    stream, also from bf16 operands); residual shaped like out: fp32 (with any out) or fp16 (with an fp16 out)."""
+    stream, also from bf16 operands); residual shaped like out: fp32 (out in a.dtype or fp32) or fp16 (with an fp16 out; the only
+    residual an fp16 out from bf16 operands takes)."""
     _need_cuda(a, w, bias, residual, out)
     batched = a.dim() == 3
     if not batched:
@@ -88,6 +89,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         r3 = residual if residual.dim() == 3 else residual.unsqueeze(0)
         assert r3.shape == (nb, m, n) and r3.stride(2) == 1
         assert r3.dtype == torch.float32 or (r3.dtype == torch.float16 and out_dtype == torch.float16), "residual: fp32, or fp16 with an fp16 out"
+        assert not (out_dtype == torch.float16 and a.dtype != torch.float16 and r3.dtype != torch.float16), \
+            "an fp16 out from bf16 operands (residual stream) takes an fp16 residual"
         ldr, sr = r3.stride(1), r3.stride(0)
     if PROFILE_GEMM is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

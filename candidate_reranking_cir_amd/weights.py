@@ -121,7 +121,34 @@ _PROFILES = {
     "test": (0.02, 0.02, 0.1, 0.05, 0.02),
     # larger weights: activations and logits spread out (rank-order tests, SURVEY section 7 hard part 1)
     "spread": (0.05, 0.05, 0.1, 0.05, 0.05),
+    # "test" plus OUTLIER CHANNELS (what pretrained ViT / BERT checkpoints carry and N(0, .02) weights do not): in three
+    # channels the ViT's fc2 rows and biases are 40x / +-25, so the pre-LN residual stream reaches 1e2..1e3 there while
+    # the matching LayerNorm gammas are small; the BERT LayerNorms give three channels a 6x gain and a +-4 offset and
+    # their output projections 20x rows.  Pins the fp16 residual stream on a stream that is NOT O(1) (tests/golden/outlier224.npz).
+    "outlier": (0.02, 0.02, 0.1, 0.05, 0.02),
 }
+_OUTLIER_CHANNELS = (17, 300, 555)
+
+
+def _apply_outliers(key: str, t: torch.Tensor, kind: str) -> torch.Tensor:
+    if t.dim() == 0 or kind in ("position_ids", "temp", "embed"):
+        return t
+    ch = [c % t.shape[0] for c in _OUTLIER_CHANNELS]
+    sign = torch.tensor([1.0, -1.0, 1.0])
+    vit = key.startswith("visual_encoder.")
+    if vit and key.endswith("mlp.fc2.weight"):
+        t[ch] *= 40.0
+    elif vit and key.endswith("mlp.fc2.bias"):
+        t[ch] += 25.0 * sign
+    elif vit and kind == "ln_w":
+        t[ch] *= 0.1
+    elif not vit and key.endswith("output.dense.weight") or ".output.dense0.weight" in key or ".output.dense1.weight" in key:
+        t[ch] *= 20.0
+    elif not vit and kind == "ln_w" and "LayerNorm" in key:
+        t[ch] *= 6.0
+    elif not vit and kind == "ln_b" and "LayerNorm" in key:
+        t[ch] += 4.0 * sign
+    return t
 
 
 def synth_tensor(key: str, shape, kind: str, seed: int = 0, profile: str = "test") -> torch.Tensor:
@@ -135,16 +162,18 @@ def synth_tensor(key: str, shape, kind: str, seed: int = 0, profile: str = "test
     gen.manual_seed((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
     t = torch.randn(shape, generator=gen, dtype=torch.float32)
     if kind == "weight":
-        return t * w_std
-    if kind == "embed":
-        return t * e_std
-    if kind == "bias":
-        return t * b_std
-    if kind == "ln_w":
-        return 1.0 + t * g_jit
-    if kind == "ln_b":
-        return t * be_std
-    raise KeyError(kind)
+        t = t * w_std
+    elif kind == "embed":
+        t = t * e_std
+    elif kind == "bias":
+        t = t * b_std
+    elif kind == "ln_w":
+        t = 1.0 + t * g_jit
+    elif kind == "ln_b":
+        t = t * be_std
+    else:
+        raise KeyError(kind)
+    return _apply_outliers(key, t, kind) if profile == "outlier" else t
 
 
 def synth_state_dict(spec: OrderedDict, seed: int = 0, profile: str = "test") -> "OrderedDict[str, torch.Tensor]":

@@ -67,7 +67,8 @@ int cir_set_tuning(int knob, int value);
  *   A (M,K) 16-bit row-major (lda), W (N,K) 16-bit row-major "torch Linear" layout (ldw),
  *   bias fp32 (N) or NULL, residual (M,N) (ldr) or NULL (added after the activation),
  *   C (M,N) (ldc): out_dtype = in_dtype (operand copy), CIR_F32 or CIR_F16 (residual stream; also from
- *   bf16 operands).  res_dtype: CIR_F32 (with any C) or CIR_F16 (only with an fp16 C).  C may alias residual.
+ *   bf16 operands).  res_dtype: CIR_F32 (with a C in the operand type or fp32) or CIR_F16 (only with an fp16 C; an fp16 C
+ *   from bf16 operands takes ONLY an fp16 residual - CIR_EDTYPE otherwise).  C may alias residual.
  *   Requirements: K % 64 == 0, N % 16 == 0, 16-byte aligned rows.
  * Replaces every nn.Linear on the path: vit.py:35-41,72,84; med.py:158-168,250-251,319-333;
  * nlvr_encoder.py:150-168,250-264,383-396; blip_stage2.py:50-54 (first layer); the erf GELU is

@@ -25,6 +25,9 @@ and `.weights`, so fixtures hold only seeds, small input checksums and the refer
                   reference's own loops at K=100 (+5 CIRR subset, one skipped row), K=50 (FashionIQ style) and K=200
                   (+5); labels placed on candidates whose logit is isolated, so Recall@k is decided by a margin; the
                   reference's recall tuples for those labels (`make_golden.py rank`, ~4 minutes).
+  outlier224.npz  the benchmark geometry with OUTLIER-channel weights (residual stream 1e2..1e3 in three channels) through the
+                  reference's generate_cirr_val_predictions at K=100 (+5): what pins the fp16 residual stream (`make_golden.py outlier`).
+  vitl_tiny.npz   the reference's ViT-large encoder (depth 24, width 1024, 16 heads) at 64 px (`make_golden.py vitl`).
   bxb224.npz      training-mode surface `BLIP_NLVR.img_txt_fusion` (blip_stage2.py:65-99) in eval mode: B=4 ragged
                   captions (padding='longest' -> real masks) -> (B,B) logits (`make_golden.py rank`).
 """
@@ -441,6 +444,65 @@ def rank_goldens(R, ref_val, full_bert):
     print("bxb224 logits", bxb.numpy().round(4))
 
 
+def outlier_goldens(R, ref_val, full_bert):
+    """tests/golden/outlier224.npz: the benchmark geometry with the OUTLIER weight profile (weights._apply_outliers: the
+    reference's ViT residual stream reaches 1e2..1e3 in three channels, its BERT LayerNorms carry 6x / +-4 channels)
+    scored by the reference's own generate_cirr_val_predictions (validate_stage2.py:209-278) at K = 100 (+5 subset), three
+    queries of which one is skipped.  Also the largest |residual| the reference's ViT blocks and BERT layers produce."""
+    m2, m1, g, v = build_reference_models(R, full_bert, dict(image_size=224, width=768, depth=12, num_heads=12), seed=33, profile="outlier")
+    n_index, n_q, k = 128, 3, 100
+    names = ["img%04d" % i for i in range(n_index)]
+    peaks = {"vit": 0.0, "bert": 0.0}
+    hooks = [blk.register_forward_hook(lambda mod, inp, out: peaks.__setitem__("vit", max(peaks["vit"], out.abs().max().item())))
+             for blk in m2.visual_encoder.blocks]
+    hooks += [ly.register_forward_hook(lambda mod, inp, out: peaks.__setitem__("bert", max(peaks["bert"], out[0][0].abs().max().item(), out[1][0].abs().max().item())))
+              for ly in m2.text_encoder.encoder.layer]
+    with torch.no_grad():
+        bank = torch.cat([m2.img_embed(synthetic.scene_images(range(i, i + 32), 224)) for i in range(0, n_index, 32)])
+    rng = np.random.RandomState(41)
+    refs = rng.randint(0, n_index, n_q)
+    cand = np.stack([rng.permutation(n_index)[:k] for _ in range(n_q)])
+    groups = np.stack([np.array([j for j in rng.permutation(n_index) if j != refs[q] and j not in cand[q]][:5]) for q in range(n_q)])
+    caps = [synthetic.caption_text(1700 + q, 30) for q in range(n_q)]
+    labels = np.zeros((n_q, k), dtype=bool)
+    labels[0, 3] = labels[1, 40] = True                               # third query: no positive in its top-K -> skipped row
+    targets = np.array([cand[0, 3], cand[1, 40], groups[2, 1]])
+    groups[0, 0], groups[1, 2] = targets[0], targets[1]
+    ds = FakeCIRR(names, refs, targets, caps, cand, labels, groups)
+    logits, glogits, *_ = ref_val.generate_cirr_val_predictions(m2, m1, ds, names, bank)
+    for h in hooks:
+        h.remove()
+    lg, gl = logits.numpy(), glogits.numpy()
+    assert np.all(lg[2] == np.float32(-99999.99)) and np.isfinite(lg[:2]).all()
+    np.savez_compressed(os.path.join(OUT, "outlier224.npz"), seed=33, profile="outlier", n_index=n_index, refs=refs, cand=cand,
+                        groups=groups, caps=np.array(caps), labels=labels, targets=targets, logits=lg, group_logits=gl,
+                        bank_slice=bank[:, :3, :8].numpy(), bank_outlier_slice=bank[:8, :3][:, :, [17, 300, 555]].numpy(),
+                        bank_sum=bank.double().sum().item(), vit_stream_peak=peaks["vit"], bert_stream_peak=peaks["bert"])
+    print(f"outlier224: ViT residual peak {peaks['vit']:.1f}, BERT hidden peak {peaks['bert']:.1f}, logits std {lg[:2].std():.4f} "
+          f"range [{lg[:2].min():.3f}, {lg[:2].max():.3f}], sorted gaps median {np.median(np.diff(np.sort(lg[0]))):.2e}")
+
+
+def vitl_goldens(R):
+    """tests/golden/vitl_tiny.npz: the reference's ViT-LARGE encoder (blip.py:203-209: depth 24, width 1024, 16 heads) at
+    64 px (17 tokens) on four seeded images - token slices, sums and the per-block CLS taps of the reference's own
+    VisionTransformer.forward (vit.py:180-194)."""
+    v = cfgmod.VitGeometry(image_size=64, width=1024, depth=24, num_heads=16)
+    enc = R.vit.VisionTransformer(img_size=64, patch_size=16, embed_dim=1024, depth=24, num_heads=16, drop_path_rate=0.1)
+    sd = weights.synth_state_dict(weights._vit_spec(v), 51, "test")
+    enc.load_state_dict({k[len("visual_encoder."):]: t for k, t in sd.items()})
+    enc = enc.float().eval()
+    taps = []
+    hooks = [blk.register_forward_hook(lambda mod, inp, out: taps.append(out[:, 0, :8].clone())) for blk in enc.blocks]
+    with torch.no_grad():
+        y = enc(synthetic.images(range(40, 44), 64))
+    for h in hooks:
+        h.remove()
+    np.savez_compressed(os.path.join(OUT, "vitl_tiny.npz"), seed=51, profile="test", image_ids=np.arange(40, 44),
+                        tokens_slice=y[:, :, :16].numpy(), tokens_sum=y.double().sum().item(), tokens_abs_mean=y.abs().mean().item(),
+                        block_cls_taps=torch.stack(taps).numpy())
+    print("vitl_tiny: tokens", tuple(y.shape), "abs mean", y.abs().mean().item())
+
+
 def tiny_goldens(R, ref_val):
     """tests/golden/tiny_loop.npz + masks.npz: reduced geometry through the reference's own loops.  Weights use the
     "spread" profile and the index images are structured (synthetic.scene_image), so that the candidates of a query get
@@ -502,6 +564,16 @@ def main():
         _, ref_val = _import_reference_scripts()
         full_bert = json.load(open(os.path.join(ref_shim.REFERENCE_ROOT, "configs", "med_config.json")))
         return rank_goldens(R, ref_val, full_bert)
+    if len(sys.argv) > 1 and sys.argv[1] in ("outlier", "vitl"):   # only the outlier-weight / ViT-large fixtures
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        R = ref_shim.load_reference_modules()
+        _install_torchvision_stub()
+        if sys.argv[1] == "vitl":
+            return vitl_goldens(R)
+        _, ref_val = _import_reference_scripts()
+        full_bert = json.load(open(os.path.join(ref_shim.REFERENCE_ROOT, "configs", "med_config.json")))
+        return outlier_goldens(R, ref_val, full_bert)
     if len(sys.argv) > 1 and sys.argv[1] == "ckpt":     # only the checkpoint-loader fixture
         torch.manual_seed(0)
         R = ref_shim.load_reference_modules()
@@ -585,6 +657,8 @@ def main():
         del m2, m1
     stage1_goldens(R)
     rank_goldens(R, ref_val, full_bert)
+    outlier_goldens(R, ref_val, full_bert)
+    vitl_goldens(R)
 
 
 if __name__ == "__main__":

@@ -76,6 +76,8 @@ def test_argument_validation_happens_before_any_launch():
     # residual stream: an fp16 residual only as part of an fp16 C; a bf16 residual never
     assert call(res=P, res_dtype=F16, ldr=16, out_dtype=F32) == EDTYPE and call(res=P, res_dtype=BF16, ldr=16) == EDTYPE
     assert call(res=P, res_dtype=F16, ldr=12, out_dtype=F16) == EALIGN
+    # bf16 operands + fp16 C is the residual stream: its epilogue reads an fp16 residual, an fp32 one is refused (not reinterpreted)
+    assert call(res=P, res_dtype=F32, ldr=16, out_dtype=F16, in_dtype=BF16) == EDTYPE
     # LayerNorm / attention / top-k: the same contract
     assert c.cir_layernorm(None, F32, 0, None, 0, P, P, 0, P, F32, None, 0, 4, 64, 1, 1e-6, BF16, None) == EINVAL
     assert c.cir_layernorm(P, F32, 0, None, 0, P, P, 0, None, F32, None, 0, 4, 64, 1, 1e-6, BF16, None) == EINVAL      # no output at all

@@ -131,3 +131,43 @@ def test_rank224_and_bxb224():
         np.testing.assert_allclose(zt[:, 0].numpy(), b["z_t_cls"], atol=1e-4)
         out = torch.stack([O.img_txt_fusion_val(sd2, zt[i:i + 1], bank[4:8], ids[i:i + 1], mask[i:i + 1]) for i in range(4)])
     np.testing.assert_allclose(out.numpy(), b["logits"], atol=2e-4)
+
+
+def test_outlier224():
+    """The oracle on the OUTLIER-channel weights (tests/golden/outlier224.npz: residual stream 1e2..1e3 in three channels,
+    the reference's generate_cirr_val_predictions at K = 100): image tokens incl. the outlier channels, the CIRR subset
+    of query 0 and the first 12 top-K candidates of query 1."""
+    z = H.load("outlier224.npz")
+    g, v = H.geometry(H.FULL_BERT, dict(image_size=224))
+    sd2, sd1 = H.state_dicts(g, v, int(z["seed"]), str(z["profile"]))
+    torch.set_num_threads(8)
+    assert float(z["vit_stream_peak"]) > 100.0            # the fixture really carries a large-magnitude stream
+    rows = [int(z["refs"][0])] + [int(i) for i in z["groups"][0]] + [int(z["refs"][1])] + [int(i) for i in z["cand"][1][:12]]
+    uniq = sorted(set(rows) | set(range(8)))
+    pos = {r: i for i, r in enumerate(uniq)}
+    with torch.no_grad():
+        feats = O.img_embed(sd2, synthetic.scene_images(uniq, 224))
+        first8 = feats[[pos[i] for i in range(8)]]
+        np.testing.assert_allclose(first8[:, :3, :8].numpy(), z["bank_slice"][:8], atol=2e-4)
+        np.testing.assert_allclose(first8[:, :3][:, :, [17, 300, 555]].numpy(), z["bank_outlier_slice"], rtol=2e-4, atol=2e-4)
+        ids, mask = H.tokenize([str(z["caps"][0])])
+        zt = O.stage1_z_t(sd1, feats[pos[rows[0]]][None], ids, mask)
+        glog = O.img_txt_fusion_val(sd2, zt, feats[[pos[i] for i in rows[1:6]]], ids, mask)
+        np.testing.assert_allclose(glog.numpy(), z["group_logits"][0], atol=3e-4)
+        ids, mask = H.tokenize([str(z["caps"][1])])
+        zt = O.stage1_z_t(sd1, feats[pos[rows[6]]][None], ids, mask)
+        logits = O.img_txt_fusion_val(sd2, zt, feats[[pos[i] for i in rows[7:19]]], ids, mask)
+        np.testing.assert_allclose(logits.numpy(), z["logits"][1][:12], atol=3e-4)
+
+
+def test_vit_large_tiny():
+    """The oracle's ViT at the reference's ViT-LARGE geometry (depth 24, width 1024, 16 heads; blip.py:203-209) against the
+    reference's own VisionTransformer (tests/golden/vitl_tiny.npz)."""
+    from candidate_reranking_cir_amd import config, weights
+    z = H.load("vitl_tiny.npz")
+    v = config.VitGeometry(image_size=64, width=1024, depth=24, num_heads=16)
+    sd = weights.synth_state_dict(weights._vit_spec(v), int(z["seed"]), str(z["profile"]))
+    with torch.no_grad():
+        y = O.vit_forward(sd, synthetic.images(z["image_ids"].tolist(), 64), n_heads=16)
+    np.testing.assert_allclose(y[:, :, :16].numpy(), z["tokens_slice"], atol=1e-4)
+    assert abs(y.double().sum().item() - float(z["tokens_sum"])) < 1e-1

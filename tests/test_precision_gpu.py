@@ -1,0 +1,151 @@
+"""Rank identity and the residual-stream precision choice, pinned on reference outputs (MI355X).
+
+north_star asks for "identical top-K rank order".  A 16-bit path cannot promise that for candidates whose fp32 logits
+differ by less than its own rounding drift, so the claim is split into what IS asserted:
+  * every pair / sorted position that the reference decides by a margin holds (tests/test_model_gpu.py);
+  * HERE, on top of that: the fraction of sorted positions holding exactly the reference's candidate, Kendall's tau of
+    the two orders and the top-10 overlap have FLOORS (measured on MI355X, minus 10 %), per operand dtype;
+  * the precision table: bf16 / fp16 operands x fp16 / fp32 residual stream against a fixture whose weights carry
+    OUTLIER CHANNELS (tests/golden/outlier224.npz: the reference's ViT residual stream peaks at ~1e2..1e3 in three
+    channels, as pretrained checkpoints do) - the default (bf16 operands, fp16 stream) must stay within the same bound
+    as the fp32 stream there, or it loses its place as the default.
+"""
+import numpy as np
+import pytest
+import torch
+from scipy.stats import kendalltau
+
+from candidate_reranking_cir_amd import synthetic
+from tests import helpers as H
+from tests.test_model_gpu import build_models
+
+pytestmark = pytest.mark.gpu
+BF, HF, F32 = torch.bfloat16, torch.float16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda")
+
+
+def order_stats(ours: np.ndarray, ref: np.ndarray):
+    """(exact-position fraction, Kendall tau, top-10 overlap fraction) of two logit rows."""
+    o, r = np.argsort(-ours, kind="stable"), np.argsort(-ref, kind="stable")
+    tau = kendalltau(ours, ref).statistic
+    return float((o == r).mean()), float(tau), len(set(o[:10]) & set(r[:10])) / 10.0
+
+
+# ------------------------------------------------------------------------------------------------ outlier-channel weights
+# (operands, stream) -> bound on max|dlogit| (the fixture's logit sigma is only 0.027: the outlier channels dominate every
+# LayerNorm's statistics and compress the informative signal), floor on Kendall tau, floor on the top-10 overlap.
+# Measured on MI355X (round 3; DESIGN.md section 2 "Outlier-channel fixture"):
+#   bf16 operands: fp16 stream 3.6e-2 / tau 0.62 / top-10 0.45      fp32 stream 3.5e-2 / 0.66 / 0.55
+#   fp16 operands: fp16 stream 9.5e-3 / tau 0.91 / top-10 0.90      fp32 stream 5.1e-3 / 0.94 / 0.90
+# i.e. the OPERAND rounding decides the drift (bf16's 8 bits against fp16's 11: 7x), not the storage of the residual stream.
+OUTLIER_BOUNDS = {
+    (BF, HF): (5.5e-2, 0.52, 0.3),
+    (BF, F32): (5.5e-2, 0.55, 0.4),
+    (HF, F32): (8.0e-3, 0.90, 0.8),
+    (HF, HF): (1.5e-2, 0.86, 0.8),
+}
+
+
+def test_outlier_weights_precision_table(cuda):
+    from candidate_reranking_cir_amd import validate_stage2 as V
+    z = H.load("outlier224.npz")
+    g, v = H.geometry(H.FULL_BERT, dict(image_size=224))
+    ref, gref = z["logits"], z["group_logits"]
+    skipped = ~z["labels"].any(1)
+    ref_out = z["bank_outlier_slice"]
+    imgs = synthetic.scene_images(range(int(z["n_index"])), 224)
+    ds = V.RelativeValSet(ref_index=z["refs"], cand_index=z["cand"], labels=z["labels"], captions=[str(c) for c in z["caps"]],
+                          group_index=z["groups"], target_index=z["targets"])
+    errs = {}
+    print(f"\n[outlier224] reference residual-stream peaks: ViT {float(z['vit_stream_peak']):.0f}, BERT {float(z['bert_stream_peak']):.0f}; "
+          f"logit sigma {ref[~skipped].std():.3f}")
+    for (dtype, stream), (tol, tau_min, top_min) in OUTLIER_BOUNDS.items():
+        m2, m1 = build_models(g, v, int(z["seed"]), str(z["profile"]), dtype, cuda)
+        m2.set_stream_dtype(stream); m1.set_stream_dtype(stream)
+        bank = V.extract_index_features(imgs, m2, batch_size=64, dtype=torch.float32)
+        assert torch.isfinite(bank).all()
+        e_tok = np.abs(bank[:, :3, :8].cpu().numpy() - z["bank_slice"]).max()
+        e_out = np.abs(bank[:8, :3][:, :, [17, 300, 555]].cpu().numpy() - ref_out).max() / np.abs(ref_out).max()
+        lt, gt = V.generate_cirr_val_predictions(m2, m1, ds, bank.to(dtype), query_batch=3)
+        logits, gl = lt.cpu().numpy(), gt.cpu().numpy()
+        assert np.array_equal(logits[skipped], ref[skipped]) and np.isfinite(logits).all() and np.isfinite(gl).all()
+        err = max(np.abs(logits[~skipped] - ref[~skipped]).max(), np.abs(gl - gref).max())
+        stats = np.array([order_stats(logits[q], ref[q]) for q in np.where(~skipped)[0]])
+        exact, tau, top10 = stats.mean(0)
+        errs[(dtype, stream)] = err
+        print(f"   operands {str(dtype)[6:]:9s} stream {str(stream)[6:]:8s} tokens {e_tok:.3e} (outlier channels rel {e_out:.2e})  "
+              f"max|dlogit| {err:.3e}  exact positions {exact:.2f}  tau {tau:.3f}  top-10 overlap {top10:.2f}")
+        assert err < tol and tau >= tau_min and top10 >= top_min
+        assert e_out < (2e-2 if dtype == BF else 3e-3)
+        del m2, m1, bank
+    # what keeps the fp16 stream the default with bf16 operands: it adds nothing measurable to the operand rounding ...
+    assert errs[(BF, HF)] < 1.25 * errs[(BF, F32)]
+    # ... and why fp16 OPERANDS default to an fp32 stream: there the stream rounding is of the operands' own size
+    assert errs[(HF, F32)] < errs[(HF, HF)] < errs[(BF, F32)]
+
+
+# ------------------------------------------------------------------------------------------------ rank identity floors
+RANK_FLOORS = {          # (exact-position fraction, Kendall tau, top-10 overlap) floors = measured on MI355X minus ~10 %:
+    # measured       bf16: c100 0.752 / 0.9933 / 0.97   c200 0.510 / 0.9915 / 0.95   f50 0.827 / 0.9924 / 1.00
+    #                fp16: c100 0.945 / 0.9989 / 1.00   c200 0.927 / 0.9992 / 1.00   f50 0.987 / 0.9995 / 1.00
+    "c100": {BF: (0.67, 0.989, 0.87), HF: (0.85, 0.997, 0.9)},
+    "c200": {BF: (0.45, 0.987, 0.85), HF: (0.83, 0.997, 0.9)},
+    "f50": {BF: (0.74, 0.988, 0.9), HF: (0.88, 0.997, 0.9)},
+}
+
+
+@pytest.fixture(scope="module", params=[BF, HF], ids=["bf16", "fp16"])
+def rank(request, cuda):
+    from candidate_reranking_cir_amd import validate_stage2 as V
+    z = H.load("rank224.npz")
+    g, v = H.geometry(H.FULL_BERT, dict(image_size=224))
+    m2, m1 = build_models(g, v, int(z["seed"]), str(z["profile"]), request.param, cuda)
+    bank = V.extract_index_features(synthetic.scene_images(range(int(z["n_index"])), 224), m2, batch_size=128)
+    return z, m2, m1, bank, request.param
+
+
+@pytest.mark.parametrize("tag", ["c100", "c200", "f50"])
+def test_rank_identity_floors(rank, tag):
+    from candidate_reranking_cir_amd import validate_stage2 as V
+    z, m2, m1, bank, dt = rank
+    if tag == "f50":
+        caps = [V.fiq_caption(str(p[0]), str(p[1])) for p in z["f50_caps"]]
+        ds = V.RelativeValSet(ref_index=z["f50_refs"], cand_index=z["f50_cand"], labels=z["f50_labels"], captions=caps)
+        logits = V.generate_fiq_val_predictions(m2, m1, ds, bank, query_batch=3).cpu().numpy()
+    else:
+        ds = V.RelativeValSet(ref_index=z[f"{tag}_refs"], cand_index=z[f"{tag}_cand"], labels=z[f"{tag}_labels"],
+                              captions=[str(c) for c in z[f"{tag}_caps"]], group_index=z[f"{tag}_groups"], target_index=z[f"{tag}_targets"])
+        logits = V.generate_cirr_val_predictions(m2, m1, ds, bank, query_batch=4)[0].cpu().numpy()
+    ref = z[f"{tag}_logits"]
+    active = z[f"{tag}_labels"].any(1)
+    stats = np.array([order_stats(logits[q], ref[q]) for q in np.where(active)[0]])
+    exact, tau, top10 = stats.mean(0)
+    f_exact, f_tau, f_top = RANK_FLOORS[tag][dt]
+    print(f"\n[rank224 {tag} {dt}] exact positions {exact:.3f} (floor {f_exact})  Kendall tau {tau:.4f} (floor {f_tau})  "
+          f"top-10 overlap {top10:.2f} (floor {f_top})  worst query tau {stats[:, 1].min():.4f}")
+    assert exact >= f_exact and tau >= f_tau and top10 >= f_top
+
+
+# ------------------------------------------------------------------------------------------------ ViT-large against the reference
+@pytest.mark.parametrize("dtype", [BF, HF], ids=["bf16", "fp16"])
+def test_vit_large_reference_golden(cuda, dtype):
+    """`vit='large'` (blip.py:203-209: depth 24, width 1024, 16 heads) against the reference's own VisionTransformer
+    (tests/golden/vitl_tiny.npz, 64 px): final tokens and the CLS row after every one of the 24 blocks."""
+    from candidate_reranking_cir_amd import config, weights
+    from candidate_reranking_cir_amd.engine import VitEngine
+    z = H.load("vitl_tiny.npz")
+    v = config.VitGeometry(image_size=64, width=1024, depth=24, num_heads=16)
+    sd = weights.synth_state_dict(weights._vit_spec(v), int(z["seed"]), str(z["profile"]))
+    eng = VitEngine({k: t.cuda() for k, t in sd.items()}, v, dtype, cuda)
+    y32, y16 = eng.forward(synthetic.images(z["image_ids"].tolist(), 64).cuda(), want32=True)
+    assert y32.shape == (4, 17, 1024)
+    err = np.abs(y32[:, :, :16].cpu().numpy() - z["tokens_slice"]).max()
+    rel_sum = abs(y32.double().sum().item() - float(z["tokens_sum"])) / (float(z["tokens_abs_mean"]) * y32.numel())
+    print(f"\n[vit-large golden {dtype}] tokens max|err| {err:.3e}  |sum error| / (n * mean|x|) {rel_sum:.2e}")
+    assert err < (5e-2 if dtype == BF else 6e-3) and rel_sum < 1e-4        # measured 2.2e-2 / 2.6e-3 after 24 blocks
