@@ -363,11 +363,14 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
-    if world > 1:
+    # (CIR_BENCH_INIT_PG=1: create the process group and run the exchange also with ONE rank - the RCCL communicator and the
+    #  device-tensor all-gather then execute on a single-GPU box; tests/test_distributed_gpu.py)
+    use_pg = world > 1 or os.environ.get("CIR_BENCH_INIT_PG") == "1"
+    if use_pg:
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from candidate_reranking_cir_amd import config, distributed as D, ops, synthetic, weights
     from candidate_reranking_cir_amd.blip_stage1 import BLIP_Retrieval
@@ -430,8 +433,8 @@ def main():
     local_scores = torch.empty((n_buf, q_n, w), dtype=torch.float32, device=dev)
     local_order = torch.empty((n_buf, q_n, w), dtype=torch.int64, device=dev)
     # (gather buffers in the concatenated layout - rank-major along dim 0 - which every backend accepts)
-    gathered_scores = torch.empty((world * n_buf, q_n, w), dtype=torch.float32, device=dev) if world > 1 else None
-    gathered_order = torch.empty((world * n_buf, q_n, w), dtype=torch.int64, device=dev) if world > 1 else None
+    gathered_scores = torch.empty((world * n_buf, q_n, w), dtype=torch.float32, device=dev) if use_pg else None
+    gathered_order = torch.empty((world * n_buf, q_n, w), dtype=torch.int64, device=dev) if use_pg else None
 
     def step(slot=0):
         toks = m2.img_embed16(images)                                   # reference images first, then candidates
@@ -449,17 +452,17 @@ def main():
         return scored
 
     def exchange():
-        if world > 1 and backend == "nccl":
+        if use_pg and backend == "nccl":
             dist.all_gather_into_tensor(gathered_scores, local_scores)
             dist.all_gather_into_tensor(gathered_order, local_order)
-        elif world > 1:                                                 # dry run: the same gather through host memory
+        elif use_pg:                                                    # dry run: the same gather through host memory
             for dst, src in ((gathered_scores, local_scores), (gathered_order, local_order)):
                 host = torch.empty(dst.shape, dtype=dst.dtype)
                 dist.all_gather_into_tensor(host, src.cpu())
                 dst.copy_(host)
 
     def fence():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -474,13 +477,28 @@ def main():
         exchange()
         fence()
         elapsed = time.perf_counter() - t0
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = te.item()
-        tn = torch.tensor([n_cand], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tn, op=dist.ReduceOp.SUM)
-        total_cand = int(tn.item())
+    collective = None
+    if use_pg:
+        cdev = dev if backend == "nccl" else "cpu"
+        mine_t = torch.tensor([elapsed, float(n_cand)], dtype=torch.float64, device=cdev)
+        all_t = torch.empty((world * 2,), dtype=torch.float64, device=cdev)   # (concatenated layout: every backend accepts it)
+        dist.all_gather_into_tensor(all_t, mine_t)                      # per-rank step time and work: load balance is visible per N
+        all_t = all_t.view(world, 2)
+        per_rank_ms = (all_t[:, 0] / args.steps * 1e3).tolist()
+        elapsed = float(all_t[:, 0].max())                             # the job is as slow as its slowest rank
+        total_cand = int(all_t[:, 1].sum())
+        # the gathered matrix must hold this rank's block bit for bit, and every rank must hold the same matrix
+        mine_blk = gathered_scores.view(world, n_buf, q_n, w)[rank]
+        chk = torch.tensor([float(gathered_scores.double().sum())], dtype=torch.float64, device=cdev)
+        chk_all = torch.empty((world,), dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(chk_all, chk)
+        collective = {"backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend, "ranks": world,
+                      "per_rank_ms_per_step": {"min": round(min(per_rank_ms), 3), "max": round(max(per_rank_ms), 3),
+                                               "mean": round(sum(per_rank_ms) / world, 3)},
+                      "per_rank_triplets_per_step": [int(x) for x in all_t[:, 1].tolist()],
+                      "gathered_bytes_per_rank": int(local_scores.numel() * 4 + local_order.numel() * 8),
+                      "own_block_bit_identical": bool(torch.equal(mine_blk, local_scores)),
+                      "gathered_checksum": float(chk_all[0]), "checksum_equal_on_all_ranks": bool((chk_all == chk_all[0]).all())}
     else:
         total_cand = n_cand
     assert torch.isfinite(out).all()
@@ -579,12 +597,14 @@ def main():
                          "peak_definition": "256 CU x 2.4 GHz x 4096 flop/clk/CU dense bf16/f16 MFMA (MI355X_MICROARCH.md)"},
             "device": dict(device_info(), **clocks.summary()),
         }
+        if collective is not None:
+            line["collective"] = collective
         if precision is not None:
             line["precision_table"] = precision
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(usable_cpus(), k + ns)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

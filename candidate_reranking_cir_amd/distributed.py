@@ -76,9 +76,9 @@ def sharded_scores(score_rows: Callable[[Sequence[int]], Union[torch.Tensor, Tup
             raise ValueError(f"score_rows returned shapes {[tuple(p.shape) for p in parts]}, expected widths {widths} for {hi - lo} rows")
         block[: hi - lo] = torch.cat([p.to(device=device, dtype=torch.float32) for p in parts], dim=1)
     idx_block = _argsort_desc(block[:, : widths[0]].contiguous()) if with_indices else None
-    if world == 1:
+    if not dist.is_initialized():
         gathered, gathered_idx = block, idx_block
-    else:
+    else:       # (also with a one-rank group: the collective then still runs - RCCL communicator, device buffers - as on N ranks)
         gathered = torch.empty((world * per, sum(widths)), dtype=torch.float32, device=device)
         dist.all_gather_into_tensor(gathered, block)
         gathered_idx = None

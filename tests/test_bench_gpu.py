@@ -63,3 +63,33 @@ def test_bank_mode_line():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
     assert d["value"] > 0 and "index-bank reuse" in d["metric"] and d["config"]["index_size"] == 64
+
+
+def test_one_rank_rccl_exchange_runs_on_device_tensors():
+    """The RCCL branch of bench.py (init_process_group('nccl'), all_gather_into_tensor on DEVICE tensors, per-rank timing and
+    checksum gathers) executed with a one-rank group on the single GPU of the box: what the 2/4/8-GPU runs do, minus peers."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, CIR_BENCH_INIT_PG="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--queries", "2",
+                        "--skip-rate", "0.5", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    c = d["collective"]
+    assert c["backend"].startswith("rccl") and c["ranks"] == 1 and c["own_block_bit_identical"] and c["checksum_equal_on_all_ranks"]
+    assert c["per_rank_ms_per_step"]["min"] == c["per_rank_ms_per_step"]["max"] > 0
+    assert c["gathered_bytes_per_rank"] == 2 * 2 * 105 * (4 + 8) and sum(c["per_rank_triplets_per_step"]) == d["config"]["triplets_per_step_rank0"]
+
+
+def test_loop_mode_line():
+    """`--mode loop`: the reference's own loop (extract_index_features + generate_cirr_val_predictions + metrics) timed end
+    to end beside the direct-engine number, the K/V-bank variant and the Level-1 per-query call."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "loop", "--loop-queries", "6", "--query-batch", "4", "--k", "20",
+                        "--index-size", "48", "--index-batch", "32", "--skip-rate", "0.2"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["value"] > 0 and "scoring loop" in d["metric"] and d["host_overhead_frac"] < 1
+    assert d["recall"] == d["recall_kv_bank"] and d["logits_max_abs_diff_bank_vs_loop"] == 0.0 and d["level1_ms_per_query"] > 0

@@ -71,3 +71,32 @@ def test_two_ranks_real_scorer_equals_single_process(use_balance):
         np.testing.assert_array_equal(a, expect)
         np.testing.assert_array_equal(b, gexpect)
         np.testing.assert_array_equal(idx, eidx)
+
+
+def _rccl_worker(rank, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from candidate_reranking_cir_amd import distributed as D, ops
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    V, m2, m1, bank, ds = _setup()
+    logits, glogits = V.generate_val_predictions(m2, m1, ds, bank, query_batch=3)      # no process group yet: plain path
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        order = D.balanced_order(ds.labels.any(axis=1).tolist())
+        (a, b), idx = D.sharded_scores(lambda rows: V.generate_val_predictions(m2, m1, ds, bank, query_batch=3, rows=rows),
+                                       n_queries=len(ds), k=(ds.K, ds.group_index.shape[1]), device=dev, order=order, with_indices=True)
+        assert a.is_cuda and b.is_cuda and idx.is_cuda and idx.dtype == torch.int64
+        ret["equal"] = bool(torch.equal(a, logits) and torch.equal(b, glogits) and torch.equal(idx, ops.argsort_desc(logits)))
+        ret["backend"] = dist.get_backend()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_one_rank_group_gathers_device_tensors():
+    """`sharded_scores(..., device=cuda, with_indices=True)` under an initialised NCCL (= RCCL) group of ONE rank: the
+    communicator is created and both all_gather_into_tensor calls run on device tensors - the code path of the 8-GPU run."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ret = mp.Manager().dict()
+    mp.spawn(_rccl_worker, args=(_free_port(), ret), nprocs=1, join=True)
+    assert ret["backend"] == "nccl" and ret["equal"]

@@ -1,0 +1,76 @@
+"""BASELINE configs[4] as a property test: ONE rank's share of the 512-query stress batch (64 queries x (200 candidates +
+5 subset members), fp16 operands, K = 200, 224 px) through `generate_val_predictions` - the sizes the 8 x MI355X run gives
+each GPU.  No reference output exists at this size (the CPU reference would need ~10 minutes), so the checks are the
+size-independent properties of the path (cirr_test_submission_stage2.py:111-178 semantics: every query with a subset is
+scored; validate_stage2.py:239/258: rows without a positive are filled with -99999.99):
+  * skip rows bit-exact, everything else finite;
+  * permutation equivariance, bit for bit: permuting the QUERIES (other batches, other batch neighbours) and permuting
+    each query's CANDIDATES permutes the logits and nothing else;
+  * the score of a candidate does not depend on K: the first 100 candidates scored alone equal the K = 200 run;
+  * descending order / indices from cir_topk_desc are a permutation and sorted;
+  * peak device memory is set by `query_batch`, not by the number of queries."""
+import numpy as np
+import pytest
+import torch
+
+from candidate_reranking_cir_amd import synthetic
+from tests import helpers as H
+from tests.test_model_gpu import build_models
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config4_one_rank_share_properties():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from candidate_reranking_cir_amd import ops, validate_stage2 as V
+    dev = torch.device("cuda")
+    g, v = H.geometry(H.FULL_BERT, dict(image_size=224))
+    m2, m1 = build_models(g, v, 21, "test", torch.float16, dev)
+    n_idx, q_n, k, ns, qb = 384, 64, 200, 5, 8
+    rng = np.random.RandomState(5)
+    bank = V.extract_index_features(synthetic.scene_images(range(n_idx), 224), m2, batch_size=128)
+    cand = np.stack([rng.permutation(n_idx)[:k] for _ in range(q_n)])
+    group = np.stack([rng.permutation(n_idx)[:ns] for _ in range(q_n)])
+    labels = np.zeros((q_n, k), dtype=bool)
+    skipped = np.zeros(q_n, dtype=bool); skipped[[3, 17, 40, 63]] = True
+    labels[np.arange(q_n)[~skipped], rng.randint(0, k, q_n)[~skipped]] = True
+    ids = torch.stack([synthetic.caption_ids(500 + q, 32) for q in range(q_n)])
+    mk = lambda c, l, gi, rows=None: V.RelativeValSet(ref_index=refs if rows is None else refs[rows], cand_index=c, labels=l, input_ids=ids if rows is None else ids[rows],
+                                                      attention_mask=torch.ones_like(ids) if rows is None else torch.ones_like(ids[rows]), group_index=gi,
+                                                      target_index=gi[:, 0])
+    refs = rng.randint(0, n_idx, q_n)
+    ds = mk(cand, labels, group)
+    torch.cuda.reset_peak_memory_stats()
+    base_mem = torch.cuda.memory_allocated()
+    logits, glogits = V.generate_val_predictions(m2, m1, ds, bank, query_batch=qb)
+    peak_64 = torch.cuda.max_memory_allocated() - base_mem
+    assert logits.shape == (q_n, k) and glogits.shape == (q_n, ns)
+    assert bool((logits[torch.tensor(skipped)] == np.float32(-99999.99)).all())
+    assert torch.isfinite(logits[torch.tensor(~skipped)]).all() and torch.isfinite(glogits).all()
+    # ---- queries permuted: other batches, other neighbours -> the same rows, bit for bit
+    perm = rng.permutation(q_n)
+    lp, gp = V.generate_val_predictions(m2, m1, mk(cand[perm], labels[perm], group[perm], perm), bank, query_batch=qb)
+    assert torch.equal(lp, logits[torch.tensor(perm)]) and torch.equal(gp, glogits[torch.tensor(perm)])
+    # ---- candidates permuted inside every query
+    cperm = np.stack([rng.permutation(k) for _ in range(q_n)])
+    lc, gc = V.generate_val_predictions(m2, m1, mk(np.take_along_axis(cand, cperm, 1), np.take_along_axis(labels, cperm, 1), group), bank, query_batch=qb)
+    assert torch.equal(lc, torch.gather(logits, 1, torch.tensor(cperm, device=dev))) and torch.equal(gc, glogits)
+    # ---- a candidate's score does not depend on how many others are scored with it (K = 100 prefix of the first 16 queries)
+    sub = np.arange(16)
+    keep = ~skipped[sub]
+    lab100 = labels[sub][:, :100].copy(); lab100[keep, 0] = True           # keep the same queries active
+    l100, _ = V.generate_val_predictions(m2, m1, mk(cand[sub][:, :100], lab100, group[sub], sub), bank, query_batch=qb)
+    assert torch.equal(l100[torch.tensor(keep)], logits[:16, :100][torch.tensor(keep)])
+    # ---- ranking: a permutation per row, sorted descending, skip rows keep index order (stable ties)
+    order = ops.argsort_desc(logits)
+    assert torch.equal(torch.sort(order, dim=1).values, torch.arange(k, device=dev).expand(q_n, k))
+    srt = torch.gather(logits, 1, order)
+    assert bool((srt[:, 1:] <= srt[:, :-1]).all()) and torch.equal(order[torch.tensor(skipped)], torch.arange(k, device=dev).expand(int(skipped.sum()), k))
+    # ---- memory follows query_batch, not Q: a quarter of the queries needs the same peak (beyond the (Q, K) result itself)
+    torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+    base_mem = torch.cuda.memory_allocated()
+    V.generate_val_predictions(m2, m1, mk(cand[:16], labels[:16], group[:16], np.arange(16)), bank, query_batch=qb)
+    peak_16 = torch.cuda.max_memory_allocated() - base_mem
+    print(f"\n[configs[4] share] 64 x 205 fp16 K=200: peak {peak_64 / 2**30:.2f} GiB at Q=64, {peak_16 / 2**30:.2f} GiB at Q=16 (query_batch {qb})")
+    assert peak_64 < 1.1 * peak_16 + (q_n * (k + ns) * 4) * 4
