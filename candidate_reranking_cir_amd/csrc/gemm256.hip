@@ -300,6 +300,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         STAMP(1)
         // ---- accumulators start at the bias ----------------------------------------------------------------------------
+        // (Measured and dropped, round 3: the bias fragment as the C operand of each accumulator's first MFMA instead of this
+        //  pass - 16 more registers live through the first K-tile: the initialisation shrank 470 -> 250 cycles, the seam
+        //  around it grew by more; 72.9 against 72.5 ms of GEMM time per step.)
         {
             float bias[2][8];
             if (a.bias != nullptr) {
