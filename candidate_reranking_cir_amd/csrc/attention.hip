@@ -22,6 +22,18 @@
 //     current one is processed: the text-side cases (32 x 32 self-attention, 32 x 197 / 32 x 577
 //     cross-attention) where nothing is shared between waves, and any Lk > 608.
 // Ragged extents: rows beyond Lq / Lk are clamped or zero-filled on load; scores of keys >= Lk are -inf.
+//
+// Measured and dropped in round 3 (ViT 1696 x 12 heads, 197 x 197, staged kernel 640 us):
+//   * a persistent STREAMING variant - one wave per query tile, two workgroups per CU walking their heads back to back, the
+//     32-key K / V tiles pulled through an 8-slot LDS ring by LDS-DMA (56 KiB per workgroup in flight across head
+//     boundaries, one barrier per key tile, next head's Q one head ahead in registers): bit-identical, 628-639 us.  The
+//     load -> barrier -> compute -> store structure is therefore NOT what bounds this kernel; a wave's tile update is
+//     one serial chain (4 MFMA -> max -> exchange -> 16 exp -> sum -> exchange -> cvt -> 4 MFMA, ~1.4 k cycles of latency for
+//     ~520 cycles of issue) and 3.5 waves per SIMD cover only half of it (VALU busy 48 %, matrix pipe 19 %).
+//   * v_permlane32_swap for the two half-wave exchanges instead of ds_bpermute: no change in time (and hipcc folds
+//     max(r.x, r.y) of the builtin's two results into one of them when both inputs are the same register: wrong values).
+// What would move it is a second independent chain per wave (two key tiles per update: +40 registers, i.e. 3 waves per
+// SIMD) - not built.
 
 #include "common.hpp"
 
