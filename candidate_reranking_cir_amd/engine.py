@@ -56,33 +56,6 @@ def additive_encoder_mask(attention_mask: torch.Tensor) -> torch.Tensor:
     return ((1.0 - attention_mask.to(torch.float32)) * torch.finfo(torch.float32).min).contiguous()
 
 
-def plan_vit_chunks(total: int, n_tok: int, max_chunk: int = 2048, cus: int = 256) -> list:
-    """Split `total` images into chunks of at most `max_chunk` so that the persistent 256 x 256-tile GEMMs of a ViT block
-    fill their last round of workgroups: a chunk of B images gives tm = ceil(B * n_tok / 256) row tiles and 3 / 9 / 12
-    column tiles (N = 768 / 2304 / 3072), walked by `cus` workgroups in ceil(tm * nt / cus) rounds.  The N = 768 GEMMs
-    (proj, fc2 with K = 3072) are the sensitive ones: 1696 images = 15.3 rounds -> 16 (4.4 % idle), 1996 images = 18.0.
-    Candidates: equal splits, and as many "round" chunks (tm a multiple of `cus`) as fit plus the remainder; cost = rounds
-    weighted by the K-loop length of the GEMMs of that width (proj 1 + fc2 4, qkv 1, fc1 1)."""
-    def cost(b):
-        tm = -(-b * n_tok // 256)
-        return 5 * -(-3 * tm // cus) + -(-9 * tm // cus) + -(-12 * tm // cus)
-    plans = []
-    p_min = -(-total // max_chunk)
-    for p in range(p_min, p_min + 3):
-        size = -(-total // p)
-        plans.append([size] * (total // size) + ([total % size] if total % size else []))
-    j = 1
-    while (cus * 256 * j) // n_tok <= max_chunk:
-        b = (cus * 256 * j) // n_tok                                          # largest batch with tm = cus * j row tiles
-        if b > 0:
-            k, rem = divmod(total, b)
-            if rem and k and rem + b <= max_chunk and cost(rem + b) < cost(rem) + cost(b):
-                plans.append([b] * (k - 1) + [rem + b])
-            plans.append([b] * k + ([rem] if rem else []))
-        j += 1
-    return min(plans, key=lambda pl: (sum(cost(b) for b in pl), len(pl)))
-
-
 # =================================================================================================
 class VitEngine:
     """ViT-B/16 patch encoder (vit.py:113-194 + timm PatchEmbed) as 7 launches per block."""
@@ -112,11 +85,9 @@ class VitEngine:
     def forward(self, image: torch.Tensor, want32: bool = False, chunk: int = 2048):
         """(B,3,H,W) fp32/16-bit -> tokens (B, N, D): 16-bit always, fp32 too if `want32`."""
         if image.shape[0] > chunk:
-            sizes = plan_vit_chunks(image.shape[0], self.geo.num_tokens, chunk)
-            parts, i = [], 0
-            for size in sizes:
-                parts.append(self.forward(image[i:i + size], want32, chunk))
-                i += size
+            n_parts = -(-image.shape[0] // chunk)
+            size = -(-image.shape[0] // n_parts)                              # balanced chunks (no ragged tail)
+            parts = [self.forward(image[i:i + size], want32, chunk) for i in range(0, image.shape[0], size)]
             return (torch.cat([p[0] for p in parts]) if want32 else None), torch.cat([p[1] for p in parts])
         geo, dt = self.geo, self.dtype
         bsz, d, n = image.shape[0], geo.width, geo.num_tokens
