@@ -82,15 +82,21 @@ class VitEngine:
                 w2=_w16(sd[b + "mlp.fc2.weight"], dtype, device), c2=_f32(sd[b + "mlp.fc2.bias"], device)))
         self.gf, self.bf = _f32(sd[p + "norm.weight"], device), _f32(sd[p + "norm.bias"], device)
 
-    def forward(self, image: torch.Tensor, want32: bool = False, chunk: int = 2048):
-        """(B,3,H,W) fp32/16-bit -> tokens (B, N, D): 16-bit always, fp32 too if `want32`."""
-        if image.shape[0] > chunk:
-            n_parts = -(-image.shape[0] // chunk)
-            size = -(-image.shape[0] // n_parts)                              # balanced chunks (no ragged tail)
-            parts = [self.forward(image[i:i + size], want32, chunk) for i in range(0, image.shape[0], size)]
-            return (torch.cat([p[0] for p in parts]) if want32 else None), torch.cat([p[1] for p in parts])
+    def forward(self, image: torch.Tensor, want32: bool = False, chunk: int = 2048, out32: Optional[torch.Tensor] = None,
+                out16: Optional[torch.Tensor] = None):
+        """(B,3,H,W) fp32/16-bit -> tokens (B, N, D): 16-bit always, fp32 too if `want32`.  `out32` / `out16`: write the
+        tokens there (contiguous (B, N, D) tensors) - the chunked path hands each chunk its slice of ONE result tensor, so
+        no concatenation copy follows (2 GB per 6784 images at 224 px)."""
         geo, dt = self.geo, self.dtype
         bsz, d, n = image.shape[0], geo.width, geo.num_tokens
+        if bsz > chunk:
+            n_parts = -(-bsz // chunk)
+            size = -(-bsz // n_parts)                                          # balanced chunks (no ragged tail)
+            y16 = torch.empty((bsz, n, d), dtype=dt, device=image.device) if out16 is None else out16
+            y32 = (torch.empty((bsz, n, d), dtype=torch.float32, device=image.device) if out32 is None else out32) if want32 else None
+            for i in range(0, bsz, size):
+                self.forward(image[i:i + size], want32, chunk, out32=None if y32 is None else y32[i:i + size], out16=y16[i:i + size])
+            return y32, y16
         if image.shape[-1] != geo.image_size or image.shape[-2] != geo.image_size:
             raise ValueError(f"image size {tuple(image.shape[-2:])} != model image_size {geo.image_size}")
         if image.dtype not in (torch.float32, dt):
@@ -110,7 +116,9 @@ class VitEngine:
             _, xb = _ln(x, blk["g2"], blk["b2"], geo.layer_norm_eps, dt, sdt, need_stream=False)
             f = ops.gemm(xb, blk["w1"], blk["c1"], act=ops.ACT_GELU)           # vit.py:36-37
             ops.gemm(f, blk["w2"], blk["c2"], residual=x, out_dtype=sdt, out=x)  # vit.py:39, :109
-        y32, y16 = ops.layernorm(x, self.gf, self.bf, geo.layer_norm_eps, want32=want32, dtype16=dt, stream_dtype=torch.float32)  # vit.py:192
+        y32, y16 = ops.layernorm(x, self.gf, self.bf, geo.layer_norm_eps, want32=want32, dtype16=dt, stream_dtype=torch.float32,
+                                 out32=None if (out32 is None or not want32) else out32.view(bsz * n, d),
+                                 out16=None if out16 is None else out16.view(bsz * n, d))                                       # vit.py:192
         return (y32.view(bsz, n, d) if want32 else None), y16.view(bsz, n, d)
 
 

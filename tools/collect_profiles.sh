@@ -1,20 +1,21 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence of one round on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh r2
+#   bash tools/collect_profiles.sh r3
 # -> gpurun_out/<tag>_stats (kernel-trace --stats), gpurun_out/<tag>_pmc_{sq,fetch,write} (one PMC pass each; --pmc is
-#    never combined with other trace domains), aggregated by tools/kstats.py / tools/pmc_summary.py into profiles/.
+#    never combined with other trace domains), aggregated by tools/kstats.py / tools/pmc_summary.py (which reads the
+#    workload from the bench line each pass printed and stamps the hash of the kernel sources).
 # The profiled program is `python3 bench.py ...` directly after `--` (no env / bash -c hop: the profiler's preloaded
 # library has initialised the GPU before the program starts).
-set -u
-TAG=${1:-r2}
-export STREAM_DTYPE=${STREAM_DTYPE:-f16}   # bench.py --stream-dtype of every profiled command (f16 = the bf16 default)
+set -euo pipefail
+TAG=${1:-r3}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
+mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o run -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --stream-dtype $STREAM_DTYPE > $OUT/${TAG}_stats_bench.json 2> $OUT/${TAG}_stats.err
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmc_sq -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --stream-dtype $STREAM_DTYPE > $OUT/${TAG}_pmc_sq.json 2> $OUT/${TAG}_pmc_sq.err
-rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_fetch -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --stream-dtype $STREAM_DTYPE > $OUT/${TAG}_pmc_fetch.json 2> $OUT/${TAG}_pmc_fetch.err
-rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_write -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --stream-dtype $STREAM_DTYPE > $OUT/${TAG}_pmc_write.json 2> $OUT/${TAG}_pmc_write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o run -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-precision-table > $OUT/${TAG}_stats.json 2> $OUT/${TAG}_stats.err
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmc_sq -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-precision-table > $OUT/${TAG}_pmc_sq.json 2> $OUT/${TAG}_pmc_sq.err
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_fetch -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-precision-table > $OUT/${TAG}_pmc_fetch.json 2> $OUT/${TAG}_pmc_fetch.err
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_write -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-precision-table > $OUT/${TAG}_pmc_write.json 2> $OUT/${TAG}_pmc_write.err
 cd $ROOT
 # keep what travels back small: the per-dispatch kernel traces are not needed (the counter CSVs carry timestamps)
 find $OUT/${TAG}_stats $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write -name "*kernel_trace.csv" -delete

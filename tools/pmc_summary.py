@@ -24,14 +24,21 @@ def canonical(name: str):
     """rocprofv3 prints some instantiations mangled and some through a lossy demangler: map both to bench.py's names."""
     if "cir" not in name:
         return None
-    m = re.search(r"gemm256_kernelI(DF16b|DF16_|Dh)Lb([01])ELb([01])E(f|DF16_|Dh)?E", name)
-    if m:
+    m = re.search(r"gemm256_kernelI(DF16b|DF16_|Dh)Lb([01])ELb([01])E(f|DF16_|Dh)Li(n?)(\d)E", name)
+    if m:                                                 # names as ops.gemm_kernel_name prints them (ACT: template constant or run time)
         t = "__bf16" if m.group(1) == "DF16b" else "_Float16"
-        st = ",_Float16" if m.group(4) in ("DF16_", "Dh") else ""
-        return f"cir::gemm256_kernel<{t},{'true' if m.group(2) == '1' else 'false'},{'true' if m.group(3) == '1' else 'false'}{st}>"
+        f32, res = m.group(2) == "1", "true" if m.group(3) == "1" else "false"
+        stream16 = m.group(4) in ("DF16_", "Dh")
+        act = None if m.group(5) == "n" else int(m.group(6))
+        base = f"cir::gemm256_kernel<{t},{'true' if f32 else 'false'},{res}"
+        if stream16:
+            return base + (",_Float16,0>" if act == 0 else ",_Float16>")
+        if not f32 and act in (0, 1):
+            return base + f",float,{act}>"
+        return base + ">"
     if "gemm256_kernel<" in name:                         # lossy demangle: keeps the trailing template arguments only
-        st = ",_Float16" if "_Float16>" in name else ""
-        res = "true" if re.search(r"true(, *[_A-Za-z0-9]+)?>", name) else "false"
+        st = ",_Float16" if "_Float16" in name else ""
+        res = "true" if re.search(r"true(, *[_A-Za-z0-9-]+)*>", name) else "false"
         return f"cir::gemm256_kernel<?,true,{res}{st}>"
     m = re.search(r"gemm_kernelI(DF16b|DF16_|Dh)Li([012])E", name)
     if m:
@@ -68,8 +75,21 @@ def main():
                 e["n"][c] = e["n"].get(c, 0) + 1
                 e["dur_ns"][c] = e["dur_ns"].get(c, 0.0) + (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         passes[d] = sorted(seen)
-    res = {"residual_stream": os.environ.get("STREAM_DTYPE", "f16"),   # bench.py --stream-dtype of the profiled command
-           "source": "rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "
+    # what was profiled: taken from the bench line the SAME pass printed (never from the environment) + the kernel-source hash
+    meta = {}
+    for d in dirs:
+        jf = d.rstrip("/") + ".json"
+        if os.path.exists(jf):
+            for ln in open(jf):
+                if ln.startswith('{"metric"'):
+                    cfg = json.loads(ln)
+                    meta = {"residual_stream": cfg["config"]["residual_stream"], "queries": cfg["config"]["queries_per_step_per_gpu"],
+                            "k": cfg["config"]["k"], "subset": cfg["config"]["subset"], "image_size": cfg["config"]["image_size"], "dtype": cfg["dtype"]}
+            break
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    res = {**meta, "csrc_sha16": bench.csrc_sha16(),
+           "source": "rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-precision-table "
                      "(one pass per counter group; all launches of the run incl. warm-up and the instrumented steps)",
            "passes": passes, "by_kernel": {}}
     for k, e in sorted(ker.items()):
