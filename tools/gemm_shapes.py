@@ -28,7 +28,9 @@ def timed(a, w, *args, **kw):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); out = orig(a, w, *args, **kw); e1.record()
     nb = a.shape[0] if a.dim() == 3 else 1
-    recs.append(((nb, a.shape[-2], w.shape[-2], a.shape[-1], kw.get("act", 0), str(out.dtype)[6:], kw.get("residual") is not None), e0, e1))
+    res = kw.get("residual")
+    recs.append(((nb, a.shape[-2], w.shape[-2], a.shape[-1], kw.get("act", 0), str(out.dtype)[6:], res is not None,
+                  None if res is None else str(res.dtype)[6:]), e0, e1))
     return out
 step(); step(); torch.cuda.synchronize()
 ops.gemm = timed
@@ -41,11 +43,12 @@ for key, e0, e1 in recs:
 tot = sum(a[1] for a in agg.values())
 print(f"{'nb':>2} {'M':>7} {'N':>5} {'K':>5} act out      calls   ms_total  us/call   TF/s   share")
 rows = []
-for (nb, m, n, kk, act, od, res), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+for (nb, m, n, kk, act, od, res, rd), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     fl = 2.0 * nb * m * n * kk * c
     print(f"{nb:>2} {m:>7} {n:>5} {kk:>5} {act:>3} {od:8s} {c:>5} {t:>9.2f} {t/c*1e3:>8.1f} {fl/t/1e9:>7.1f} {t/tot:>6.3f}")
     rows.append({"batch": nb, "M": m, "N": n, "K": kk, "act": act, "out": od, "residual": res, "calls_per_step": c,
-                 "kernel": ops.gemm_kernel_name(m, n, kk, nb, res, act, od == "float32", torch.bfloat16),
+                 "kernel": ops.gemm_kernel_name(m, n, kk, nb, res, act, getattr(torch, od), torch.bfloat16,
+                                                res_dtype=None if rd is None else getattr(torch, rd)),
                  "us_per_call": round(t / c * 1e3, 1), "tflops": round(fl / t / 1e9, 1), "frac_of_2516.6": round(fl / t / 1e9 / 2516.6, 4),
                  "share_of_gemm_time": round(t / tot, 4)})
 print("total gemm ms", tot)
