@@ -377,6 +377,149 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const AttnArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// cir_cls_cross_attention - cross-attention of ONE query row per (branch, head) over a candidate's image tokens, with the
+// K and V projections folded out of the token side (last fusion layer: only the two CLS rows reach cls_head,
+// nlvr_encoder.py:906-908, so per candidate there are 2 * H query vectors and N keys):
+//   scores[r][j] = q_r . (W_k x_j + b_k) = (W_k^T q_r) . x_j + const_r      -> qp_r = W_k^T q_r   (a 64 x D GEMM per (branch, head))
+//   ctx_r        = sum_j p[r][j] (W_v x_j + b_v) = W_v (sum_j p[r][j] x_j) + b_v  -> o_r = sum_j p[r][j] x_j   (THIS kernel), then a D x 64 GEMM
+// The constant drops out of the softmax.  The kernel is attention with K = V = the raw tokens (width D = 128 * NO) shared by
+// all R <= 32 query rows: one workgroup of 4 waves per candidate, 32-key token tiles staged once in LDS; wave w owns the
+// k-slice / column slice [w * D/4, (w+1) * D/4): partial S^T tiles are summed through LDS, every wave repeats the (cheap)
+// online softmax, and accumulates its 32 x D/4 slice of O^T with transposed LDS reads of the same tile.  HBM-bound on the
+// token tensor (read once) instead of the 4 D x D projection of every token of the layer.
+template <typename T, int NO>
+__global__ __launch_bounds__(256, 2) void cls_xattn_kernel(const T* __restrict__ x, int64_t x_s1, const T* __restrict__ qp, T* __restrict__ out,
+                                                           int Lk, float scale) {
+    using X8 = typename Elem<T>::x8;
+    constexpr int D = 128 * NO, SL = 32 * NO;            // token width, columns (= k-slice) per wave
+    constexpr int RS = D * 2 + 16;                         // padded LDS row: consecutive keys 4 banks apart
+    constexpr int CH = D / 8;                              // 16-byte chunks per token row
+    constexpr int PER = (32 * CH + 255) / 256;             // staging chunks per thread and tile
+    __shared__ __attribute__((aligned(16))) char xs[32 * RS];
+    __shared__ __attribute__((aligned(16))) float exch[4][16][64];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int64_t t = blockIdx.x;
+    const T* xb = x + t * x_s1;
+    const T* qb = qp + t * (32 * D);
+    T* ob = out + t * (32 * D);
+    const int nkt = (Lk + 31) >> 5;
+
+    // Q' fragments of this wave's k-slice: B operand of S^T = X_tile * Q'^T (column = query row r, 8 consecutive k per lane)
+    X8 qf[2 * NO];
+#pragma unroll
+    for (int ks = 0; ks < 2 * NO; ++ks) qf[ks] = *reinterpret_cast<const X8*>(qb + r * D + wave * SL + 16 * ks + 8 * hh);
+
+    X8 stage[PER];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = threadIdx.x + i * 256;
+            const int row = c / CH, ch = c - row * CH;
+            if (c < 32 * CH) stage[i] = *reinterpret_cast<const X8*>(xb + (int64_t)min(kt * 32 + row, Lk - 1) * D + ch * 8);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = threadIdx.x + i * 256;
+            const int row = c / CH, ch = c - row * CH;
+            if (c < 32 * CH) *reinterpret_cast<X8*>(xs + row * RS + ch * 16) = stage[i];
+        }
+    };
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 o[NO];
+#pragma unroll
+    for (int dt = 0; dt < NO; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+    const float sl = scale * kLog2e;
+    // transposed-read lane offset inside a 4-key x 16-column block (see tr_lane_offset), for this tile's row stride
+    const int i16 = lane & 15;
+    const int troff = (4 * hh + (i16 >> 2)) * RS + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2 + wave * SL * 2;
+
+    load_tile(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();                                   // every wave is done with the previous tile
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < nkt) load_tile(kt + 1);               // next tile in flight under this tile's arithmetic
+        // ---- partial S^T over this wave's k-slice ----
+        f32x16 s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2 * NO; ++ks) {
+            const X8 kf = *reinterpret_cast<const X8*>(xs + r * RS + (wave * SL + 16 * ks + 8 * hh) * 2);
+            s = Elem<T>::mfma32(kf, qf[ks], s);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) exch[wave][i][lane] = s[i];
+        __syncthreads();
+        float sv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sv[i] = exch[0][i][lane] + exch[1][i][lane] + exch[2][i][lane] + exch[3][i][lane];
+        // ---- online softmax (log2 domain; lane = query row r, 16 of the tile's 32 keys) ----
+        const int key0 = kt * 32;
+        if (key0 + 32 > Lk) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sv[i] = (key0 + (i & 3) + 8 * (i >> 2) + 4 * hh) < Lk ? sv[i] : -INFINITY;
+        }
+        float mx = sv[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sv[i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sl;
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            sv[i] = __builtin_amdgcn_exp2f(fmaf(sv[i], sl, -m_new));
+            psum += sv[i];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        X8 pf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[s2][j] = static_cast<T>(sv[8 * s2 + j]);
+        // ---- O^T slice += X_tile^T * P^T ----
+#pragma unroll
+        for (int dt = 0; dt < NO; ++dt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const char* base = xs + troff + dt * 64 + (16 * s2) * RS;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + 8 * RS));
+                s16x8 both;
+                both.s0 = lo.x; both.s1 = lo.y; both.s2 = lo.z; both.s3 = lo.w;
+                both.s4 = hi.x; both.s5 = hi.y; both.s6 = hi.z; both.s7 = hi.w;
+                o[dt] = Elem<T>::mfma32(__builtin_bit_cast(X8, both), pf[s2], o[dt]);
+            }
+        }
+    }
+    const float inv = 1.0f / l_run;
+    T* op = ob + r * D + wave * SL + 4 * hh;
+#pragma unroll
+    for (int dt = 0; dt < NO; ++dt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            u32x2 p;
+            p.x = pack2<T>(o[dt][qd * 4 + 0] * inv, o[dt][qd * 4 + 1] * inv);
+            p.y = pack2<T>(o[dt][qd * 4 + 2] * inv, o[dt][qd * 4 + 3] * inv);
+            *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * qd) = p;
+        }
+}
+
 }  // namespace cir
 
 extern "C" int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t q_rs, const void* k, int64_t k_s1,
@@ -433,5 +576,25 @@ extern "C" int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t 
     const bool mk = mask != nullptr;
     if (dtype == CIR_BF16) { if (mk) hipLaunchKernelGGL((attn_stream_kernel<__bf16, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((attn_stream_kernel<__bf16, false>), grid, block, 0, s, a); }
     else { if (mk) hipLaunchKernelGGL((attn_stream_kernel<_Float16, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((attn_stream_kernel<_Float16, false>), grid, block, 0, s, a); }
+    CIR_LAUNCH_RESULT();
+}
+
+extern "C" int cir_cls_cross_attention(const void* x, int64_t x_s1, const void* qp, void* out, int T, int Lk, int D, float scale,
+                                       int dtype, void* stream) {
+    using namespace cir;
+    CIR_CHECK_PTR(x); CIR_CHECK_PTR(qp); CIR_CHECK_PTR(out);
+    if (T <= 0 || Lk <= 0) return CIR_EINVAL;
+    if (D % 128 != 0 || D < 128 || D > 768) return CIR_ESHAPE;
+    if (dtype != CIR_BF16 && dtype != CIR_F16) return CIR_EDTYPE;
+    if (!cir_aligned16(x) || !cir_aligned16(qp) || !cir_aligned16(out) || x_s1 % 8) return CIR_EALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)T), block(256);
+#define CIR_CLSX(TT, NO) hipLaunchKernelGGL((cls_xattn_kernel<TT, NO>), grid, block, 0, s, reinterpret_cast<const TT*>(x), x_s1, \
+                                            reinterpret_cast<const TT*>(qp), reinterpret_cast<TT*>(out), Lk, scale)
+#define CIR_CLSX_NO(TT) switch (D / 128) { case 1: CIR_CLSX(TT, 1); break; case 2: CIR_CLSX(TT, 2); break; case 3: CIR_CLSX(TT, 3); break; \
+                                            case 4: CIR_CLSX(TT, 4); break; case 5: CIR_CLSX(TT, 5); break; default: CIR_CLSX(TT, 6); break; }
+    if (dtype == CIR_BF16) { CIR_CLSX_NO(__bf16) } else { CIR_CLSX_NO(_Float16) }
+#undef CIR_CLSX_NO
+#undef CIR_CLSX
     CIR_LAUNCH_RESULT();
 }

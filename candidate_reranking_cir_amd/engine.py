@@ -206,6 +206,7 @@ class NlvrEngine:
         self.geo, self.dtype, self.device, self.fold_merge, self.stream_dtype = geo, dtype, device, fold_merge, _auto_stream(dtype, stream_dtype)
         self.trim_last = True   # last layer: per-token work on the CLS rows only (results identical for the rows that are used)
         self.kv_chunk = 0       # candidates per K|V + cross-attention chunk (0 = all at once; attribute, for A/B runs)
+        self.fold_cls_kv = True  # last layer: fold the cross K / V projections out of the token side (False: K|V GEMM + attention)
         e = prefix + "embeddings."
         self.word, self.posemb = _f32(sd[e + "word_embeddings.weight"], device), _f32(sd[e + "position_embeddings.weight"], device)
         self.ge, self.be = _f32(sd[e + "LayerNorm.weight"], device), _f32(sd[e + "LayerNorm.bias"], device)
@@ -255,6 +256,19 @@ class NlvrEngine:
             ly["g3"] = _f32(sd[p + "output.LayerNorm.weight"], device)
             ly["b3"] = _f32(sd[p + "output.LayerNorm.bias"], device)
             self.layers.append(ly)
+        # Last layer, CLS rows only: the cross K / V projections fold out of the token side (cir_cls_cross_attention) -
+        # per (branch, head) W_k^T as a (Dv, 64) GEMM weight for q -> qp, W_v rows as a (64, Dv) one for sum_j p_j x_j -> ctx
+        h_n, dv = geo.num_attention_heads, geo.encoder_width
+        self.cls_fold = None
+        if geo.num_hidden_layers > 1 and 2 * h_n <= 32 and dv % 128 == 0 and dv <= 768 and d == h_n * 64:
+            p = f"{prefix}encoder.layer.{geo.num_hidden_layers - 1}.crossattention."
+            wk = [sd[p + f"self{b}.key.weight"].detach().float() for b in (0, 1)]                    # (D, Dv)
+            wv = [sd[p + f"self{b}.value.weight"].detach().float() for b in (0, 1)]
+            bv = [sd[p + f"self{b}.value.bias"].detach().float() for b in (0, 1)]
+            self.cls_fold = dict(
+                wkt=[_w16(w.view(h_n, 64, dv).transpose(1, 2).contiguous(), dtype, device) for w in wk],   # (H, Dv, 64) per branch
+                wv=_w16(torch.cat(wv).view(2 * h_n, 64, dv), dtype, device),                               # (2H, 64, Dv)
+                bv=_f32(torch.cat(bv).view(2 * h_n, 64), device), qp={})
         self.wc0, self.bc0 = _w16(sd["cls_head.0.weight"], dtype, device), _f32(sd["cls_head.0.bias"], device)
         self.wc2, self.bc2 = _w16(sd["cls_head.2.weight"], dtype, device), _f32(sd["cls_head.2.bias"], device)
 
@@ -336,7 +350,19 @@ class NlvrEngine:
                 a32, a16 = self._self_block(ly, h32, h16, t_n, l, smask)
             qc = ops.gemm(a16, ly["wq"], ly["bq"]).view(2, t_n, lq, d).permute(1, 0, 2, 3)              # (T, 2, Lq, D) view
             ccl = cc if not cls_only else torch.empty((t_n, 1, 2, d), dtype=dt, device=cc.device)
-            if kv_bank is None:
+            if cls_only and kv_bank is None and emask is None and self.cls_fold is not None and self.fold_cls_kv:
+                # one query row per (branch, head): scores = (W_k^T q) . x_j, context = W_v (sum_j p_j x_j) + b_v - the
+                # 4 D x Dv projection of all T * N candidate tokens of this layer is never formed (nlvr_encoder.py:321-344)
+                f, h_n, dv = self.cls_fold, geo.num_attention_heads, cand16.shape[2]
+                qp = f["qp"].get(t_n)
+                if qp is None:                                                                            # rows >= 2H stay zero
+                    qp = f["qp"][t_n] = torch.zeros((t_n, 32, dv), dtype=dt, device=cc.device)
+                q2 = qc.permute(1, 0, 2, 3).reshape(2, t_n, h_n, 64)                                      # view of the (2, T, D) GEMM result
+                for b in (0, 1):
+                    ops.gemm(q2[b].permute(1, 0, 2), f["wkt"][b], None, out=qp[:, b * h_n:(b + 1) * h_n, :].permute(1, 0, 2))
+                o = ops.cls_cross_attention(cand16, qp, scale)
+                ops.gemm(o[:, :2 * h_n, :].permute(1, 0, 2), f["wv"], f["bv"], out=ccl.view(t_n, 2 * h_n, 64).permute(1, 0, 2))
+            elif kv_bank is None:
                 # K|V projection + cross-attention, optionally in candidate chunks (`kv_chunk`; measured: no gain from
                 # keeping a chunk's K|V in the Infinity Cache, so the default is one launch each)
                 step_c = self.kv_chunk if self.kv_chunk > 0 else t_n

@@ -163,6 +163,22 @@ def test_attention_guard_bands(ops, dtype, lq, lk):
     guard.assert_intact(f"attention {lq}x{lk}")
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "fp16"])
+@pytest.mark.parametrize("t,n,d", [(3, 5, 128), (7, 197, 768), (600, 40, 256)])
+def test_cls_cross_attention_guard_bands(ops, dtype, t, n, d):
+    """cir_cls_cross_attention writes exactly T x 32 x D elements: canaries before and after the result stay intact, and
+    reading past the last token row (clamped ragged tiles) never shows up in the result."""
+    g = torch.Generator(device="cpu").manual_seed(t + n)
+    x = torch.randn((t, n, d), generator=g).to(dtype).cuda()
+    qp = (torch.randn((t, 32, d), generator=g) * 0.3).to(dtype).cuda()
+    buf, out = _flat_guard(t * 32 * d, dtype)
+    ops.cls_cross_attention(x, qp, 0.125, out=out.view(t, 32, d))
+    torch.cuda.synchronize()
+    ref = torch.softmax(torch.einsum("trd,tnd->trn", qp.float(), x.float()) * 0.125, -1) @ x.float()
+    torch.testing.assert_close(out.view(t, 32, d).float(), ref, atol=1.5e-2 if dtype == torch.bfloat16 else 2e-3, rtol=0)
+    assert _flat_intact(buf, t * 32 * d, dtype)
+
+
 # ------------------------------------------------------------------------------------------------ row kernels
 def _flat_guard(n_elems, dtype, slack=4096):
     buf = torch.empty((n_elems + 2 * slack,), dtype=dtype, device="cuda")

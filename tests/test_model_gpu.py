@@ -438,6 +438,29 @@ def test_vit_large_width(cuda, dtype):
     assert y32.shape == (3, 197, 1024) and err < TOK_TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", [BF, HF], ids=["bf16", "fp16"])
+def test_last_layer_kv_fold_matches_projected_path(cuda, dtype):
+    """The last fusion layer with the cross K / V projections folded out of the token side (cir_cls_cross_attention + two
+    small GEMMs per branch) against the same layer through the K|V GEMM + attention (`fold_cls_kv = False`): same logits
+    within the operand rounding - and both within the fixture's bound of the reference."""
+    z = H.load("full224.npz")
+    g, v = H.geometry(H.FULL_BERT, dict(image_size=224))
+    m2, m1 = build_models(g, v, int(z["seed"]), str(z["profile"]), dtype, cuda)
+    k = int(z["k"])
+    feats = m2.img_embed(synthetic.images(range(k + 1), 224).cuda())
+    cap = [synthetic.caption_text(0, 30)]
+    zt = m1.img_txt_fusion(feats[:1], None, cap, train=False, return_raw=True)
+    eng = m2.engines()[1]
+    assert eng.cls_fold is not None and eng.fold_cls_kv
+    a = m2.img_txt_fusion_val(zt, feats[1:], cap).cpu().numpy()
+    eng.fold_cls_kv = False
+    b = m2.img_txt_fusion_val(zt, feats[1:], cap).cpu().numpy()
+    eng.fold_cls_kv = True
+    tol = LOGIT_TOL["full224"][dtype]
+    print(f"\n[last-layer K/V fold {dtype}] folded vs projected {np.abs(a - b).max():.3e}; vs reference {np.abs(a - z['logits']).max():.3e} / {np.abs(b - z['logits']).max():.3e}")
+    assert np.abs(a - b).max() < tol and np.abs(a - z["logits"]).max() < tol and np.abs(b - z["logits"]).max() < tol
+
+
 def test_edge_cases_k1_all_skipped_empty_and_long_caption(tiny):
     """Edges the reference's loop handles explicitly: K == 1 (its `unsqueeze` special case, validate_stage2.py:247-250),
     a dataset whose every row is skipped, an empty shard, B = 1 in the B x B surface, and a caption longer than the

@@ -371,3 +371,45 @@ def test_vit_assemble_and_embed_stream16(ops):
     torch.cuda.synchronize()
     torch.testing.assert_close(ys.float(), refe.half().float(), atol=1e-3, rtol=1e-3)
     torch.testing.assert_close(y16.float(), refe.bfloat16().float(), atol=1e-3, rtol=8e-3)
+
+
+# ------------------------------------------------------------------------------------------------ CLS cross-attention (K / V folded out)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("t,n,d", [(1, 1, 128), (3, 17, 128), (5, 197, 768), (2, 577, 768), (4, 33, 256), (300, 70, 384)])
+def test_cls_cross_attention_matches_fp32_torch(ops, dtype, t, n, d):
+    """out[t, r] = sum_j softmax_j(qp[t, r] . x[t, j] * scale) x[t, j] for 32 query rows per item (cir_cls_cross_attention):
+    ragged key counts (one key, < one tile, several tiles), every supported width class, more items than CUs x 2."""
+    g = torch.Generator(device="cpu").manual_seed(t * 31 + n)
+    x = torch.randn((t, n, d), generator=g).to(dtype).cuda()
+    qp = (torch.randn((t, 32, d), generator=g) * 0.3).to(dtype).cuda()
+    out = ops.cls_cross_attention(x, qp, 0.125)
+    torch.cuda.synchronize()
+    s = torch.einsum("trd,tnd->trn", qp.float(), x.float()) * 0.125
+    ref = torch.softmax(s, -1) @ x.float()
+    assert out.shape == (t, 32, d) and out.dtype == dtype
+    torch.testing.assert_close(out.float(), ref, atol=1.5e-2 if dtype == torch.bfloat16 else 2e-3, rtol=0)
+
+
+def test_cls_cross_attention_equals_projected_attention(ops):
+    """The identity the last fusion layer relies on: attention over K = x W_k^T + b_k, V = x W_v^T + b_v with ONE query row
+    per head equals W_v (sum_j p_j x_j) + b_v with p from (W_k^T q) . x_j - the key bias drops out of the softmax."""
+    dtype, t, n, d, h = torch.float16, 6, 197, 768, 12
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn((t, n, d), generator=g).to(dtype).cuda()
+    q = torch.randn((t, d), generator=g).to(dtype).cuda()
+    wk, wv = ((torch.randn((d, d), generator=g) * 0.03).to(dtype).cuda() for _ in range(2))
+    bk, bv = (torch.randn((d,), generator=g).cuda() * 0.5 for _ in range(2))
+    # reference: projected K / V through the ordinary operators
+    k = ops.gemm(x.view(t * n, d), wk, bk).view(t, 1, n, d)
+    v = ops.gemm(x.view(t * n, d), wv, bv).view(t, 1, n, d)
+    ctx = torch.empty((t, 1, 1, d), dtype=dtype, device="cuda")
+    ops.attention(q.view(t, 1, 1, d), k, v, ctx, 0.125)
+    # folded: qp[t, head] = W_k[head rows]^T q[t, head slice]; out rows -> W_v[head rows] (.) + b_v
+    qp = torch.zeros((t, 32, d), dtype=dtype, device="cuda")
+    wkt = wk.view(h, 64, d).transpose(1, 2).contiguous()
+    ops.gemm(q.view(t, h, 64).permute(1, 0, 2), wkt, None, out=qp[:, :h, :].permute(1, 0, 2))
+    o = ops.cls_cross_attention(x, qp, 0.125)
+    folded = torch.empty((t, d), dtype=dtype, device="cuda")
+    ops.gemm(o[:, :h, :].permute(1, 0, 2), wv.view(h, 64, d), bv.view(h, 64), out=folded.view(t, h, 64).permute(1, 0, 2))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(folded.float(), ctx.view(t, d).float(), atol=4e-3, rtol=0)
