@@ -32,8 +32,8 @@
 //     ~520 cycles of issue) and 3.5 waves per SIMD cover only half of it (VALU busy 48 %, matrix pipe 19 %).
 //   * v_permlane32_swap for the two half-wave exchanges instead of ds_bpermute: no change in time (and hipcc folds
 //     max(r.x, r.y) of the builtin's two results into one of them when both inputs are the same register: wrong values).
-// What would move it is a second independent chain per wave (two key tiles per update: +40 registers, i.e. 3 waves per
-// SIMD) - not built.
+//   * two key tiles per update (one running-max / rescale / exchange step per 64 keys, two independent score chains, +24
+//     registers = exactly the 128 that keep 4 waves per SIMD, 2 spilled): 689 us - slower.
 
 #include "common.hpp"
 
