@@ -529,7 +529,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                         dd[j] = __builtin_bit_cast(u32x4, o);
                     }
                 }
-                if (!OUT_F32 && !HAS_RES && full) {   // (with a residual the burst of scalar-base stores measured 3-8 % slower than the paced path below)
+                if (!OUT_F32 && full) {   // (also with a residual: +1-2.5 % on proj / fc2; fetching the residual the same way - scalar row base + lane offset - measured 3-8 % slower than the per-lane addresses of LOAD_RES and was dropped)
                     // interior tile: wave-uniform row base (SGPR pair, scalar adds) + the lane's tile-invariant 32-bit byte offset
                     // (one statement, closed by wait states: a store wider than 64 bits reads its data registers up to two cycles after
                     //  issue, and the hazard recogniser does not see inline asm - the next VALU write could land in dd first)
