@@ -1,26 +1,29 @@
 #!/bin/bash
-# Secondary-configuration bench lines, per-shape GEMM table, clock probe (GPU box; run through gpurun from the repo root):
-#   bash tools/collect_secondary.sh r2   -> gpurun_out/<tag>_sec/*.json|txt   (copy what is judged into profiles/)
-TAG=${1:-r2}
+# Secondary-configuration bench lines, per-shape GEMM table, stand-alone kernel timings (GPU box; run through gpurun from
+# the repo root):   bash tools/collect_secondary.sh r3   -> gpurun_out/<tag>_sec/*.json|txt   (copy what is judged into profiles/)
+set -uo pipefail
+TAG=${1:-r3}
 O=gpurun_out/${TAG}_sec
 mkdir -p $O
-python bench.py --steps 20 --warmup 3 > $O/bench_default_20steps.json 2> $O/err.txt
-python bench.py --steps 300 --warmup 5 --no-cpu-baseline > $O/bench_steady_300steps.json 2>> $O/err.txt
-python bench.py --steps 20 --warmup 3 --skip-rate 0.25 --no-cpu-baseline > $O/bench_skip025.json 2>> $O/err.txt
-python bench.py --k 50 --subset 0 --queries 32 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_k50_fiq.json 2>> $O/err.txt
-python bench.py --k 200 --dtype f16 --queries 8 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_k200_f16.json 2>> $O/err.txt
-python bench.py --dtype f16 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_k100_f16.json 2>> $O/err.txt
-python bench.py --image-size 384 --queries 6 --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_384px.json 2>> $O/err.txt
-python bench.py --mode bank --steps 20 --warmup 3 > $O/bench_bank_mode.json 2>> $O/err.txt
-Q=16 python tools/gemm_shapes.py $O/gemm_shapes.json > $O/gemm_shapes.txt 2>> $O/err.txt
-python tools/clock_probe.py > $O/clock_probe.txt 2>> $O/err.txt
+python bench.py --steps 20 --warmup 5 > $O/bench_default_20steps.json 2> $O/err.txt                                   # the driver's command
+python bench.py --steps 80 --warmup 5 --no-cpu-baseline --no-precision-table > $O/bench_steady_80steps.json 2>> $O/err.txt
+python bench.py --queries 16 --steps 20 --warmup 5 --no-cpu-baseline --no-precision-table > $O/bench_q16.json 2>> $O/err.txt   # round 2's step size
+python bench.py --steps 10 --warmup 3 --skip-rate 0.25 --no-cpu-baseline --no-precision-table > $O/bench_skip025.json 2>> $O/err.txt
+python bench.py --k 50 --subset 0 --steps 10 --warmup 3 --no-cpu-baseline --no-precision-table > $O/bench_k50_fiq.json 2>> $O/err.txt
+python bench.py --k 200 --dtype f16 --queries 32 --steps 10 --warmup 3 --no-cpu-baseline --no-precision-table > $O/bench_k200_f16.json 2>> $O/err.txt
+python bench.py --image-size 384 --queries 16 --steps 6 --warmup 2 --no-cpu-baseline --no-precision-table > $O/bench_384px.json 2>> $O/err.txt
+python bench.py --mode bank --steps 10 --warmup 3 > $O/bench_bank_mode.json 2>> $O/err.txt
+python bench.py --mode loop > $O/bench_loop_mode.json 2>> $O/err.txt
+Q=64 python tools/gemm_shapes.py $O/gemm_shapes.json > $O/gemm_shapes.txt 2>> $O/err.txt
+python tools/gemm_ab.py > $O/gemm_ab.txt 2>> $O/err.txt
 python tools/attn_bench.py > $O/attn_bench.txt 2>> $O/err.txt
+python tools/cls_xattn_check.py > $O/cls_xattn.txt 2>> $O/err.txt
 rocminfo | grep -E "Marketing Name|Max Clock|Compute Unit|gfx" > $O/rocminfo.txt
 for f in $O/bench_*.json; do python - "$f" <<'PY'
 import json, sys
 try:
-    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    print(sys.argv[1].split('/')[-1], d["value"], d["unit"], "ms/step", d["ms_per_step"], "path frac", d.get("path_frac_of_mfma_peak"))
+    d = json.loads([l for l in open(sys.argv[1]).read().strip().splitlines() if l.startswith("{")][-1])
+    print(sys.argv[1].split('/')[-1], d["value"], d["unit"], "ms/step", d.get("ms_per_step"), "path frac", d.get("path_frac_of_mfma_peak"))
 except Exception as e:
     print(sys.argv[1], "ERR", e)
 PY
