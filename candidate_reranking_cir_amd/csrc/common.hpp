@@ -123,6 +123,47 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     return x * r;
 }
 
+// eight GELUs as FOUR interleaved packed chains, stage by stage (a scheduling barrier between the stages keeps the compiler
+// from re-serialising them to save registers): in the GEMM epilogue every stage of gelu_erf2 depends on the one before, so
+// one pair at a time issues at the dependent-op latency plus the packed-fp32 / transcendental hazard wait states (388 s_nop
+// in the GELU epilogue before); four independent pairs per stage fill those slots.
+__device__ __forceinline__ void gelu_erf8(float (&v)[8]) {
+    f32x2 x[4], xc[4], t[4], p[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = f32x2{v[2 * j], v[2 * j + 1]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { xc[j].x = __builtin_amdgcn_fmed3f(x[j].x, -5.5f, 5.5f); xc[j].y = __builtin_amdgcn_fmed3f(x[j].y, -5.5f, 5.5f); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = xc[j] * xc[j];
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x2 c3 = {-2.48362952e-05f, -2.48362952e-05f}, c2 = {-7.36062896e-04f, -7.36062896e-04f};
+    const f32x2 c1 = {1.05982735e-01f, 1.05982735e-01f}, c0 = {2.30164715e+00f, 2.30164715e+00f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = __builtin_elementwise_fma(t[j], c3, c2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = __builtin_elementwise_fma(t[j], p[j], c1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = __builtin_elementwise_fma(t[j], p[j], c0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = xc[j] * p[j];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { t[j].x = __builtin_amdgcn_exp2f(-t[j].x); t[j].y = __builtin_amdgcn_exp2f(-t[j].y); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = t[j] + 1.0f;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { t[j].x = __builtin_amdgcn_rcpf(t[j].x); t[j].y = __builtin_amdgcn_rcpf(t[j].y); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const f32x2 y = x[j] * t[j]; v[2 * j] = y.x; v[2 * j + 1] = y.y; }
+}
+
 // bijective XCD remap: consecutive "logical" ids land on one XCD (blocks b and b+8 share an XCD)
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int q = nblk >> 3, r = nblk & 7, x = bid & 7;

@@ -453,10 +453,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                         _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) v[ni * 4 + jj] = acc[(PS) / (NPASS / 2)][mi][nh][ni][jj]; \
                     const int act_ = ACT >= 0 ? ACT : a.act;                                                                 \
                     if (act_ == CIR_ACT_GELU) {                                                                              \
-                        _Pragma("unroll") for (int q = 0; q < 8; q += 2) {                                                   \
-                            const f32x2 y = gelu_erf2(f32x2{v[q], v[q + 1]});                                                \
-                            v[q] = y.x; v[q + 1] = y.y;                                                                      \
-                        }                                                                                                    \
+                        gelu_erf8(v);   /* four interleaved packed chains */                                                 \
                     } else if (act_ == CIR_ACT_RELU) {                                                                       \
                         _Pragma("unroll") for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);                               \
                     }                                                                                                        \
