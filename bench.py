@@ -229,7 +229,7 @@ def bank_mode(args, m2, m1, dev, dt, rank, world):
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{q_n} queries x {k} candidates per step drawn from a resident bank of {n_idx} index images "
                                    f"({n_tok} tokens): cached ViT tokens + 12-layer cross-attention K/V", "index_size": n_idx,
-                       "bank_bytes": int(bank.numel() * 2 + sum(t.numel() for t in kvb) * 2),
+                       "bank_bytes": int(bank.numel() * 2 + sum(t.numel() for t in kvb if t is not None) * 2),
                        "one_off_index_vit_s": round(t_vit, 3), "one_off_kv_bank_s": round(t_kv, 3)}}), flush=True)
 
 

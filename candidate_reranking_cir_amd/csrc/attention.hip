@@ -390,8 +390,8 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const AttnArgs a) {
 // online softmax, and accumulates its 32 x D/4 slice of O^T with transposed LDS reads of the same tile.  HBM-bound on the
 // token tensor (read once) instead of the 4 D x D projection of every token of the layer.
 template <typename T, int NO>
-__global__ __launch_bounds__(256, 2) void cls_xattn_kernel(const T* __restrict__ x, int64_t x_s1, const T* __restrict__ qp, T* __restrict__ out,
-                                                           int Lk, float scale) {
+__global__ __launch_bounds__(256, 2) void cls_xattn_kernel(const T* __restrict__ x, int64_t x_s1, const int64_t* __restrict__ x_index,
+                                                           const T* __restrict__ qp, T* __restrict__ out, int Lk, float scale) {
     using X8 = typename Elem<T>::x8;
     constexpr int D = 128 * NO, SL = 32 * NO;            // token width, columns (= k-slice) per wave
     constexpr int RS = D * 2 + 16;                         // padded LDS row: consecutive keys 4 banks apart
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void cls_xattn_kernel(const T* __restrict__
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int64_t t = blockIdx.x;
-    const T* xb = x + t * x_s1;
+    const T* xb = x + (x_index ? x_index[t] : t) * x_s1;     // optional gather: item t attends the tokens of bank row x_index[t]
     const T* qb = qp + t * (32 * D);
     T* ob = out + t * (32 * D);
     const int nkt = (Lk + 31) >> 5;
@@ -579,8 +579,8 @@ extern "C" int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t 
     CIR_LAUNCH_RESULT();
 }
 
-extern "C" int cir_cls_cross_attention(const void* x, int64_t x_s1, const void* qp, void* out, int T, int Lk, int D, float scale,
-                                       int dtype, void* stream) {
+extern "C" int cir_cls_cross_attention(const void* x, int64_t x_s1, const int64_t* x_index, const void* qp, void* out, int T, int Lk, int D,
+                                       float scale, int dtype, void* stream) {
     using namespace cir;
     CIR_CHECK_PTR(x); CIR_CHECK_PTR(qp); CIR_CHECK_PTR(out);
     if (T <= 0 || Lk <= 0) return CIR_EINVAL;
@@ -589,7 +589,7 @@ extern "C" int cir_cls_cross_attention(const void* x, int64_t x_s1, const void* 
     if (!cir_aligned16(x) || !cir_aligned16(qp) || !cir_aligned16(out) || x_s1 % 8) return CIR_EALIGN;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((unsigned)T), block(256);
-#define CIR_CLSX(TT, NO) hipLaunchKernelGGL((cls_xattn_kernel<TT, NO>), grid, block, 0, s, reinterpret_cast<const TT*>(x), x_s1, \
+#define CIR_CLSX(TT, NO) hipLaunchKernelGGL((cls_xattn_kernel<TT, NO>), grid, block, 0, s, reinterpret_cast<const TT*>(x), x_s1, x_index, \
                                             reinterpret_cast<const TT*>(qp), reinterpret_cast<TT*>(out), Lk, scale)
 #define CIR_CLSX_NO(TT) switch (D / 128) { case 1: CIR_CLSX(TT, 1); break; case 2: CIR_CLSX(TT, 2); break; case 3: CIR_CLSX(TT, 3); break; \
                                             case 4: CIR_CLSX(TT, 4); break; case 5: CIR_CLSX(TT, 5); break; default: CIR_CLSX(TT, 6); break; }

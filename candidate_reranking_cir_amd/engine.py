@@ -123,6 +123,13 @@ class VitEngine:
 
 
 # =================================================================================================
+class KVBank(list):
+    """Per-layer cross-attention K|V of an index-feature bank: entry i is (n_index, N, 4D) - or None for
+    the last layer when its K / V projections are folded out of the token side, which then reads `tokens` (the 16-bit
+    index features themselves) through cir_cls_cross_attention's row index."""
+    tokens: Optional[torch.Tensor] = None
+
+
 def _cat(sd: SD, keys, suffix: str) -> torch.Tensor:
     return torch.cat([sd[k + suffix].detach().float() for k in keys], dim=0)
 
@@ -291,12 +298,17 @@ class NlvrEngine:
         across 1e5-1e6 candidate slots, and 288 GB of HBM holds the whole bank (CIRR val at 384 px: 98 GB)."""
         n_idx, n, dv = bank16.shape
         d = self.geo.hidden_size
-        out = []
-        for ly in self.layers:
+        out = KVBank()
+        out.tokens = bank16
+        last = len(self.layers) - 1
+        for i, ly in enumerate(self.layers):
+            if i == last and self.trim_last and last > 0 and self.cls_fold is not None and self.fold_cls_kv:
+                out.append(None)            # the folded last layer attends the raw tokens: no K|V of this layer is ever formed
+                continue
             kv = torch.empty((n_idx, n, 4 * d), dtype=self.dtype, device=bank16.device)
-            for i in range(0, n_idx, chunk):
-                rows = bank16[i:i + chunk].reshape(-1, dv)
-                ops.gemm(rows, ly["wkv"], ly["bkv"], out=kv[i:i + chunk].view(-1, 4 * d))
+            for i0 in range(0, n_idx, chunk):
+                rows = bank16[i0:i0 + chunk].reshape(-1, dv)
+                ops.gemm(rows, ly["wkv"], ly["bkv"], out=kv[i0:i0 + chunk].view(-1, 4 * d))
             out.append(kv)
         return out
 
@@ -350,17 +362,21 @@ class NlvrEngine:
                 a32, a16 = self._self_block(ly, h32, h16, t_n, l, smask)
             qc = ops.gemm(a16, ly["wq"], ly["bq"]).view(2, t_n, lq, d).permute(1, 0, 2, 3)              # (T, 2, Lq, D) view
             ccl = cc if not cls_only else torch.empty((t_n, 1, 2, d), dtype=dt, device=cc.device)
-            if cls_only and kv_bank is None and emask is None and self.cls_fold is not None and self.fold_cls_kv:
+            fold = cls_only and emask is None and self.cls_fold is not None and self.fold_cls_kv and (kv_bank is None or kv_bank[i] is None)
+            if kv_bank is not None and kv_bank[i] is None and not fold:
+                raise ValueError("this K/V bank was built with the last layer folded (no K|V of that layer): rebuild it with fold_cls_kv = False")
+            if fold:
                 # one query row per (branch, head): scores = (W_k^T q) . x_j, context = W_v (sum_j p_j x_j) + b_v - the
                 # 4 D x Dv projection of all T * N candidate tokens of this layer is never formed (nlvr_encoder.py:321-344)
-                f, h_n, dv = self.cls_fold, geo.num_attention_heads, cand16.shape[2]
+                tok = cand16 if kv_bank is None else kv_bank.tokens                                       # (T, N, Dv) or the index bank + row index
+                f, h_n, dv = self.cls_fold, geo.num_attention_heads, tok.shape[2]
                 qp = f["qp"].get(t_n)
                 if qp is None:                                                                            # rows >= 2H stay zero
                     qp = f["qp"][t_n] = torch.zeros((t_n, 32, dv), dtype=dt, device=cc.device)
                 q2 = qc.permute(1, 0, 2, 3).reshape(2, t_n, h_n, 64)                                      # view of the (2, T, D) GEMM result
                 for b in (0, 1):
                     ops.gemm(q2[b].permute(1, 0, 2), f["wkt"][b], None, out=qp[:, b * h_n:(b + 1) * h_n, :].permute(1, 0, 2))
-                o = ops.cls_cross_attention(cand16, qp, scale)
+                o = ops.cls_cross_attention(tok, qp, scale, x_index=None if kv_bank is None else cand_rows)
                 ops.gemm(o[:, :2 * h_n, :].permute(1, 0, 2), f["wv"], f["bv"], out=ccl.view(t_n, 2 * h_n, 64).permute(1, 0, 2))
             elif kv_bank is None:
                 # K|V projection + cross-attention, optionally in candidate chunks (`kv_chunk`; measured: no gain from

@@ -178,18 +178,22 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     return out
 
 
-def cls_cross_attention(x: torch.Tensor, qp: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def cls_cross_attention(x: torch.Tensor, qp: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None,
+                        x_index: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[t, r] = sum_j softmax_j(qp[t, r] . x[t, j] * scale) x[t, j]: x (T, Lk, D) 16-bit tokens (rows contiguous), qp (T, 32, D)
-    contiguous (every row finite) -> out (T, 32, D).  The K / V projections live in the caller's two small GEMMs
-    (include/cirrank.h: cir_cls_cross_attention)."""
-    _need_cuda(x, qp, out)
-    t_n, lk, d = x.shape
+    contiguous (every row finite) -> out (T, 32, D).  With `x_index` (T,) int64, x is a bank (rows, Lk, D) and item t attends
+    bank row x_index[t].  The K / V projections live in the caller's two small GEMMs (include/cirrank.h: cir_cls_cross_attention)."""
+    _need_cuda(x, qp, out, x_index)
+    lk, d = x.shape[1], x.shape[2]
+    t_n = qp.shape[0]
+    assert x_index is not None or x.shape[0] == t_n
+    assert x_index is None or (x_index.dtype == torch.int64 and x_index.shape == (t_n,) and x_index.is_contiguous())
     assert x.stride(2) == 1 and x.stride(1) == d and qp.shape == (t_n, 32, d) and qp.is_contiguous() and qp.dtype == x.dtype
     if out is None:
         out = torch.empty((t_n, 32, d), dtype=x.dtype, device=x.device)
     assert out.shape == (t_n, 32, d) and out.is_contiguous() and out.dtype == x.dtype
-    _lib.check(_lib.load().cir_cls_cross_attention(x.data_ptr(), x.stride(0), qp.data_ptr(), out.data_ptr(), t_n, lk, d, float(scale),
-                                                   _DT[x.dtype], _stream()), "cir_cls_cross_attention")
+    _lib.check(_lib.load().cir_cls_cross_attention(x.data_ptr(), x.stride(0), _ptr(x_index), qp.data_ptr(), out.data_ptr(), t_n, lk, d,
+                                                   float(scale), _DT[x.dtype], _stream()), "cir_cls_cross_attention")
     return out
 
 

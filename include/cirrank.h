@@ -117,14 +117,15 @@ int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t q_rs,
  * Cross-attention of ONE query row per (branch, head) over the tokens of each candidate, K / V projections folded out of
  * the token side (last fusion layer, where only the two CLS rows are used: nlvr_encoder.py:906-908 with :321-344):
  *   out[t][r][:] = sum_j softmax_j(qp[t][r] . x[t][j] * scale) x[t][j]     r < 32 rows, j < Lk keys, width D
- * x (T, Lk, D) 16-bit tokens (item stride x_s1, rows contiguous), qp (T, 32, D) = W_k^T q per row (rows beyond 2H: any
- * finite values), out (T, 32, D).  The caller forms qp with a 64 x D GEMM per (branch, head) and applies W_v (+ b_v) to
+ * x (T, Lk, D) 16-bit tokens (item stride x_s1, rows contiguous; with x_index (T int64, or NULL) item t reads the tokens of
+ * row x_index[t] of an index-feature bank instead - the cross-query reuse of SURVEY section 8(f)-1), qp (T, 32, D) =
+ * W_k^T q per row (rows beyond 2H: any finite values), out (T, 32, D).  The caller forms qp with a 64 x D GEMM per (branch, head) and applies W_v (+ b_v) to
  * `out` with a D x 64 GEMM (cir_gemm_bias_act, batched); the key bias is constant over j and drops out of the softmax.
  * D in {128, 256, .., 768}; no key mask.  Replaces, for that layer, the 4 D x D K|V projection of every candidate token
  * plus BertSelfAttention.forward's cross branch (nlvr_encoder.py:150-168, 183-217).
  */
-int cir_cls_cross_attention(const void* x, int64_t x_s1, const void* qp, void* out, int T, int Lk, int D, float scale,
-                            int dtype, void* stream);
+int cir_cls_cross_attention(const void* x, int64_t x_s1, const int64_t* x_index, const void* qp, void* out, int T, int Lk, int D,
+                            float scale, int dtype, void* stream);
 
 /*
  * BertEmbeddings.forward (nlvr_encoder.py:68-91, med.py:87-110):

@@ -96,10 +96,10 @@ def test_argument_validation_happens_before_any_launch():
     assert c.cir_attention(*bad) == EDTYPE
     assert c.cir_topk_desc(P, P, 1, 9000, None) == ESHAPE and c.cir_topk_desc(None, P, 1, 8, None) == EINVAL
     clsx = c.cir_cls_cross_attention
-    assert clsx(None, 0, P, P, 1, 4, 128, 0.125, BF16, None) == EINVAL and clsx(P, 0, P, P, 0, 4, 128, 0.125, BF16, None) == EINVAL
-    assert clsx(P, 0, P, P, 1, 4, 1024, 0.125, BF16, None) == ESHAPE and clsx(P, 0, P, P, 1, 4, 192, 0.125, BF16, None) == ESHAPE
-    assert clsx(P, 4, P, P, 1, 4, 128, 0.125, BF16, None) == EALIGN and clsx(P, 0, P + 2, P, 1, 4, 128, 0.125, BF16, None) == EALIGN
-    assert clsx(P, 0, P, P, 1, 4, 128, 0.125, F32, None) == EDTYPE
+    assert clsx(None, 0, None, P, P, 1, 4, 128, 0.125, BF16, None) == EINVAL and clsx(P, 0, None, P, P, 0, 4, 128, 0.125, BF16, None) == EINVAL
+    assert clsx(P, 0, None, P, P, 1, 4, 1024, 0.125, BF16, None) == ESHAPE and clsx(P, 0, None, P, P, 1, 4, 192, 0.125, BF16, None) == ESHAPE
+    assert clsx(P, 4, None, P, P, 1, 4, 128, 0.125, BF16, None) == EALIGN and clsx(P, 0, None, P + 2, P, 1, 4, 128, 0.125, BF16, None) == EALIGN
+    assert clsx(P, 0, None, P, P, 1, 4, 128, 0.125, F32, None) == EDTYPE
     # kernel-selection overrides: range-checked, default automatic, and the library reads no environment variables
     assert c.cir_set_tuning(7, 0) == EINVAL and c.cir_set_tuning(0, 64) == EINVAL and c.cir_set_tuning(2, 9000) == EINVAL
     assert c.cir_set_tuning(0, 128) == 0 and c.cir_set_tuning(0, 0) == 0 and c.cir_set_tuning(2, -1) == 0 and c.cir_set_tuning(2, 0) == 0

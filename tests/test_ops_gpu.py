@@ -390,6 +390,19 @@ def test_cls_cross_attention_matches_fp32_torch(ops, dtype, t, n, d):
     torch.testing.assert_close(out.float(), ref, atol=1.5e-2 if dtype == torch.bfloat16 else 2e-3, rtol=0)
 
 
+def test_cls_cross_attention_bank_index(ops):
+    """`x_index`: item t attends row x_index[t] of a token bank - bit-identical to gathering the rows first."""
+    dtype = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(9)
+    bank = torch.randn((11, 70, 256), generator=g).to(dtype).cuda()
+    idx = torch.tensor([3, 3, 10, 0, 7, 1], dtype=torch.int64).cuda()
+    qp = (torch.randn((6, 32, 256), generator=g) * 0.3).to(dtype).cuda()
+    a = ops.cls_cross_attention(bank, qp, 0.125, x_index=idx)
+    b = ops.cls_cross_attention(bank[idx].contiguous(), qp, 0.125)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+
+
 def test_cls_cross_attention_equals_projected_attention(ops):
     """The identity the last fusion layer relies on: attention over K = x W_k^T + b_k, V = x W_v^T + b_v with ONE query row
     per head equals W_v (sum_j p_j x_j) + b_v with p from (W_k^T q) . x_j - the key bias drops out of the softmax."""
