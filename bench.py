@@ -144,7 +144,7 @@ class ClockSampler:
 
     def __init__(self, index: int):
         import ctypes
-        self.sclk, self.power, self._stop, self.index = [], [], None, index
+        self.sclk, self.power, self._stop, self.index, self.mapping = [], [], None, index, None
         self.lib = None
         try:
             class Freqs(ctypes.Structure):
@@ -154,7 +154,22 @@ class ClockSampler:
             lib = ctypes.CDLL("librocm_smi64.so")
             if lib.rsmi_init(ctypes.c_uint64(0)) == 0:
                 self.lib = lib
-        except OSError:
+                # ROCm-SMI enumerates every physical GPU and ignores HIP_VISIBLE_DEVICES: find the SMI index of the HIP device
+                # that is being timed by its PCI address (BDFID = domain << 32 | bus << 8 | device << 3 | function)
+                p = torch.cuda.get_device_properties(index)
+                want = (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", None), getattr(p, "pci_device_id", None))
+                n = ctypes.c_uint32(0)
+                if want[1] is not None and lib.rsmi_num_monitor_devices(ctypes.byref(n)) == 0:
+                    for i in range(n.value):
+                        bdf = ctypes.c_uint64(0)
+                        if lib.rsmi_dev_pci_id_get(ctypes.c_uint32(i), ctypes.byref(bdf)) == 0:
+                            got = ((bdf.value >> 32) & 0xffffffff, (bdf.value >> 8) & 0xff, (bdf.value >> 3) & 0x1f)
+                            if got == want:
+                                self.index, self.mapping = i, "hip device %d = rocm-smi device %d (pci %04x:%02x:%02x)" % (index, i, *got)
+                                break
+                if self.mapping is None:
+                    self.mapping = "hip ordinal used as the rocm-smi index (no PCI match found)"
+        except (OSError, AttributeError):
             pass
 
     def _sample(self):
@@ -187,6 +202,7 @@ class ClockSampler:
     def summary(self):
         med = lambda v: round(sorted(v)[len(v) // 2], 1) if v else None
         return {"sclk_mhz_under_load_median": med(self.sclk), "socket_power_w_median": med(self.power), "samples": len(self.sclk),
+                "smi_device": self.mapping,
                 "source": "librocm_smi64 (rsmi_dev_gpu_clk_freq_get SYS / rsmi_dev_current_socket_power_get) every 0.2 s during the timed region"}
 
 

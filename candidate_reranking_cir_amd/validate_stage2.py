@@ -138,6 +138,12 @@ def generate_val_predictions(blip_model, model_stage1, ds: RelativeValSet, index
             for row, which, n in slots:
                 (glogits if which else logits)[row] = out[o:o + n]
                 o += n
+    # One check at the end (a device reduction, no per-batch synchronisation): the fp16-stored residual stream has fp16's range;
+    # a checkpoint whose pre-LayerNorm sums exceed 65504 would turn into inf -> NaN logits instead of an error.
+    bad = ~torch.isfinite(logits).all() if glogits is None else ~(torch.isfinite(logits).all() & torch.isfinite(glogits).all())
+    if bool(bad):
+        raise FloatingPointError("non-finite logits: the residual stream overflowed its storage format - call "
+                                 "model.set_stream_dtype(torch.float32) on both models (DESIGN.md section 2)")
     return (logits, glogits) if glogits is not None else logits
 
 

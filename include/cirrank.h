@@ -70,6 +70,9 @@ int cir_set_tuning(int knob, int value);
  *   bf16 operands).  res_dtype: CIR_F32 (with a C in the operand type or fp32) or CIR_F16 (only with an fp16 C; an fp16 C
  *   from bf16 operands takes ONLY an fp16 residual - CIR_EDTYPE otherwise).  C may alias residual.
  *   Requirements: K % 64 == 0, N % 16 == 0, 16-byte aligned rows.
+ *   Rounding: one rounding of the fp32 result to the type of C - except an fp16 residual-stream C WITH a residual from the
+ *   256 x 256 kernel (large M*N), which rounds A*W^T + bias to fp16 first, adds the residual in fp32 and rounds again: the same
+ *   GEMM can differ by one rounding between batch sizes on either side of the tile heuristic (fp32-stream C: bit-identical).
  * Replaces every nn.Linear on the path: vit.py:35-41,72,84; med.py:158-168,250-251,319-333;
  * nlvr_encoder.py:150-168,250-264,383-396; blip_stage2.py:50-54 (first layer); the erf GELU is
  * ACT2FN['gelu'] (nlvr_encoder.py:376-379) / nn.GELU (vit.py:26).
