@@ -46,7 +46,7 @@ def canonical(name: str):
     if "gemm_kernel<" in name:
         return "cir::gemm_kernel<?>"
     for short in ("attn_shared_kernel", "attn_stream_kernel", "layernorm_h16_kernel", "layernorm_kernel", "embed_ln_kernel", "patchify_kernel", "vit_assemble_kernel",
-                  "gather_rows_kernel", "topk_desc_kernel", "small_linear_kernel"):
+                  "gather_rows_kernel", "topk_desc_kernel", "small_linear_kernel", "cls_xattn_kernel"):
         if short in name:
             masked = ""
             if short.startswith("attn"):
