@@ -67,19 +67,13 @@ __device__ unsigned long long g_pair[2][64][8];  // end of each K-tile pair of t
 #define STAMP_PAIR(SLOT)
 #endif
 
-// Output stores: cache policy of the C lines (A/B switch CIR_STORE_POLICY: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1)
-#ifndef CIR_STORE_POLICY
-#define CIR_STORE_POLICY 1
-#endif
-#if CIR_STORE_POLICY == 0
-#define STORE_C(P, V) *(P) = (V);
-#elif CIR_STORE_POLICY == 1
-#define STORE_C(P, V) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(P), "v"(V) : "memory");   /* wait states: see the interior-tile stores */
-#elif CIR_STORE_POLICY == 2
-#define STORE_C(P, V) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(P), "v"(V) : "memory");
-#else
-#define STORE_C(P, V) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(P), "v"(V) : "memory");
-#endif
+// Output stores are NON-TEMPORAL (`nt`): plain stores leave the tile's 128 KiB of C lines dirty in the XCD's L2, where they
+// displace the weight / activation panels the next tiles re-read (every K-tile pair of the following tile 5.2-5.6 k cycles instead
+// of 4.4 k); with `nt` only the first pair behind the stores is slow.  Measured on the wide GEMMs of a step, same box: plain
+// 1171 / 1148 / 1022 TFLOP/s (K|V, QKV, fc1+GELU), nt 1240 / 1188 / 1057, sc1 1208 / 1184 / 1059, sc0 sc1 1213 / 1170 / 1052.
+// (Inline asm: wait states close the statement - a store wider than 64 bits reads its data registers after issue and the
+// hazard recogniser does not see inline asm.)
+#define STORE_C(P, V) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(P), "v"(V) : "memory");
 
 constexpr int T256 = 256;
 constexpr int kHalf = 16384;       // one half-tile: 128 rows x 64 k x 2 B
