@@ -67,6 +67,10 @@ __device__ unsigned long long g_pair[2][64][8];  // end of each K-tile pair of t
 #define STAMP_PAIR(SLOT)
 #endif
 
+// (Measured and dropped, round 3: the epilogue of M-half 0 - final after the last K-tile's phase a - as four 16-row mini-passes
+// BETWEEN the MFMAs of the tile's last phase (pack, 2 ds_write, 2 ds_read, 2 stores every 8 MFMAs; plain-pack variants, interior
+// tiles): correct, the epilogue shrank 2.9 k -> 1.3 k cycles and the last K-tile pair grew 5.2 k -> 7.6-8.3 k: the work is not
+// hidden under the matrix pipe, it stretches the phase; 75.2 against 74.8 ms of GEMM time per step.)
 // Output stores are NON-TEMPORAL (`nt`): plain stores leave the tile's 128 KiB of C lines dirty in the XCD's L2, where they
 // displace the weight / activation panels the next tiles re-read (every K-tile pair of the following tile 5.2-5.6 k cycles instead
 // of 4.4 k); with `nt` only the first pair behind the stores is slow.  Measured on the wide GEMMs of a step, same box: plain
