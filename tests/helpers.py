@@ -27,10 +27,20 @@ def fixture_images(z, ids, size):
     return synthetic.images(ids, size)
 
 
+_SD_CACHE = {}
+
+
 def state_dicts(g, v, seed, profile):
-    sd2 = weights.synth_state_dict(weights.nlvr_param_spec(g, v), seed, profile)
-    sd1 = weights.synth_state_dict(weights.retrieval_param_spec(g, v), seed + 1, profile)
-    return sd2, sd1
+    """Synthesised (stage-II, stage-I) state dicts; the last few (geometry, seed, profile) combinations stay cached - a full-size
+    pair is 0.5 G parameters of CPU random numbers (~25 s), and a dozen tests build the same models.  Callers only read them
+    (`load_state_dict` copies)."""
+    key = (repr(g), repr(v), int(seed), str(profile))
+    if key not in _SD_CACHE:
+        if len(_SD_CACHE) >= 3:
+            _SD_CACHE.pop(next(iter(_SD_CACHE)))
+        _SD_CACHE[key] = (weights.synth_state_dict(weights.nlvr_param_spec(g, v), seed, profile),
+                          weights.synth_state_dict(weights.retrieval_param_spec(g, v), seed + 1, profile))
+    return _SD_CACHE[key]
 
 
 def tiny_setup():
