@@ -188,26 +188,28 @@ class BLIP_NLVR(_EngineHost):
         qidx = torch.zeros((k,), dtype=torch.int64, device=self.device)
         return self.score(z, ids, mask, t_image_embeds, qidx)
 
-    @torch.no_grad()
     def img_txt_fusion(self, r_image_embeds, t_image_embeds, text, train=True):
         """B queries x B candidates -> (B, B) logits (blip_stage2.py:65-99): row i scores caption i / z_t i against all B
         candidates; ragged captions are padded to the longest (real attention masks inside the batch).
 
-        FORWARD ONLY: no autograd graph, no dropout / DropPath.  As in the reference the `train` argument
-        itself is unused - the mode is the module's: in `.eval()` this is the reference's arithmetic (pinned by
-        tests/golden/bxb224.npz); in `.train()` mode the reference would apply dropout and build a graph for backward,
-        which this library does not implement, so it raises instead of returning logits no optimiser could use."""
-        if self.training:
-            raise NotImplementedError("forward only: img_txt_fusion in train() mode needs dropout / DropPath and backward "
-                                      "(stage2_train.py), which the MI355X path does not implement - call model.eval()")
+        As in the reference the `train` argument itself is unused - the mode is the module's.  In `.eval()` this is the
+        inference engine (no graph; pinned by tests/golden/bxb224.npz).  In `.train()` mode it is the training step's forward
+        (stage2_train.py:210-212) on `train.fusion_train`: dropout with the config's probabilities, fp32 residual stream, and
+        a result that `loss.backward()` differentiates w.r.t. every `text_encoder.*` / `cls_head.*` parameter (pinned by
+        tests/golden/train768.npz).  The image tokens and z_t are inputs there, as with the reference's frozen ViT."""
         z = r_image_embeds.last_hidden_state if hasattr(r_image_embeds, "last_hidden_state") else r_image_embeds
         ids, mask = encode_text(self.tokenizer, text, self.device)
-        b = z.shape[0]
-        cand = self._cand16(t_image_embeds)
-        qidx = torch.arange(b, device=self.device).repeat_interleave(b)
-        rows = torch.arange(b, device=self.device).repeat(b)
-        logits = self.score(z, ids, mask, ops.gather_rows(cand, rows), qidx)
-        return logits.view(b, b)
+        if self.training and torch.is_grad_enabled():
+            from .train import fusion_train
+            g = self.bert_geometry
+            return fusion_train(self, z, t_image_embeds, ids, mask, g.hidden_dropout_prob, g.attention_probs_dropout_prob)
+        with torch.no_grad():
+            b = z.shape[0]
+            cand = self._cand16(t_image_embeds)
+            qidx = torch.arange(b, device=self.device).repeat_interleave(b)
+            rows = torch.arange(b, device=self.device).repeat(b)
+            logits = self.score(z, ids, mask, ops.gather_rows(cand, rows), qidx)
+            return logits.view(b, b)
 
 
 def blip_stage2(pretrained: str = "", **kwargs) -> BLIP_NLVR:

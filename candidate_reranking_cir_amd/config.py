@@ -25,6 +25,8 @@ class BertGeometry:
     encoder_width: int = 768
     merge_mlp_from_layer: int = 6  # nlvr_encoder.py:286: mergeMLP for layer_num >= 6, mergeAvg below
     pad_token_id: int = 0
+    hidden_dropout_prob: float = 0.1            # training mode only (train.py); eval-mode dropout is the identity
+    attention_probs_dropout_prob: float = 0.1
     extra: dict = field(default_factory=dict)
 
     @classmethod

@@ -1,0 +1,324 @@
+// Training-mode operators of the two-branch encoder (BLIP_NLVR.img_txt_fusion in train() mode + backward,
+// blip_stage2.py:65-99 driven by stage2_train.py:202-216).  The dense Linear layers keep running on the MFMA GEMM
+// (cir_gemm_bias_act: dgrad through a transposed weight copy, wgrad through transposed activation copies); this file holds
+// what the backward pass needs besides: 16-bit transposes, a general small batched matmul for the attention pieces
+// (32 x 32 / 32 x 197 tiles whose extents fit no MFMA tile constraint), row softmax with additive mask and counter-based dropout
+// (+ backward), LayerNorm backward, GELU / ReLU forward-backward, dropout, column sums, embedding scatter-add, AdamW.
+// First version: every kernel is HBM- or latency-bound by design and correct first; none is on the inference path.
+
+#include "common.hpp"
+
+namespace cir {
+
+// counter-based uniform in [0, 1): one 64-bit mix (splitmix64) of (seed, element index) - the same mask is regenerated in
+// the backward pass from the same (seed, index), no mask tensor is stored
+__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p) { return static_cast<float>(*p); }
+
+// ---- transpose: dst[b][c][r] = src[b][r][c] (16-bit elements; 32 x 32 tiles through LDS) --------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* src, T* dst, int rows, int cols, int64_t ld_src, int64_t ld_dst,
+                                                        int64_t s_src, int64_t s_dst) {
+    __shared__ T tile[32][33];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 8 rows per pass
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? src[b * s_src + (int64_t)r * ld_src + c] : static_cast<T>(0.f);
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) dst[b * s_dst + (int64_t)c * ld_dst + r] = tile[tx][i];
+    }
+}
+
+// ---- small batched matmul: C[b] = alpha * op(A[b]) * op(B[b]) (+ C[b]) ----------------------------------------------------
+// op(A) is (M, K): A stored (M, K) [ta = 0] or (K, M) [ta = 1]; op(B) is (K, N): B stored (K, N) [tb = 0] or (N, K) [tb = 1].
+// 16 x 16 output tile per 256-thread block, fp32 accumulate; inputs TI (16-bit or float), output TO.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void bmm_kernel(const TI* A, const TI* B, TO* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                                                  int ta, int tb, int64_t sA, int64_t sB, int64_t sC, float alpha, int accumulate) {
+    __shared__ float As[16][17], Bs[16][17];
+    const int b = blockIdx.z;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx;
+    const TI* Ab = A + b * sA;
+    const TI* Bb = B + b * sB;
+    float acc = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        {   // A tile: element (ty = m-local, tx = k-local)
+            const int kk = k0 + tx;
+            As[ty][tx] = (m < M && kk < K) ? ldf(ta ? Ab + (int64_t)kk * lda + m : Ab + (int64_t)m * lda + kk) : 0.f;
+        }
+        {   // B tile: element (ty = k-local, tx = n-local)
+            const int kk = k0 + ty;
+            Bs[ty][tx] = (kk < K && n < N) ? ldf(tb ? Bb + (int64_t)n * ldb + kk : Bb + (int64_t)kk * ldb + n) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = fmaf(As[ty][k], Bs[k][tx], acc);
+        __syncthreads();
+    }
+    if (m < M && n < N) {
+        TO* cp = C + b * sC + (int64_t)m * ldc + n;
+        const float v = alpha * acc + (accumulate ? static_cast<float>(*cp) : 0.f);
+        *cp = static_cast<TO>(v);
+    }
+}
+
+// ---- row softmax with additive key mask and dropout: P = softmax(S * scale + mask), Pd = dropout(P) ----------------------
+// one wave per row; S fp32 (rows, cols) with leading dimension lds_; mask fp32 (cols) per group of `rows_per_mask` rows or NULL.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* S, int64_t ld_s, const float* mask, int64_t rows_per_mask, int64_t ld_mask,
+                                                          T* P, T* Pd, int64_t ld_p, int64_t rows, int cols, float scale, float p_drop, uint64_t seed) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* sr = S + row * ld_s;
+    const float* mr = mask ? mask + (row / rows_per_mask) * ld_mask : nullptr;
+    float mx = -INFINITY;
+    for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, fmaf(sr[c], scale, mr ? mr[c] : 0.f));
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane; c < cols; c += 64) sum += __expf(fmaf(sr[c], scale, mr ? mr[c] : 0.f) - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum, keep = 1.0f / (1.0f - p_drop);
+    for (int c = lane; c < cols; c += 64) {
+        const float p = __expf(fmaf(sr[c], scale, mr ? mr[c] : 0.f) - mx) * inv;
+        P[row * ld_p + c] = static_cast<T>(p);
+        const bool kept = p_drop <= 0.f || uniform01(seed, (uint64_t)row * (uint64_t)cols + c) >= p_drop;
+        Pd[row * ld_p + c] = static_cast<T>(kept ? p * (p_drop > 0.f ? keep : 1.0f) : 0.f);
+    }
+}
+
+// dS = scale * P * (dP - sum_c dP * P) with dP = dropout-backward(dPd): rows as in the forward, dPd fp32, dS 16-bit
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* P, int64_t ld_p, const float* dPd, int64_t ld_d, T* dS, int64_t ld_ds,
+                                                          int64_t rows, int cols, float scale, float p_drop, uint64_t seed) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    float dot = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+        const bool kept = p_drop <= 0.f || uniform01(seed, (uint64_t)row * (uint64_t)cols + c) >= p_drop;
+        const float dp = kept ? dPd[row * ld_d + c] * keep : 0.f;
+        dot += dp * static_cast<float>(P[row * ld_p + c]);
+    }
+    dot = wave_sum(dot);
+    for (int c = lane; c < cols; c += 64) {
+        const bool kept = p_drop <= 0.f || uniform01(seed, (uint64_t)row * (uint64_t)cols + c) >= p_drop;
+        const float dp = kept ? dPd[row * ld_d + c] * keep : 0.f;
+        dS[row * ld_ds + c] = static_cast<T>(scale * static_cast<float>(P[row * ld_p + c]) * (dp - dot));
+    }
+}
+
+// ---- LayerNorm backward: y = (x - mean) * rstd * gamma + beta over `cols`; x fp32 (the saved pre-LN sum) -----------------
+// dx fp32 (written), dgamma / dbeta fp32 (atomically accumulated: zero them first).  One wave per row.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta,
+                                                            int64_t rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * cols;
+    const float* dr = dy + row * cols;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / cols;
+    float q = 0.f;
+    for (int c = lane; c < cols; c += 64) { const float d = xr[c] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / cols + eps);
+    float a = 0.f, b = 0.f;           // mean(dy*gamma), mean(dy*gamma*xhat)
+    for (int c = lane; c < cols; c += 64) {
+        const float xh = (xr[c] - mean) * rstd, g = dr[c] * gamma[c];
+        a += g; b += g * xh;
+    }
+    a = wave_sum(a) / cols; b = wave_sum(b) / cols;
+    for (int c = lane; c < cols; c += 64) {
+        const float xh = (xr[c] - mean) * rstd, g = dr[c] * gamma[c];
+        dx[row * cols + c] = rstd * (g - a - xh * b);
+        atomicAdd(dgamma + c, dr[c] * xh);
+        atomicAdd(dbeta + c, dr[c]);
+    }
+}
+
+// ---- elementwise ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+// mode 0: y = gelu(z); 1: dz = dy * gelu'(z); 2: y = relu(z); 3: dz = dy * (z > 0); 4: y = dropout(z) [dy unused]; 5: y = z + dy (add);
+// 6: y = p_drop * z (scale by the factor passed in p_drop)
+template <typename TZ, typename TO>
+__global__ __launch_bounds__(256) void eltwise_kernel(const TZ* z, const float* dy, TO* out, int64_t n, int mode, float p_drop, uint64_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = static_cast<float>(z[i]);
+    float r;
+    switch (mode) {
+        case 0: r = gelu_exact(v); break;
+        case 1: r = dy[i] * gelu_grad(v); break;
+        case 2: r = fmaxf(v, 0.f); break;
+        case 3: r = v > 0.f ? dy[i] : 0.f; break;
+        case 4: r = (p_drop <= 0.f || uniform01(seed, (uint64_t)i) >= p_drop) ? v * (p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f) : 0.f; break;
+        case 5: r = v + dy[i]; break;
+        default: r = v * p_drop; break;
+    }
+    out[i] = static_cast<TO>(r);
+}
+
+// column sums: out[c] += sum_r x[r][c] (fp32 x, atomics: zero `out` first)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, int64_t ld, float* out, int64_t rows, int cols, int64_t rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += x[r * ld + c];
+    atomicAdd(out + c, s);
+}
+
+// embedding backward: dword[ids[r]][c] += dy[r][c], dpos[r % L][c] += dy[r][c]  (fp32, atomics: zero first)
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* ids, const float* dy, float* dword, float* dpos, int64_t rows, int L, int cols) {
+    const int64_t r = blockIdx.x;
+    if (r >= rows) return;
+    const int64_t id = ids[r];
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float g = dy[r * cols + c];
+        atomicAdd(dword + id * cols + c, g);
+        atomicAdd(dpos + (r % L) * cols + c, g);
+    }
+}
+
+// AdamW (decoupled weight decay, torch.optim.AdamW semantics): in place on fp32 param / moments
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi, vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    float w = p[i] * (1.f - lr * wd);
+    w -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    p[i] = w;
+}
+
+}  // namespace cir
+
+using namespace cir;
+
+extern "C" int cir_transpose16(const void* src, void* dst, int rows, int cols, int64_t ld_src, int64_t ld_dst, int batch, int64_t s_src,
+                               int64_t s_dst, int dtype, void* stream) {
+    CIR_CHECK_PTR(src); CIR_CHECK_PTR(dst);
+    if (rows <= 0 || cols <= 0 || batch <= 0) return CIR_EINVAL;
+    if (dtype != CIR_BF16 && dtype != CIR_F16) return CIR_EDTYPE;
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // (bf16 and fp16 are both 16-bit payloads: one instantiation moves either)
+    hipLaunchKernelGGL((transpose_kernel<unsigned short>), grid, block, 0, s, reinterpret_cast<const unsigned short*>(src),
+                       reinterpret_cast<unsigned short*>(dst), rows, cols, ld_src, ld_dst, s_src, s_dst);
+    CIR_LAUNCH_RESULT();
+}
+
+extern "C" int cir_bmm(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b,
+                       int batch, int64_t sA, int64_t sB, int64_t sC, float alpha, int accumulate, int in_dtype, int out_dtype, void* stream) {
+    CIR_CHECK_PTR(A); CIR_CHECK_PTR(B); CIR_CHECK_PTR(C);
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return CIR_EINVAL;
+    if (batch > 65535) return CIR_ESHAPE;
+    dim3 grid((N + 15) / 16, (M + 15) / 16, batch), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define CIR_BMM(TI, TO) hipLaunchKernelGGL((bmm_kernel<TI, TO>), grid, block, 0, s, reinterpret_cast<const TI*>(A), reinterpret_cast<const TI*>(B), \
+                                           reinterpret_cast<TO*>(C), M, N, K, lda, ldb, ldc, trans_a, trans_b, sA, sB, sC, alpha, accumulate)
+    if (in_dtype == CIR_BF16) { if (out_dtype == CIR_F32) CIR_BMM(__bf16, float); else if (out_dtype == CIR_BF16) CIR_BMM(__bf16, __bf16); else return CIR_EDTYPE; }
+    else if (in_dtype == CIR_F16) { if (out_dtype == CIR_F32) CIR_BMM(_Float16, float); else if (out_dtype == CIR_F16) CIR_BMM(_Float16, _Float16); else return CIR_EDTYPE; }
+    else if (in_dtype == CIR_F32) { if (out_dtype == CIR_F32) CIR_BMM(float, float); else return CIR_EDTYPE; }
+    else return CIR_EDTYPE;
+#undef CIR_BMM
+    CIR_LAUNCH_RESULT();
+}
+
+extern "C" int cir_softmax_dropout(const float* S, int64_t ld_s, const float* mask, int64_t rows_per_mask, int64_t ld_mask, void* P, void* Pd,
+                                   int64_t ld_p, int64_t rows, int cols, float scale, float p_drop, uint64_t seed, int dtype, void* stream) {
+    CIR_CHECK_PTR(S); CIR_CHECK_PTR(P); CIR_CHECK_PTR(Pd);
+    if (rows <= 0 || cols <= 0 || p_drop < 0.f || p_drop >= 1.f || (mask && rows_per_mask <= 0)) return CIR_EINVAL;
+    if (dtype != CIR_BF16 && dtype != CIR_F16) return CIR_EDTYPE;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == CIR_BF16) hipLaunchKernelGGL((softmax_fwd_kernel<__bf16>), grid, block, 0, s, S, ld_s, mask, rows_per_mask, ld_mask, reinterpret_cast<__bf16*>(P), reinterpret_cast<__bf16*>(Pd), ld_p, rows, cols, scale, p_drop, seed);
+    else hipLaunchKernelGGL((softmax_fwd_kernel<_Float16>), grid, block, 0, s, S, ld_s, mask, rows_per_mask, ld_mask, reinterpret_cast<_Float16*>(P), reinterpret_cast<_Float16*>(Pd), ld_p, rows, cols, scale, p_drop, seed);
+    CIR_LAUNCH_RESULT();
+}
+
+extern "C" int cir_softmax_dropout_bwd(const void* P, int64_t ld_p, const float* dPd, int64_t ld_d, void* dS, int64_t ld_ds, int64_t rows, int cols,
+                                       float scale, float p_drop, uint64_t seed, int dtype, void* stream) {
+    CIR_CHECK_PTR(P); CIR_CHECK_PTR(dPd); CIR_CHECK_PTR(dS);
+    if (rows <= 0 || cols <= 0 || p_drop < 0.f || p_drop >= 1.f) return CIR_EINVAL;
+    if (dtype != CIR_BF16 && dtype != CIR_F16) return CIR_EDTYPE;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == CIR_BF16) hipLaunchKernelGGL((softmax_bwd_kernel<__bf16>), grid, block, 0, s, reinterpret_cast<const __bf16*>(P), ld_p, dPd, ld_d, reinterpret_cast<__bf16*>(dS), ld_ds, rows, cols, scale, p_drop, seed);
+    else hipLaunchKernelGGL((softmax_bwd_kernel<_Float16>), grid, block, 0, s, reinterpret_cast<const _Float16*>(P), ld_p, dPd, ld_d, reinterpret_cast<_Float16*>(dS), ld_ds, rows, cols, scale, p_drop, seed);
+    CIR_LAUNCH_RESULT();
+}
+
+extern "C" int cir_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int64_t rows, int cols,
+                                 float eps, void* stream) {
+    CIR_CHECK_PTR(x); CIR_CHECK_PTR(gamma); CIR_CHECK_PTR(dy); CIR_CHECK_PTR(dx); CIR_CHECK_PTR(dgamma); CIR_CHECK_PTR(dbeta);
+    if (rows <= 0 || cols <= 0) return CIR_EINVAL;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), x, gamma, dy, dx, dgamma, dbeta, rows, cols, eps);
+    CIR_LAUNCH_RESULT();
+}
+
+extern "C" int cir_eltwise(const void* z, int z_dtype, const float* dy, void* out, int out_dtype, int64_t n, int mode, float p_drop, uint64_t seed,
+                           void* stream) {
+    CIR_CHECK_PTR(z); CIR_CHECK_PTR(out);
+    if (n <= 0 || mode < 0 || mode > 6 || (mode != 6 && (p_drop < 0.f || p_drop >= 1.f))) return CIR_EINVAL;
+    if ((mode == 1 || mode == 3 || mode == 5) && dy == nullptr) return CIR_EINVAL;
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define CIR_ELT(TZ, TO) hipLaunchKernelGGL((eltwise_kernel<TZ, TO>), grid, block, 0, s, reinterpret_cast<const TZ*>(z), dy, reinterpret_cast<TO*>(out), n, mode, p_drop, seed)
+#define CIR_ELT_OUT(TZ) do { if (out_dtype == CIR_F32) CIR_ELT(TZ, float); else if (out_dtype == CIR_BF16) CIR_ELT(TZ, __bf16); else if (out_dtype == CIR_F16) CIR_ELT(TZ, _Float16); else return CIR_EDTYPE; } while (0)
+    if (z_dtype == CIR_F32) CIR_ELT_OUT(float);
+    else if (z_dtype == CIR_BF16) CIR_ELT_OUT(__bf16);
+    else if (z_dtype == CIR_F16) CIR_ELT_OUT(_Float16);
+    else return CIR_EDTYPE;
+#undef CIR_ELT_OUT
+#undef CIR_ELT
+    CIR_LAUNCH_RESULT();
+}
+
+extern "C" int cir_colsum(const float* x, int64_t ld, float* out, int64_t rows, int cols, void* stream) {
+    CIR_CHECK_PTR(x); CIR_CHECK_PTR(out);
+    if (rows <= 0 || cols <= 0) return CIR_EINVAL;
+    const int64_t rpb = 256;
+    dim3 grid((cols + 255) / 256, (unsigned)((rows + rpb - 1) / rpb)), block(256);
+    hipLaunchKernelGGL(colsum_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), x, ld, out, rows, cols, rpb);
+    CIR_LAUNCH_RESULT();
+}
+
+extern "C" int cir_embed_bwd(const int64_t* ids, const float* dy, float* dword, float* dpos, int64_t rows, int L, int cols, void* stream) {
+    CIR_CHECK_PTR(ids); CIR_CHECK_PTR(dy); CIR_CHECK_PTR(dword); CIR_CHECK_PTR(dpos);
+    if (rows <= 0 || L <= 0 || cols <= 0) return CIR_EINVAL;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), ids, dy, dword, dpos, rows, L, cols);
+    CIR_LAUNCH_RESULT();
+}
+
+extern "C" int cir_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                              int step, void* stream) {
+    CIR_CHECK_PTR(p); CIR_CHECK_PTR(g); CIR_CHECK_PTR(m); CIR_CHECK_PTR(v);
+    if (n <= 0 || step <= 0) return CIR_EINVAL;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n, lr, beta1,
+                       beta2, eps, weight_decay, bc1, bc2);
+    CIR_LAUNCH_RESULT();
+}

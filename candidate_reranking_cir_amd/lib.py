@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import c_uint64, c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CIR_LIB", os.path.join(_HERE, "libcirrank.so"))   # CIR_LIB: A/B a second build
@@ -40,6 +40,19 @@ SIGNATURES = {
     "cir_topk_desc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "cir_linear_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "cir_l2_normalize": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    # training-mode operators
+    "cir_transpose16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int, c_int64, c_int64, c_int, c_void_p]),
+    "cir_bmm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int64, c_int64, c_int64,
+                        c_float, c_int, c_int, c_int, c_void_p]),
+    "cir_softmax_dropout": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_float, c_float,
+                                    c_uint64, c_int, c_void_p]),
+    "cir_softmax_dropout_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_float, c_float, c_uint64, c_int,
+                                        c_void_p]),
+    "cir_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "cir_eltwise": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_uint64, c_void_p]),
+    "cir_colsum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
+    "cir_embed_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "cir_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p]),
 }
 
 _lib = None

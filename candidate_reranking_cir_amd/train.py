@@ -1,0 +1,414 @@
+"""Training-mode `img_txt_fusion` and its backward pass on the libcirrank kernels.
+
+What the reference does per step (stage2_train.py:202-216): z_t from the frozen stage-I model, image tokens from the (by default
+frozen) ViT, then under autocast `logits = model.img_txt_fusion(z_t, target_feats, captions, train=True)` - the B x B surface of
+blip_stage2.py:65-99: row i's caption / z_t expanded to B rows against all B targets - cross-entropy against arange(B),
+`loss.backward()`, AdamW.  Trainable: the two-branch BERT (`text_encoder.*`) and `cls_head.*`.
+
+`NlvrTrainer` runs that forward with every intermediate the backward needs kept on the device, and the backward as an explicit
+reverse pass - no autograd graph over the kernels: each step of nlvr_encoder.BertLayer.forward (:414-476), BertSelfAttention
+(:140-222), BertSelfOutput (:248-264, incl. the averaging / merge_layer variants), BertIntermediate / BertOutput (:383-409),
+BertEmbeddings (:49-91) and cls_head (blip_stage2.py:50-54) has its hand-written adjoint below.  Arithmetic: dense layers on the
+MFMA GEMM (`ops.gemm`; dgrad over a transposed weight copy, wgrad over transposed activation copies) or, where an extent misses
+the GEMM's tile constraints, on `train_ops.bmm`; attention un-fused per head (scores, softmax + dropout, context) so that its
+adjoint is four small matmuls and one row kernel; LayerNorm / GELU / dropout / embedding adjoints in `train_ops`.
+Precision: 16-bit MFMA operands (activations, weights, and the gradients fed to the GEMMs), fp32 accumulation, fp32 residual
+stream, fp32 LayerNorm inputs, fp32 weight gradients - the forward plan of DESIGN.md section 2 with an fp32 stream.
+Dropout is counter-based (seed per site); with p = 0 the pass is deterministic and is what the reference-gradient fixture pins.
+
+`fusion_train(model, ...)` wraps the pair as ONE `torch.autograd.Function`, so the reference's training step runs unchanged:
+`logits = model.img_txt_fusion(z_t, feats, captions)` in `.train()` mode, `loss = F.cross_entropy(logits, gt)`, `loss.backward()`
+fills `.grad` of every trainable parameter (accumulating, as autograd does); `AdamW` below is torch.optim.AdamW's update on
+`cir_adamw_step`.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops, train_ops as T
+
+
+def _cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    return T.eltwise(x.contiguous(), T.MODE_SCALE, out_dtype=dtype, p_drop=1.0)
+
+
+def _gemm_ok(m: int, n: int, k: int) -> bool:
+    return k % 64 == 0 and n % 16 == 0
+
+
+class _Lin:
+    """One nn.Linear of the reference (weight (N, K), bias (N)) with the copies the kernels want, refreshed per step."""
+
+    def __init__(self, w: torch.Tensor, b: Optional[torch.Tensor], dtype: torch.dtype):
+        self.w32, self.b32 = w, b
+        self.w16 = _cast(w.detach(), dtype)                         # (N, K): forward operand
+        self.w16t = T.transpose16(self.w16)                                         # (K, N): dgrad operand
+        self.bias = None if b is None else b.detach().float().contiguous()
+        self.dw = torch.zeros_like(self.w16, dtype=torch.float32)
+        self.db = None if b is None else torch.zeros_like(self.bias)
+
+    def fwd(self, x16: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
+        m, k = x16.shape
+        n = self.w16.shape[0]
+        if _gemm_ok(m, n, k):
+            return ops.gemm(x16, self.w16, self.bias, out_dtype=out_dtype)
+        y = T.bmm(x16.unsqueeze(0), self.w16.unsqueeze(0), False, True, out_dtype=torch.float32)[0]
+        if self.bias is not None:
+            y = T.eltwise(y, T.MODE_ADD, self.bias.unsqueeze(0).expand(m, n).contiguous())
+        return y if out_dtype == torch.float32 else _cast(y, out_dtype)
+
+    def bwd(self, x16: torch.Tensor, dy: torch.Tensor, need_dx: bool = True) -> Optional[torch.Tensor]:
+        """dy fp32 (M, N): accumulates dW, db; returns dx fp32 (M, K)."""
+        m, k = x16.shape
+        n = self.w16.shape[0]
+        dy16 = _cast(dy, x16.dtype)
+        if self.db is not None:
+            T.colsum(dy, self.db)
+        if _gemm_ok(n, k, m) and m % 8 == 0:                                        # dW (N, K) = dy^T (N, M) . (x^T (K, M))^T
+            dw = ops.gemm(T.transpose16(dy16), T.transpose16(x16), None, out_dtype=torch.float32)
+            self.dw = T.eltwise(self.dw, T.MODE_ADD, dw)
+        else:
+            T.bmm(dy16.unsqueeze(0), x16.unsqueeze(0), True, False, out=self.dw.unsqueeze(0), accumulate=True)
+        if not need_dx:
+            return None
+        if _gemm_ok(m, k, n):                                                       # dx (M, K) = dy (M, N) . (W^T (K, N))^T
+            return ops.gemm(dy16, self.w16t, None, out_dtype=torch.float32)
+        return T.bmm(dy16.unsqueeze(0), self.w16.unsqueeze(0), False, False, out_dtype=torch.float32)[0]
+
+
+class _LN:
+    def __init__(self, g: torch.Tensor, b: torch.Tensor, eps: float):
+        self.g32, self.b32, self.eps = g, b, eps
+        self.g, self.b = g.detach().float().contiguous(), b.detach().float().contiguous()
+        self.dg, self.db = torch.zeros_like(self.g), torch.zeros_like(self.b)
+
+    def fwd(self, pre: torch.Tensor, dtype: torch.dtype):
+        return ops.layernorm(pre, self.g, self.b, self.eps, want32=True, dtype16=dtype, stream_dtype=torch.float32)
+
+    def bwd(self, pre: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+        return T.layernorm_bwd(pre, self.g, dy, self.dg, self.db, self.eps)
+
+
+class NlvrTrainer:
+    """Forward (with saved activations) and backward of the two-branch encoder + cls_head for a B x B training batch."""
+
+    def __init__(self, model, p_hidden: float = 0.1, p_attn: float = 0.1, seed: int = 0):
+        self.model, self.p_hidden, self.p_attn, self.seed = model, float(p_hidden), float(p_attn), int(seed)
+        self.geo = model.bert_geometry
+        self.dtype = model.compute_dtype
+        self.step_no = 0
+        self._hd = self.geo.hidden_size // self.geo.num_attention_heads
+        self._scale = self._hd ** -0.5
+
+    # ------------------------------------------------------------------------------------------------ parameters
+    def _pack(self):
+        P = dict(self.model.named_parameters())
+        g, dt = self.geo, self.dtype
+        lin = lambda name: _Lin(P[name + ".weight"], P.get(name + ".bias"), dt)
+        ln = lambda name: _LN(P[name + ".weight"], P[name + ".bias"], g.layer_norm_eps)
+        e = "text_encoder.embeddings."
+        self.word, self.pos = P[e + "word_embeddings.weight"], P[e + "position_embeddings.weight"]
+        self.dword, self.dpos = torch.zeros_like(self.word, dtype=torch.float32), torch.zeros_like(self.pos, dtype=torch.float32)
+        self.ln_e = ln(e + "LayerNorm")
+        self.layers: List[Dict] = []
+        for i in range(g.num_hidden_layers):
+            p = f"text_encoder.encoder.layer.{i}."
+            ly = {}
+            for b in (0, 1):
+                ly[f"q{b}"], ly[f"k{b}"], ly[f"v{b}"] = (lin(p + f"attention.self{b}.{n}") for n in ("query", "key", "value"))
+                ly[f"o{b}"] = lin(p + f"attention.output.dense{b}")
+                ly[f"cq{b}"], ly[f"ck{b}"], ly[f"cv{b}"] = (lin(p + f"crossattention.self{b}.{n}") for n in ("query", "key", "value"))
+                ly[f"d{b}"] = lin(p + f"crossattention.output.dense{b}")
+            for c, b in (("A", 0), ("B", 1)):
+                ly[f"ln1{b}"] = ln(p + f"attention.output.LayerNorm{c}")
+                ly[f"ln2{b}"] = ln(p + f"crossattention.output.LayerNorm{c}")
+            mk = p + "crossattention.output.merge_layer"
+            ly["merge"] = lin(mk) if (mk + ".weight") in P else None
+            ly["w1"], ly["w2"], ly["ln3"] = lin(p + "intermediate.dense"), lin(p + "output.dense"), ln(p + "output.LayerNorm")
+            self.layers.append(ly)
+        self.c0, self.c2 = lin("cls_head.0"), lin("cls_head.2")
+
+    def _site(self, *ids) -> int:
+        s = self.seed * 1000003 + self.step_no * 7919
+        for v in ids:
+            s = s * 131 + int(v) + 1
+        return s & (2 ** 62 - 1)
+
+    def _drop(self, x: torch.Tensor, site: int) -> torch.Tensor:
+        return x if self.p_hidden <= 0 else T.eltwise(x, T.MODE_DROPOUT, p_drop=self.p_hidden, seed=site)
+
+    # ------------------------------------------------------------------------------------------------ attention
+    def _attn_fwd(self, q16, k16, v16, t_n, lq, lk, mask, site):
+        """q16 (T*Lq, D), k16 / v16 (T*Lk, D) views (row stride = their parent's); mask (T, Lk) additive fp32 or None."""
+        h_n, d = self.geo.num_attention_heads, self.geo.hidden_size
+        s = torch.empty((t_n, h_n, lq, lk), dtype=torch.float32, device=q16.device)
+        q3, k3, v3 = q16.view(t_n, lq, -1), k16.view(t_n, lk, -1), v16.view(t_n, lk, -1)
+        for h in range(h_n):
+            sl = slice(h * self._hd, (h + 1) * self._hd)
+            T.bmm(q3[:, :, sl], k3[:, :, sl], False, True, out=s[:, h])
+        p, pd = T.softmax_dropout(s.view(-1, lk), mask, h_n * lq, self._scale, self.p_attn, site, q16.dtype)
+        ctx = torch.empty((t_n, lq, d), dtype=q16.dtype, device=q16.device)
+        pd4 = pd.view(t_n, h_n, lq, lk)
+        for h in range(h_n):
+            sl = slice(h * self._hd, (h + 1) * self._hd)
+            T.bmm(pd4[:, h], v3[:, :, sl], False, False, out=ctx[:, :, sl])
+        return ctx.view(t_n * lq, d), (p, pd, site)
+
+    def _attn_bwd(self, dctx, q16, k16, v16, t_n, lq, lk, saved):
+        """dctx fp32 (T*Lq, D) -> (dq (T*Lq, D), dk (T*Lk, D), dv (T*Lk, D)) fp32."""
+        p, pd, site = saved
+        h_n, d = self.geo.num_attention_heads, self.geo.hidden_size
+        dc16 = _cast(dctx, q16.dtype).view(t_n, lq, d)
+        q3, k3, v3 = q16.view(t_n, lq, -1), k16.view(t_n, lk, -1), v16.view(t_n, lk, -1)
+        pd4 = pd.view(t_n, h_n, lq, lk)
+        dpd = torch.empty((t_n, h_n, lq, lk), dtype=torch.float32, device=dctx.device)
+        dq = torch.empty((t_n, lq, d), dtype=torch.float32, device=dctx.device)
+        dk = torch.empty((t_n, lk, d), dtype=torch.float32, device=dctx.device)
+        dv = torch.empty((t_n, lk, d), dtype=torch.float32, device=dctx.device)
+        for h in range(h_n):
+            sl = slice(h * self._hd, (h + 1) * self._hd)
+            T.bmm(dc16[:, :, sl], v3[:, :, sl], False, True, out=dpd[:, h])                       # dPd = dctx . V^T
+            T.bmm(pd4[:, h], dc16[:, :, sl], True, False, out=dv[:, :, sl])                        # dV  = Pd^T . dctx
+        ds = T.softmax_dropout_bwd(p, dpd.view(-1, lk), self._scale, self.p_attn, site).view(t_n, h_n, lq, lk)
+        for h in range(h_n):
+            sl = slice(h * self._hd, (h + 1) * self._hd)
+            T.bmm(ds[:, h], k3[:, :, sl], False, False, out=dq[:, :, sl])                          # dQ = dS . K
+            T.bmm(ds[:, h], q3[:, :, sl], True, False, out=dk[:, :, sl])                           # dK = dS^T . Q
+        return dq.view(-1, d), dk.view(-1, d), dv.view(-1, d)
+
+    # ------------------------------------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, z_t: torch.Tensor, feats: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        """z_t (B, L, D) fp32, feats (B, N, Dv), ids / mask (B, L) with [ENC] set -> logits (B, B) fp32; keeps what backward needs."""
+        self._pack()
+        self.model._engines = None                                                  # a training step is about to change the parameters: the
+        self.step_no += 1                                                           # inference engines repack on their next use
+        g, dt, dev = self.geo, self.dtype, z_t.device
+        b_n, l = input_ids.shape
+        n, d = feats.shape[1], g.hidden_size
+        t_n = b_n * b_n
+        r = t_n * l
+        qi = torch.arange(b_n, device=dev).repeat_interleave(b_n)                   # row i's text / z_t for items i*B .. i*B+B-1
+        ci = torch.arange(b_n, device=dev).repeat(b_n)                              # against candidate j
+        ids_t = input_ids.to(dev)[qi].contiguous()                                  # (T, L)
+        self.sv = sv = {"ids": ids_t, "t_n": t_n, "l": l, "n": n, "b_n": b_n}
+        # embeddings (BertEmbeddings: LayerNorm(word + pos), dropout) -> branch 1; z_t -> branch 0 (nlvr_encoder.py:880-892)
+        pos_idx = torch.arange(l, device=dev).repeat(t_n)
+        pre_e = T.eltwise(ops.gather_rows(self.word.detach().float(), ids_t.view(-1), torch.float32), T.MODE_ADD,
+                          ops.gather_rows(self.pos.detach().float(), pos_idx, torch.float32))
+        sv["pre_e"] = pre_e
+        e32, _ = self.ln_e.fwd(pre_e, dt)
+        e32 = self._drop(e32, self._site(9000))
+        h32 = [ops.gather_rows(z_t.to(dev).float().contiguous().view(b_n, l * d), qi, torch.float32).view(r, d), e32]
+        h16 = [_cast(x, dt) for x in h32]
+        cand16 = ops.gather_rows(feats.to(dev).contiguous().view(b_n, -1), ci, dt).view(t_n * n, -1)      # (T*N, Dv)
+        sv["cand16"] = cand16
+        smask = ((1.0 - attention_mask.to(dev).float()) * -10000.0)[qi].contiguous()                      # (T, L), nlvr_encoder.py:773-774
+        sv["layers"] = []
+        for i, ly in enumerate(self.layers):
+            s = {"h16": h16, "q": [], "k": [], "v": [], "sa": [], "ctx": [], "pre1": [], "a16": [], "cq": [], "ck": [], "cv": [], "ca": [],
+                 "c": [], "pre2": [], "x16": [], "z": [], "f16": [], "pre3": []}
+            a32, dd = [], []
+            for b in (0, 1):
+                q, k, v = (ly[f"{nm}{b}"].fwd(h16[b], dt) for nm in ("q", "k", "v"))
+                ctx, sa = self._attn_fwd(q, k, v, t_n, l, l, smask, self._site(i, b, 1))
+                t = self._drop(ly[f"o{b}"].fwd(ctx, torch.float32), self._site(i, b, 2))
+                pre1 = T.eltwise(t, T.MODE_ADD, h32[b])
+                a, a16 = ly[f"ln1{b}"].fwd(pre1, dt)
+                cq = ly[f"cq{b}"].fwd(a16, dt)
+                ck, cv = ly[f"ck{b}"].fwd(cand16, dt), ly[f"cv{b}"].fwd(cand16, dt)
+                c, ca = self._attn_fwd(cq, ck, cv, t_n, l, n, None, self._site(i, b, 3))
+                dd.append(ly[f"d{b}"].fwd(c, torch.float32))
+                a32.append(a)
+                for key, val in (("q", q), ("k", k), ("v", v), ("sa", sa), ("ctx", ctx), ("pre1", pre1), ("a16", a16), ("cq", cq), ("ck", ck),
+                                 ("cv", cv), ("ca", ca), ("c", c)):
+                    s[key].append(val)
+            if ly["merge"] is None:                                                 # layers < 6: average (nlvr_encoder.py:257-260)
+                m = T.eltwise(T.eltwise(dd[0], T.MODE_ADD, dd[1]), T.MODE_SCALE, p_drop=0.5)
+            else:                                                                   # layers >= 6: merge_layer(cat) (:252-256)
+                cat16 = torch.cat([_cast(dd[0], dt), _cast(dd[1], dt)], dim=1).contiguous()
+                s["cat16"] = cat16
+                m = ly["merge"].fwd(cat16, torch.float32)
+            m = self._drop(m, self._site(i, 2, 4))
+            h32n, h16n = [], []
+            for b in (0, 1):
+                pre2 = T.eltwise(m, T.MODE_ADD, a32[b])
+                x32, x16 = ly[f"ln2{b}"].fwd(pre2, dt)
+                z = ly["w1"].fwd(x16, torch.float32)
+                f16 = T.eltwise(z, T.MODE_GELU, out_dtype=dt)
+                o = self._drop(ly["w2"].fwd(f16, torch.float32), self._site(i, b, 5))
+                pre3 = T.eltwise(o, T.MODE_ADD, x32)
+                hn, hn16 = ly["ln3"].fwd(pre3, dt)
+                h32n.append(hn); h16n.append(hn16)
+                for key, val in (("pre2", pre2), ("x16", x16), ("z", z), ("f16", f16), ("pre3", pre3)):
+                    s[key].append(val)
+            sv["layers"].append(s)
+            h32, h16 = h32n, h16n
+        # cat(CLS_0, CLS_1) -> cls_head (nlvr_encoder.py:906-908, blip_stage2.py:50-54, 94-99)
+        cls_rows = torch.arange(t_n, device=dev) * l
+        hid16 = torch.cat([ops.gather_rows(h16[0], cls_rows, dt), ops.gather_rows(h16[1], cls_rows, dt)], dim=1).contiguous()
+        z1 = self.c0.fwd(hid16, torch.float32)
+        y16 = T.eltwise(z1, T.MODE_RELU, out_dtype=dt)
+        logits2 = self.c2.fwd(y16, torch.float32)                                   # (T, 2)
+        sv.update(hid16=hid16, z1=z1, y16=y16, cls_rows=cls_rows)
+        return logits2[:, 0].contiguous().view(b_n, b_n)
+
+    # ------------------------------------------------------------------------------------------------ backward
+    @torch.no_grad()
+    def backward(self, dlogits: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """dlogits (B, B) fp32 -> {parameter name: fp32 gradient} for every text_encoder.* / cls_head.* parameter."""
+        sv, g, dt = self.sv, self.geo, self.dtype
+        dev = dlogits.device
+        t_n, l, n, d = sv["t_n"], sv["l"], sv["n"], g.hidden_size
+        r = t_n * l
+        # Gradient scaling (what the reference's GradScaler does for its fp16 autocast, stage2_train.py:215-218, done inside):
+        # every adjoint below is linear in the incoming gradient, so the pass runs on S * dlogits with S a power of two that
+        # puts the largest entry near 512 - the 16-bit copies fed to the dgrad / wgrad GEMMs then sit in fp16's normal range
+        # (hidden-state gradients are ~1e-5 per element unscaled, fp16's smallest normal is 6e-5) - and `_collect` divides by S.
+        amax = float(dlogits.abs().max())
+        self.grad_scale = 2.0 ** round(math.log2(512.0 / amax)) if amax > 0 and math.isfinite(amax) else 1.0
+        dl2 = torch.zeros((t_n, 2), dtype=torch.float32, device=dev)
+        dl2[:, 0] = T.eltwise(dlogits.reshape(-1).float().contiguous(), T.MODE_SCALE, p_drop=self.grad_scale)
+        dy1 = self.c2.bwd(sv["y16"], dl2)
+        dz1 = T.eltwise(sv["z1"], T.MODE_RELU_BWD, dy1)
+        dhid = self.c0.bwd(sv["hid16"], dz1)                                        # (T, 2D)
+        dh = []
+        for b in (0, 1):
+            x = torch.zeros((r, d), dtype=torch.float32, device=dev)
+            x[sv["cls_rows"]] = dhid[:, b * d:(b + 1) * d]
+            dh.append(x)
+        add = lambda x, y: T.eltwise(x, T.MODE_ADD, y)
+        undrop = lambda x, site: x if self.p_hidden <= 0 else T.eltwise(x, T.MODE_DROPOUT, p_drop=self.p_hidden, seed=site)
+        for i in reversed(range(len(self.layers))):
+            ly, s = self.layers[i], sv["layers"][i]
+            dpre2 = []
+            for b in (0, 1):
+                dpre3 = ly["ln3"].bwd(s["pre3"][b], dh[b])
+                do = undrop(dpre3, self._site(i, b, 5))
+                df = ly["w2"].bwd(s["f16"][b], do)
+                dz = T.eltwise(s["z"][b], T.MODE_GELU_BWD, df)
+                dx = add(ly["w1"].bwd(s["x16"][b], dz), dpre3)
+                dpre2.append(ly[f"ln2{b}"].bwd(s["pre2"][b], dx))
+            dm = undrop(add(dpre2[0], dpre2[1]), self._site(i, 2, 4))
+            if ly["merge"] is None:
+                half = T.eltwise(dm, T.MODE_SCALE, p_drop=0.5)
+                dd = [half, half]
+            else:
+                dcat = ly["merge"].bwd(s["cat16"], dm)
+                dd = [dcat[:, :d].contiguous(), dcat[:, d:].contiguous()]
+            dh_in = []
+            for b in (0, 1):
+                dc = ly[f"d{b}"].bwd(s["c"][b], dd[b])
+                dcq, dck, dcv = self._attn_bwd(dc, s["cq"][b], s["ck"][b], s["cv"][b], t_n, l, n, s["ca"][b])
+                ly[f"ck{b}"].bwd(sv["cand16"], dck, need_dx=False)                  # image tokens are inputs: no gradient beyond the weights
+                ly[f"cv{b}"].bwd(sv["cand16"], dcv, need_dx=False)
+                da = add(ly[f"cq{b}"].bwd(s["a16"][b], dcq), dpre2[b])
+                dpre1 = ly[f"ln1{b}"].bwd(s["pre1"][b], da)
+                dt_ = undrop(dpre1, self._site(i, b, 2))
+                dctx = ly[f"o{b}"].bwd(s["ctx"][b], dt_)
+                dq, dk, dv = self._attn_bwd(dctx, s["q"][b], s["k"][b], s["v"][b], t_n, l, l, s["sa"][b])
+                dhb = dpre1
+                for nm, gr in (("q", dq), ("k", dk), ("v", dv)):
+                    dhb = add(dhb, ly[f"{nm}{b}"].bwd(s["h16"][b], gr))
+                dh_in.append(dhb)
+            dh = dh_in
+        # branch 1 entered through BertEmbeddings; branch 0 is z_t (frozen stage I)
+        de = undrop(dh[1], self._site(9000))
+        dpre_e = self.ln_e.bwd(sv["pre_e"], de)
+        T.embed_bwd(sv["ids"].view(-1), dpre_e, self.dword, self.dpos, l)
+        return self._collect()
+
+    def _collect(self) -> Dict[str, torch.Tensor]:
+        out = self._collect_scaled()
+        inv = 1.0 / self.grad_scale
+        return out if inv == 1.0 else {k: T.eltwise(g, T.MODE_SCALE, p_drop=inv) for k, g in out.items()}
+
+    def _collect_scaled(self) -> Dict[str, torch.Tensor]:
+        out = {}
+        e = "text_encoder.embeddings."
+        out[e + "word_embeddings.weight"], out[e + "position_embeddings.weight"] = self.dword, self.dpos
+        out[e + "LayerNorm.weight"], out[e + "LayerNorm.bias"] = self.ln_e.dg, self.ln_e.db
+
+        def put(name, lin):
+            out[name + ".weight"] = lin.dw
+            if lin.db is not None:
+                out[name + ".bias"] = lin.db
+        for i, ly in enumerate(self.layers):
+            p = f"text_encoder.encoder.layer.{i}."
+            for b in (0, 1):
+                for nm, ref in (("q", "query"), ("k", "key"), ("v", "value")):
+                    put(p + f"attention.self{b}.{ref}", ly[f"{nm}{b}"])
+                    put(p + f"crossattention.self{b}.{ref}", ly[f"c{nm}{b}"])
+                put(p + f"attention.output.dense{b}", ly[f"o{b}"])
+                put(p + f"crossattention.output.dense{b}", ly[f"d{b}"])
+            for c, b in (("A", 0), ("B", 1)):
+                out[p + f"attention.output.LayerNorm{c}.weight"], out[p + f"attention.output.LayerNorm{c}.bias"] = ly[f"ln1{b}"].dg, ly[f"ln1{b}"].db
+                out[p + f"crossattention.output.LayerNorm{c}.weight"], out[p + f"crossattention.output.LayerNorm{c}.bias"] = ly[f"ln2{b}"].dg, ly[f"ln2{b}"].db
+            if ly["merge"] is not None:
+                put(p + "crossattention.output.merge_layer", ly["merge"])
+            put(p + "intermediate.dense", ly["w1"])
+            put(p + "output.dense", ly["w2"])
+            out[p + "output.LayerNorm.weight"], out[p + "output.LayerNorm.bias"] = ly["ln3"].dg, ly["ln3"].db
+        put("cls_head.0", self.c0)
+        put("cls_head.2", self.c2)
+        return out
+
+
+class _FusionTrainFn(torch.autograd.Function):
+    """One autograd node around NlvrTrainer.forward / backward: `loss.backward()` of the reference's training step reaches
+    the hand-written reverse pass through it.  `anchor` is a trainable parameter (it makes the node differentiable); every
+    other parameter's gradient is accumulated into `.grad` directly, as autograd's AccumulateGrad would."""
+
+    @staticmethod
+    def forward(ctx, anchor, trainer, z_t, feats, ids, mask):
+        ctx.trainer = trainer
+        return trainer.forward(z_t, feats, ids, mask)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        tr = ctx.trainer
+        grads = tr.backward(dlogits.contiguous().float())
+        anchor_grad = None
+        for name, p in tr.model.named_parameters():
+            if name not in grads:
+                continue
+            gq = grads[name].view_as(p)
+            if name == tr.anchor_name:
+                anchor_grad = gq
+            else:
+                p.grad = gq.clone() if p.grad is None else T.eltwise(p.grad.contiguous(), T.MODE_ADD, gq.contiguous())
+        return anchor_grad, None, None, None, None, None
+
+
+def fusion_train(model, z_t, feats, ids, mask, p_hidden: float = 0.1, p_attn: float = 0.1, seed: int = 0) -> torch.Tensor:
+    """(B, B) logits of `img_txt_fusion` in training mode, differentiable w.r.t. the model's text_encoder / cls_head parameters."""
+    tr = getattr(model, "_trainer", None)
+    if tr is None or (tr.p_hidden, tr.p_attn) != (float(p_hidden), float(p_attn)):
+        tr = model._trainer = NlvrTrainer(model, p_hidden, p_attn, seed)
+    tr.anchor_name = "cls_head.2.bias"
+    anchor = dict(model.named_parameters())[tr.anchor_name]
+    return _FusionTrainFn.apply(anchor, tr, z_t, feats, ids, mask)
+
+
+class AdamW:
+    """torch.optim.AdamW's update rule on cir_adamw_step (stage2_train.py:138 builds that optimizer), fp32 master parameters."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.params = [p for p in params if p.requires_grad]
+        self.lr, self.betas, self.eps, self.wd, self.t = lr, betas, eps, weight_decay, 0
+        self.m = [torch.zeros_like(p, dtype=torch.float32) for p in self.params]
+        self.v = [torch.zeros_like(p, dtype=torch.float32) for p in self.params]
+
+    @torch.no_grad()
+    def step(self):
+        self.t += 1
+        for p, m, v in zip(self.params, self.m, self.v):
+            if p.grad is not None:
+                T.adamw_step(p.data, p.grad.contiguous(), m, v, self.lr, self.betas, self.eps, self.wd, self.t)
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None

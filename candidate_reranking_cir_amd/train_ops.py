@@ -1,0 +1,122 @@
+"""Tensor-level wrappers of the training-mode entry points of libcirrank (include/cirrank.h, "Training-mode operators";
+SURVEY section 8(f)-4).  Same rules as `ops`: CUDA tensors only, no fallback, work on torch's current stream."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import lib as _lib
+from .ops import _DT, _need_cuda, _ptr, _stream
+
+MODE_GELU, MODE_GELU_BWD, MODE_RELU, MODE_RELU_BWD, MODE_DROPOUT, MODE_ADD, MODE_SCALE = 0, 1, 2, 3, 4, 5, 6
+
+
+def transpose16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x (R, C) or (B, R, C) 16-bit with unit last stride -> (…, C, R) contiguous."""
+    _need_cuda(x, out)
+    x3 = x if x.dim() == 3 else x.unsqueeze(0)
+    b, r, c = x3.shape
+    assert x3.stride(2) == 1 and x3.dtype in (torch.bfloat16, torch.float16)
+    if out is None:
+        out = torch.empty((b, c, r) if x.dim() == 3 else (c, r), dtype=x.dtype, device=x.device)
+    o3 = out if out.dim() == 3 else out.unsqueeze(0)
+    assert o3.shape == (b, c, r) and o3.stride(2) == 1
+    _lib.check(_lib.load().cir_transpose16(x3.data_ptr(), o3.data_ptr(), r, c, x3.stride(1), o3.stride(1), b, x3.stride(0) if b > 1 else 0,
+                                           o3.stride(0) if b > 1 else 0, _DT[x.dtype], _stream()), "cir_transpose16")
+    return out
+
+
+def bmm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False, out: Optional[torch.Tensor] = None,
+        out_dtype: Optional[torch.dtype] = None, alpha: float = 1.0, accumulate: bool = False) -> torch.Tensor:
+    """out[i] = alpha * op(a[i]) @ op(b[i]) (+ out[i]); a, b (B, ., .) views with unit last stride and any row / batch strides."""
+    _need_cuda(a, b, out)
+    assert a.dim() == 3 and b.dim() == 3 and a.shape[0] == b.shape[0] and a.stride(2) == 1 and b.stride(2) == 1 and a.dtype == b.dtype
+    nb = a.shape[0]
+    m, k = (a.shape[2], a.shape[1]) if trans_a else (a.shape[1], a.shape[2])
+    k2, n = (b.shape[2], b.shape[1]) if trans_b else (b.shape[1], b.shape[2])
+    assert k == k2, (a.shape, b.shape, trans_a, trans_b)
+    out_dtype = out_dtype or (out.dtype if out is not None else a.dtype)
+    if out is None:
+        out = torch.empty((nb, m, n), dtype=out_dtype, device=a.device)
+    assert out.shape == (nb, m, n) and out.stride(2) == 1 and out.dtype == out_dtype
+    lib = _lib.load()
+    for b0 in range(0, nb, 65535):                                   # grid.z limit
+        b1 = min(nb, b0 + 65535)
+        _lib.check(lib.cir_bmm(a[b0:b1].data_ptr(), b[b0:b1].data_ptr(), out[b0:b1].data_ptr(), m, n, k, a.stride(1), b.stride(1), out.stride(1),
+                               int(trans_a), int(trans_b), b1 - b0, a.stride(0), b.stride(0), out.stride(0), float(alpha), int(accumulate),
+                               _DT[a.dtype], _DT[out_dtype], _stream()), "cir_bmm")
+    return out
+
+
+def softmax_dropout(s: torch.Tensor, mask: Optional[torch.Tensor], rows_per_mask: int, scale: float, p_drop: float, seed: int, dtype: torch.dtype):
+    """s fp32 (rows, cols) contiguous; mask fp32 (groups, cols) additive, one row per `rows_per_mask` consecutive rows of s, or None
+    -> (P, dropout(P)) in `dtype`."""
+    _need_cuda(s, mask)
+    rows, cols = s.shape
+    assert s.dtype == torch.float32 and s.is_contiguous()
+    p = torch.empty((rows, cols), dtype=dtype, device=s.device)
+    pd = torch.empty_like(p)
+    if mask is not None:
+        assert mask.dtype == torch.float32 and mask.stride(-1) == 1 and mask.shape[-1] == cols
+    _lib.check(_lib.load().cir_softmax_dropout(s.data_ptr(), cols, _ptr(mask), int(rows_per_mask), mask.stride(0) if mask is not None else 0,
+                                               p.data_ptr(), pd.data_ptr(), cols, rows, cols, float(scale), float(p_drop), int(seed) & (2 ** 63 - 1),
+                                               _DT[dtype], _stream()), "cir_softmax_dropout")
+    return p, pd
+
+
+def softmax_dropout_bwd(p: torch.Tensor, dpd: torch.Tensor, scale: float, p_drop: float, seed: int) -> torch.Tensor:
+    """P 16-bit (rows, cols), dPd fp32 (rows, cols) -> dS 16-bit (rows, cols)."""
+    _need_cuda(p, dpd)
+    rows, cols = p.shape
+    assert p.is_contiguous() and dpd.is_contiguous() and dpd.dtype == torch.float32 and dpd.shape == p.shape
+    ds = torch.empty_like(p)
+    _lib.check(_lib.load().cir_softmax_dropout_bwd(p.data_ptr(), cols, dpd.data_ptr(), cols, ds.data_ptr(), cols, rows, cols, float(scale), float(p_drop),
+                                                   int(seed) & (2 ** 63 - 1), _DT[p.dtype], _stream()), "cir_softmax_dropout_bwd")
+    return ds
+
+
+def layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor, eps: float) -> torch.Tensor:
+    """x, dy fp32 (rows, cols) contiguous; dgamma / dbeta fp32 (cols) are ACCUMULATED into -> dx fp32."""
+    _need_cuda(x, gamma, dy, dgamma, dbeta)
+    rows, cols = x.shape
+    assert x.dtype == dy.dtype == gamma.dtype == dgamma.dtype == dbeta.dtype == torch.float32 and x.is_contiguous() and dy.is_contiguous()
+    dx = torch.empty_like(x)
+    _lib.check(_lib.load().cir_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, cols,
+                                             float(eps), _stream()), "cir_layernorm_bwd")
+    return dx
+
+
+def eltwise(z: torch.Tensor, mode: int, dy: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, p_drop: float = 0.0,
+            seed: int = 0) -> torch.Tensor:
+    """Elementwise modes of cir_eltwise on contiguous tensors (see the MODE_* constants)."""
+    _need_cuda(z, dy)
+    assert z.is_contiguous() and (dy is None or (dy.is_contiguous() and dy.dtype == torch.float32 and dy.numel() == z.numel()))
+    out = torch.empty(z.shape, dtype=out_dtype or z.dtype, device=z.device)
+    _lib.check(_lib.load().cir_eltwise(z.data_ptr(), _DT[z.dtype], _ptr(dy), out.data_ptr(), _DT[out.dtype], z.numel(), mode, float(p_drop),
+                                       int(seed) & (2 ** 63 - 1), _stream()), "cir_eltwise")
+    return out
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out (cols) fp32 += column sums of x fp32 (rows, cols) (unit last stride)."""
+    _need_cuda(x, out)
+    assert x.dtype == out.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and out.shape == (x.shape[1],)
+    _lib.check(_lib.load().cir_colsum(x.data_ptr(), x.stride(0), out.data_ptr(), x.shape[0], x.shape[1], _stream()), "cir_colsum")
+    return out
+
+
+def embed_bwd(ids: torch.Tensor, dy: torch.Tensor, dword: torch.Tensor, dpos: torch.Tensor, length: int):
+    """ids (rows,) int64, dy fp32 (rows, cols): dword[ids[r]] += dy[r], dpos[r % length] += dy[r]."""
+    _need_cuda(ids, dy, dword, dpos)
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and dy.dtype == torch.float32 and dy.is_contiguous()
+    _lib.check(_lib.load().cir_embed_bwd(ids.data_ptr(), dy.data_ptr(), dword.data_ptr(), dpos.data_ptr(), dy.shape[0], int(length), dy.shape[1], _stream()),
+               "cir_embed_bwd")
+
+
+def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
+               weight_decay: float = 0.01, step: int = 1):
+    _need_cuda(p, g, m, v)
+    assert all(t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel() for t in (p, g, m, v))
+    _lib.check(_lib.load().cir_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(betas[0]), float(betas[1]),
+                                          float(eps), float(weight_decay), int(step), _stream()), "cir_adamw_step")

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CIR_ABI_VERSION 6
+#define CIR_ABI_VERSION 7
 
 enum { CIR_BF16 = 0, CIR_F16 = 1, CIR_F32 = 2 };
 enum { CIR_ACT_NONE = 0, CIR_ACT_GELU = 1, CIR_ACT_RELU = 2 };
@@ -190,6 +190,43 @@ int cir_linear_f32(const float* x, int64_t ldx, const float* W, const float* bia
 
 /* y = x / max(||x||_2, 1e-12) row-wise, fp32 (F.normalize at blip_stage1.py:58, 83). */
 int cir_l2_normalize(const float* x, float* y, int64_t rows, int cols, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * Training-mode operators: what BLIP_NLVR.img_txt_fusion in train() mode and its backward need
+ * besides the operators above (blip_stage2.py:65-99 driven by stage2_train.py:202-216; dropout nlvr_encoder.py:86-90, 207,
+ * 250-264, 397).  The dense layers' dgrad / wgrad run on cir_gemm_bias_act over transposed copies (cir_transpose16).
+ * Dropout is counter-based: element i of a launch is kept iff hash(seed, i) >= p, scaled by 1 / (1 - p); the backward
+ * operators regenerate the same mask from the same (seed, p) - no mask tensor exists.  None of these is on the inference path.
+ */
+/* dst[b][c][r] = src[b][r][c], 16-bit elements (dtype CIR_BF16 / CIR_F16 names the payload only). */
+int cir_transpose16(const void* src, void* dst, int rows, int cols, int64_t ld_src, int64_t ld_dst, int batch, int64_t s_src, int64_t s_dst,
+                    int dtype, void* stream);
+/* C[b] = alpha * op(A[b]) * op(B[b]) (+ C[b] if accumulate): op(A) (M,K) from A (M,K) [trans_a 0] or (K,M) [1]; op(B) (K,N) from B
+ * (K,N) [trans_b 0] or (N,K) [1].  Any extents; fp32 accumulate.  in_dtype CIR_BF16 / CIR_F16 / CIR_F32; out_dtype = in_dtype or
+ * CIR_F32.  The attention pieces of the backward pass (Q K^T, P V, dP, dQ, dK, dV: 32 x 32 / 32 x 197 tiles per head). */
+int cir_bmm(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b, int batch,
+            int64_t sA, int64_t sB, int64_t sC, float alpha, int accumulate, int in_dtype, int out_dtype, void* stream);
+/* P = softmax(S * scale + mask) per row (S fp32 (rows, cols); mask fp32 (cols) shared by each group of rows_per_mask rows, or
+ * NULL), Pd = dropout(P, p_drop, seed); both 16-bit (dtype).  nlvr_encoder.py:183-207. */
+int cir_softmax_dropout(const float* S, int64_t ld_s, const float* mask, int64_t rows_per_mask, int64_t ld_mask, void* P, void* Pd, int64_t ld_p,
+                        int64_t rows, int cols, float scale, float p_drop, uint64_t seed, int dtype, void* stream);
+/* dS = scale * P * (dP - sum_cols(dP * P)), dP = dropout-backward(dPd) with the forward's (p_drop, seed); dPd fp32, dS 16-bit. */
+int cir_softmax_dropout_bwd(const void* P, int64_t ld_p, const float* dPd, int64_t ld_d, void* dS, int64_t ld_ds, int64_t rows, int cols,
+                            float scale, float p_drop, uint64_t seed, int dtype, void* stream);
+/* LayerNorm backward from the saved fp32 input x of the forward: dx (written), dgamma / dbeta (fp32, ACCUMULATED atomically). */
+int cir_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int64_t rows, int cols,
+                      float eps, void* stream);
+/* mode 0: out = gelu(z) (erf form, ACT2FN['gelu']); 1: out = dy * gelu'(z); 2: relu(z); 3: dy * (z > 0); 4: dropout(z, p_drop, seed);
+ * 5: z + dy; 6: p_drop * z (scale).  z in z_dtype (CIR_F32 / CIR_BF16 / CIR_F16), dy fp32, out in out_dtype. */
+int cir_eltwise(const void* z, int z_dtype, const float* dy, void* out, int out_dtype, int64_t n, int mode, float p_drop, uint64_t seed, void* stream);
+/* out[c] += sum_r x[r][c] (bias gradients; fp32, atomics). */
+int cir_colsum(const float* x, int64_t ld, float* out, int64_t rows, int cols, void* stream);
+/* BertEmbeddings backward (nlvr_encoder.py:49-91): dword[ids[r]] += dy[r], dpos[r % L] += dy[r] (fp32, atomics). */
+int cir_embed_bwd(const int64_t* ids, const float* dy, float* dword, float* dpos, int64_t rows, int L, int cols, void* stream);
+/* torch.optim.AdamW step in place on fp32 parameter / moments (stage2_train.py:120-126 builds that optimizer). */
+int cir_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   int step, void* stream);
 
 #ifdef __cplusplus
 }

@@ -225,6 +225,30 @@ def img_txt_fusion_val(w: Weights, z_t: torch.Tensor, cand: torch.Tensor, input_
     return y[:, 0]
 
 
+def img_txt_fusion_train(w: Weights, z_t: torch.Tensor, feats: torch.Tensor, input_ids: torch.Tensor,
+                          attention_mask: torch.Tensor, enc_token_id: int = 30523, relu_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """BLIP_NLVR.img_txt_fusion, blip_stage2.py:65-99 -> (B, B): row i runs caption i / z_t[i] (expanded to B rows, :83-87)
+    against all B target images, rows stacked (:94), cls_head, column 0 (:96-99).  Dropout-free (p = 0 or eval mode);
+    differentiable: with `requires_grad` weights, torch autograd over this function is the gradient oracle of the training
+    step (stage2_train.py:210-216), pinned by tests/golden/train768.npz.
+
+    `relu_mask` ((B*B, hidden) bool, optional) replaces cls_head's ReLU by a multiplication with that mask: the same function on
+    the linear piece the mask selects.  The gradient of the head is discontinuous where a pre-activation crosses zero, so a
+    16-bit forward whose pre-activations differ by 1e-3 takes a different piece for a handful of the B*B*hidden entries (each
+    flip moves that row's whole gradient by ~1/sqrt(hidden/2)); tests that check the BACKWARD arithmetic pass the mask of the
+    forward under test, tests that check the forward leave it out."""
+    b = z_t.shape[0]
+    ids = input_ids.clone()
+    ids[:, 0] = enc_token_id                                                   # blip_stage2.py:71
+    rows = []
+    for i in range(b):
+        hid = nlvr_forward(w, ids[i:i + 1].expand(b, -1), attention_mask[i:i + 1].expand(b, -1), z_t[i:i + 1].expand(b, -1, -1), feats)
+        y = F.linear(hid, w["cls_head.0.weight"], w["cls_head.0.bias"])
+        y = F.relu(y) if relu_mask is None else y * relu_mask[i * b:(i + 1) * b].to(y.dtype)
+        rows.append(F.linear(y, w["cls_head.2.weight"], w["cls_head.2.bias"])[:, 0])
+    return torch.stack(rows)
+
+
 def img_embed(w: Weights, image: torch.Tensor) -> torch.Tensor:
     """BLIP_NLVR.img_embed, blip_stage2.py:57-63."""
     return vit_forward(w, image)

@@ -503,6 +503,53 @@ def vitl_goldens(R):
     print("vitl_tiny: tokens", tuple(y.shape), "abs mean", y.abs().mean().item())
 
 
+def grad_sample_index(numel: int, n: int = 64) -> np.ndarray:
+    """The fixed positions of a flattened gradient the training fixture keeps (spread over the tensor by a multiplicative hash)."""
+    return (np.arange(n, dtype=np.int64) * 2654435761 + 12345) % numel
+
+
+def train_goldens(R, full_bert):
+    """tests/golden/train768.npz: ONE training step's forward + backward of the real reference (SURVEY 8(f)-4,
+    stage2_train.py:202-216) with the full 12-layer med_config (blip_stage2.py:81 hard-codes the 768-wide hidden state) over a
+    2-block 64-px ViT (17 image tokens), on CPU in fp32: BLIP_NLVR in .train() mode with both dropout probabilities
+    set to 0 (the only way a mask-free fixture can pin the arithmetic), `logits = model.img_txt_fusion(z_t, target_feats,
+    captions, train=True)` for B = 4 ragged captions, cross-entropy against arange(B), loss.backward().  Stored: the inputs
+    (z_t, target tokens, ids, mask), logits, loss, and for every parameter that received a gradient its L2 norm, its sum and
+    64 sampled entries (`grad_sample_index`); the small cls_head tensors and two LayerNorm gradients in full."""
+    cfg = dict(full_bert, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    vit = dict(image_size=64, width=768, depth=2, num_heads=12)
+    m2, m1, g, v = build_reference_models(R, cfg, vit, seed=11, profile="test")      # "spread" saturates the self-attention
+    b = 4                                                                             # softmax: q/k gradients ~1e-11 of the largest
+    caps = [synthetic.caption_text(70 + i, n) for i, n in enumerate((5, 9, 3, 7))]
+    with torch.no_grad():
+        feats = m2.img_embed(synthetic.scene_images(range(2 * b), v.image_size))
+        z = m1.img_txt_fusion(feats[:b], feats[:b], caps, train=False, return_raw=True)
+    m2.train()
+    for p in m2.visual_encoder.parameters():                                     # blip_img_tune False: the ViT is frozen
+        p.requires_grad_(False)
+    logits = m2.img_txt_fusion(z, feats[b:], caps, train=True)
+    loss = torch.nn.functional.cross_entropy(logits, torch.arange(b))
+    loss.backward()
+    tok = m2.tokenizer(caps, padding="longest", return_tensors="pt")
+    ids = tok.input_ids.clone(); ids[:, 0] = m2.tokenizer.enc_token_id
+    names, norms, sums, samples, full = [], [], [], [], {}
+    for name, p in m2.named_parameters():
+        if p.grad is None:
+            continue
+        gq = p.grad.detach().flatten()
+        names.append(name); norms.append(gq.double().norm().item()); sums.append(gq.double().sum().item())
+        samples.append(gq[torch.from_numpy(grad_sample_index(gq.numel()))].numpy())
+        if (name.startswith("cls_head.") and gq.numel() <= 4096) or name in ("text_encoder.encoder.layer.0.attention.output.LayerNormA.weight",
+                                                    "text_encoder.encoder.layer.11.output.LayerNorm.bias"):
+            full["full__" + name] = p.grad.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "train768.npz"), bert_cfg=json.dumps(cfg), vit_cfg=json.dumps(vit), seed=11, profile="test",
+                        caps=np.array(caps), input_ids=ids.numpy(), attention_mask=tok.attention_mask.numpy(),
+                        z_t=z.last_hidden_state.numpy(), feats=feats[b:].numpy(), logits=logits.detach().numpy(), loss=loss.item(),
+                        names=np.array(names), norms=np.array(norms), sums=np.array(sums), samples=np.stack(samples), **full)
+    print("train768: loss", loss.item(), "logits sigma", logits.std().item(), "params with grad", len(names),
+          "norm range", min(norms), max(norms))
+
+
 def tiny_goldens(R, ref_val):
     """tests/golden/tiny_loop.npz + masks.npz: reduced geometry through the reference's own loops.  Weights use the
     "spread" profile and the index images are structured (synthetic.scene_image), so that the candidates of a query get
@@ -574,6 +621,13 @@ def main():
         _, ref_val = _import_reference_scripts()
         full_bert = json.load(open(os.path.join(ref_shim.REFERENCE_ROOT, "configs", "med_config.json")))
         return outlier_goldens(R, ref_val, full_bert)
+    if len(sys.argv) > 1 and sys.argv[1] == "train":    # only the training-step (forward + backward) fixture
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        R = ref_shim.load_reference_modules()
+        _install_torchvision_stub()
+        full_bert = json.load(open(os.path.join(ref_shim.REFERENCE_ROOT, "configs", "med_config.json")))
+        return train_goldens(R, full_bert)
     if len(sys.argv) > 1 and sys.argv[1] == "ckpt":     # only the checkpoint-loader fixture
         torch.manual_seed(0)
         R = ref_shim.load_reference_modules()

@@ -59,3 +59,8 @@ def fiq_caption(pair):
 def tokenize(texts):
     enc = synthetic.HashTokenizer()(list(texts))
     return enc.input_ids, enc.attention_mask
+
+
+def grad_sample_index(numel: int, n: int = 64) -> np.ndarray:
+    """The positions of a flattened gradient kept by tests/golden/train768.npz (oracle/make_golden.py: grad_sample_index)."""
+    return (np.arange(n, dtype=np.int64) * 2654435761 + 12345) % numel

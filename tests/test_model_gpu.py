@@ -454,9 +454,9 @@ def test_img_txt_fusion_bxb_matches_reference(cuda, dtype):
     e = np.abs(out.cpu().numpy() - z["logits"]).max()
     print(f"\n[bxb224 {dtype}] z_t cls {e_z:.3e}  logits {e:.3e} (sigma {z['logits'].std():.3f})")
     assert e_z < TOK_TOL[dtype] and e < LOGIT_TOL["bxb224"][dtype]
-    m2.train()
-    with pytest.raises(NotImplementedError, match="forward only"):
-        m2.img_txt_fusion(zt, bank[4:8], caps)
+    m2.train()                                          # training mode: the differentiable surface (tests/test_train_gpu.py); with
+    with torch.no_grad():                               # autograd off it is the same inference path
+        assert torch.equal(m2.img_txt_fusion(zt, bank[4:8], caps), out)
     m2.eval()
 
 

@@ -171,3 +171,36 @@ def test_vit_large_tiny():
         y = O.vit_forward(sd, synthetic.images(z["image_ids"].tolist(), 64), n_heads=16)
     np.testing.assert_allclose(y[:, :, :16].numpy(), z["tokens_slice"], atol=1e-4)
     assert abs(y.double().sum().item() - float(z["tokens_sum"])) < 1e-1
+
+
+def test_training_step_gradients():
+    """The gradient oracle (torch autograd through O.img_txt_fusion_train) against ONE training step of the
+    real reference (tests/golden/train768.npz: BLIP_NLVR.train() with dropout 0, img_txt_fusion, cross-entropy, backward):
+    logits, loss, the set of parameters that receive a gradient, every gradient's norm, sum and 64 sampled entries."""
+    import json
+    import torch.nn.functional as F
+    z = H.load("train768.npz")
+    g, v = H.geometry(json.loads(str(z["bert_cfg"])), json.loads(str(z["vit_cfg"])))
+    sd2, _ = H.state_dicts(g, v, int(z["seed"]), str(z["profile"]))
+    torch.set_num_threads(8)
+    w = {k: t.clone().float() for k, t in sd2.items()}
+    keys = [k for k in w if k.startswith(("text_encoder.", "cls_head.")) and w[k].is_floating_point()]
+    for k in keys:
+        w[k].requires_grad_(True)
+    logits = O.img_txt_fusion_train(w, torch.from_numpy(z["z_t"]), torch.from_numpy(z["feats"]), torch.from_numpy(z["input_ids"]),
+                                    torch.from_numpy(z["attention_mask"]))
+    loss = F.cross_entropy(logits, torch.arange(4))
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().numpy(), z["logits"], atol=2e-4)
+    assert abs(loss.item() - float(z["loss"])) < 1e-4
+    names = [str(n) for n in z["names"]]
+    assert sorted(names) == sorted(k for k in keys if w[k].grad is not None)
+    gmax = float(z["norms"].max())
+    for i, n in enumerate(names):
+        gq = w[n].grad.flatten()
+        assert abs(gq.double().norm().item() - float(z["norms"][i])) < 1e-3 * float(z["norms"][i]) + 1e-7 * gmax, n
+        got = gq[torch.from_numpy(H.grad_sample_index(gq.numel()))].numpy()
+        np.testing.assert_allclose(got, z["samples"][i], atol=1e-3 * float(z["norms"][i]) / np.sqrt(gq.numel()) * 8 + 1e-7 * gmax, err_msg=n)
+    for key in z.files:
+        if key.startswith("full__"):
+            np.testing.assert_allclose(w[key[6:]].grad.numpy(), z[key], atol=1e-3 * np.abs(z[key]).max() + 1e-7 * gmax, err_msg=key)
