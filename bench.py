@@ -340,6 +340,68 @@ def loop_mode(args, m2, m1, dev, dt):
         "logits_max_abs_diff_bank_vs_loop": float((lg[0] - lg_b[0]).abs().max()) if ns else float((lg - lg_b).abs().max())}), flush=True)
 
 
+def train_mode(args, m2, m1, dev, dt):
+    """One stage-II TRAINING step (stage2_train.py:176-218 with the default frozen ViT), timed end to end:
+    reference + target images through the ViT (no grad), z_t from the frozen stage-I model, `img_txt_fusion` in .train() mode
+    (dropout 0.1, B x B triplets), cross-entropy against arange(B), backward through the hand-written reverse pass, AdamW.
+    Reported separately from the headline metric; unit: triplets (B*B per step) forward+backward per second."""
+    import torch.nn.functional as F
+    from candidate_reranking_cir_amd import synthetic
+    from candidate_reranking_cir_amd.train import AdamW
+    b, l = args.train_batch, args.tokens
+    gen = torch.Generator(device=dev).manual_seed(5)
+    ref = torch.randn((b, 3, args.image_size, args.image_size), generator=gen, device=dev).to(dt)
+    tgt = torch.randn((b, 3, args.image_size, args.image_size), generator=gen, device=dev).to(dt)
+    ids = torch.stack([synthetic.caption_ids(q, l) for q in range(b)])
+    enc = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
+    for n, p in m2.named_parameters():
+        p.requires_grad_(not n.startswith("visual_encoder."))           # blip_img_tune False (stage2_train.py:87-92)
+    m2.train()
+    opt = AdamW([p for p in m2.parameters() if p.requires_grad], lr=2e-5, weight_decay=0.05)
+    gt = torch.arange(b, device=dev)
+    sync = torch.cuda.synchronize
+    legs = {"vit": 0.0, "z_t": 0.0, "fusion_forward": 0.0, "backward": 0.0, "adamw": 0.0}
+
+    def step(timed_legs=False):
+        def mark(name, t0):
+            if timed_legs:
+                sync(); legs[name] += time.perf_counter() - t0
+            return time.perf_counter()
+        t = time.perf_counter()
+        with torch.no_grad():
+            rf, tf = m2.img_embed(ref).float(), m2.img_embed(tgt).float()
+            t = mark("vit", t)
+            z = m1.img_txt_fusion(rf, rf, enc, train=False, return_raw=True)
+            t = mark("z_t", t)
+        opt.zero_grad()
+        logits = m2.img_txt_fusion(z, tf, enc, train=True)
+        loss = F.cross_entropy(logits, gt)
+        t = mark("fusion_forward", t)
+        loss.backward()
+        t = mark("backward", t)
+        opt.step()
+        mark("adamw", t)
+        return loss
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt_s = (time.perf_counter() - t0) / args.steps
+    step(True)
+    n_tok = (args.image_size // 16) ** 2 + 1
+    print(json.dumps({
+        "metric": "stage-II training step, query-target pairs (B x B) forward+backward per second (stage2_train.py loop; not the headline metric)",
+        "value": round(b * b / dt_s, 1), "unit": "triplets/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt_s * 1e3, 2), "higher_is_better": True, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"batch {b} (B x B = {b * b} triplets), {l} caption tokens, {n_tok} image tokens ({args.image_size} px), ViT frozen, "
+                               f"dropout 0.1, AdamW; fp32 residual stream"},
+        "legs_ms": {k: round(v * 1e3, 2) for k, v in legs.items()}, "loss": round(float(loss.detach()), 4)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -360,9 +422,10 @@ def main():
     ap.add_argument("--loop-queries", type=int, default=512, help="loop mode: queries of the synthetic split (CIRR val: 4181)")
     ap.add_argument("--query-batch", type=int, default=16, help="loop mode: queries per stage-II batch")
     ap.add_argument("--index-batch", type=int, default=256, help="loop mode: images per extract_index_features batch")
-    ap.add_argument("--mode", default="pixels", choices=["pixels", "bank", "loop"],
+    ap.add_argument("--mode", default="pixels", choices=["pixels", "bank", "loop", "train"],
                     help="pixels: headline metric (every candidate encoded from pixels); bank: SURVEY 8(f)-1 real-dataset regime, "
                          "candidates drawn from a resident index bank with cached ViT tokens and cross-attention K/V")
+    ap.add_argument("--train-batch", type=int, default=16, help="train mode: B of the B x B training step (Instructions_*.md: --batch-size 16)")
     ap.add_argument("--index-size", type=int, default=2297, help="bank mode: number of index images (CIRR val: 2297)")
     args = ap.parse_args()
 
@@ -412,6 +475,10 @@ def main():
     q_n, k, ns = args.queries, args.k, args.subset
     if args.mode == "bank":
         return bank_mode(args, m2, m1, dev, dt, rank, world)
+    if args.mode == "train":
+        if world != 1:
+            raise SystemExit("--mode train is a single-GPU measurement")
+        return train_mode(args, m2, m1, dev, dt)
     if args.mode == "loop":
         if world != 1:
             raise SystemExit("--mode loop is a single-GPU measurement")

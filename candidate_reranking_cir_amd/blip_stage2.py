@@ -76,6 +76,7 @@ class _EngineHost(nn.Module):
     def __init__(self):
         super().__init__()
         self._engines = None
+        self._text_stale = False               # set by a training step (train.py): text_encoder / cls_head changed, the ViT did not
         self.compute_dtype = torch.bfloat16
         self._stream_dtype = None              # None = automatic (see `stream_dtype`)
 
@@ -132,7 +133,7 @@ class BLIP_NLVR(_EngineHost):
         self.text_encoder.config = self.bert_geometry                        # callers read .config.hidden_size
 
     # ------------------------------------------------------------------------------------------
-    def engines(self):
+    def engines(self, text: bool = True):
         if self._engines is None:
             dev = self.device
             if dev.type != "cuda":
@@ -140,12 +141,17 @@ class BLIP_NLVR(_EngineHost):
             sd = self.state_dict()
             self._engines = (VitEngine(sd, self.vit_geometry, self.compute_dtype, dev, stream_dtype=self.stream_dtype),
                              NlvrEngine(sd, self.bert_geometry, self.compute_dtype, dev, fold_merge=self.fold_merge, stream_dtype=self.stream_dtype))
+            self._text_stale = False
+        elif self._text_stale and text:        # after training steps: repack the two-branch encoder only (the ViT is frozen there),
+            self._engines = (self._engines[0], NlvrEngine(self.state_dict(), self.bert_geometry, self.compute_dtype, self.device,
+                                                          fold_merge=self.fold_merge, stream_dtype=self.stream_dtype))
+            self._text_stale = False           # and only when a caller needs it (`text`): img_embed between steps does not
         return self._engines
 
     @torch.no_grad()
     def img_embed(self, image, train=True, atts=False):
         """(B,3,H,W) -> (B, N, D) fp32 image tokens [+ ones (B, N) int64], blip_stage2.py:57-63."""
-        y32, _ = self.engines()[0].forward(image.to(self.device), want32=True)
+        y32, _ = self.engines(text=False)[0].forward(image.to(self.device), want32=True)
         if atts:
             return y32, torch.ones(y32.shape[:-1], dtype=torch.long, device=y32.device)
         return y32
@@ -153,7 +159,7 @@ class BLIP_NLVR(_EngineHost):
     @torch.no_grad()
     def img_embed16(self, image) -> torch.Tensor:
         """Same tokens in the 16-bit compute dtype (what the fusion GEMMs consume)."""
-        return self.engines()[0].forward(image.to(self.device), want32=False)[1]
+        return self.engines(text=False)[0].forward(image.to(self.device), want32=False)[1]
 
     def _cand16(self, t_image_embeds: torch.Tensor) -> torch.Tensor:
         t = t_image_embeds.to(self.device)

@@ -46,13 +46,14 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* src, T* dst, in
 // 16 x 16 output tile per 256-thread block, fp32 accumulate; inputs TI (16-bit or float), output TO.
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void bmm_kernel(const TI* A, const TI* B, TO* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
-                                                  int ta, int tb, int64_t sA, int64_t sB, int64_t sC, float alpha, int accumulate) {
+                                                  int ta, int tb, int nb2, int64_t sA1, int64_t sA2, int64_t sB1, int64_t sB2, int64_t sC1, int64_t sC2,
+                                                  float alpha, int accumulate) {
     __shared__ float As[16][17], Bs[16][17];
-    const int b = blockIdx.z;
+    const int z1 = blockIdx.z / nb2, z2 = blockIdx.z % nb2;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx;
-    const TI* Ab = A + b * sA;
-    const TI* Bb = B + b * sB;
+    const TI* Ab = A + z1 * sA1 + z2 * sA2;
+    const TI* Bb = B + z1 * sB1 + z2 * sB2;
     float acc = 0.f;
     for (int k0 = 0; k0 < K; k0 += 16) {
         {   // A tile: element (ty = m-local, tx = k-local)
@@ -69,10 +70,169 @@ __global__ __launch_bounds__(256) void bmm_kernel(const TI* A, const TI* B, TO* 
         __syncthreads();
     }
     if (m < M && n < N) {
-        TO* cp = C + b * sC + (int64_t)m * ldc + n;
+        TO* cp = C + z1 * sC1 + z2 * sC2 + (int64_t)m * ldc + n;
         const float v = alpha * acc + (accumulate ? static_cast<float>(*cp) : 0.f);
         *cp = static_cast<TO>(v);
     }
+}
+
+// ---- the same product on the matrix cores (16-bit operands) ------------------------------------------------------------------
+// 64 x 64 output tile per 256-thread block (4 waves, 32 x 32 each = 2 x 2 MFMA 16x16x32 tiles), K in steps of 32 through LDS.
+// Every extent is arbitrary (edges are zero-filled / predicated) and each operand may be stored either way, so the adjoints
+// need no transposed copies: wgrad reads dy (rows, N) and x (rows, K) as they are (ta = 1), attention reads head slices of the
+// (rows, D) projections in place.  Two batch levels (z = z1 * nb2 + z2, a stride per level and operand): (candidate, head) or
+// (triplet, head) in one launch; split-K of a weight gradient is a batch over row chunks into partial sums.
+// 16-byte global loads when the host says the operand allows them (leading dimension and strides multiples of 8 elements,
+// base 16-byte aligned; a row then also has room for the 8-element read past a ragged edge), 2-byte loads otherwise.
+struct BmmArgs {
+    const void* A; const void* B; void* C;
+    int M, N, K;
+    int64_t lda, ldb, ldc;
+    int ta, tb, nb2;
+    int64_t sA1, sA2, sB1, sB2, sC1, sC2;
+    float alpha;
+    int accumulate, vecA, vecB;
+};
+
+constexpr int kBmmLd = 40;      // LDS row: 32 k-elements + 8 pad (80 bytes: 16-byte aligned fragments, rows spread over the banks)
+
+// 64 rows of an operand tile (rows r0 .. r0+63 of the M or N extent x 32 of K) from global memory into 8 registers per thread
+// kmajor = 0: stored (R, K), K contiguous: thread -> (row = tid / 4, 8 consecutive k)
+// kmajor = 1: stored (K, R), R contiguous: thread -> (k = tid / 8, 8 consecutive rows)
+template <typename T>
+__device__ __forceinline__ typename Elem<T>::x8 bmm_fetch(const T* base, int64_t ld, int kmajor, int R, int K, int r0, int k0, int vec, int tid) {
+    typedef typename Elem<T>::x8 X8;
+    X8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = static_cast<T>(0.f);
+    if (!kmajor) {
+        const int r = r0 + (tid >> 2), k = k0 + (tid & 3) * 8;
+        if (r < R && k < K) {
+            const T* p = base + (int64_t)r * ld + k;
+            if (vec) {
+                v = *reinterpret_cast<const X8*>(p);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) if (k + i >= K) v[i] = static_cast<T>(0.f);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) if (k + i < K) v[i] = p[i];
+            }
+        }
+    } else {
+        const int k = k0 + (tid >> 3), r = r0 + (tid & 7) * 8;
+        if (k < K && r < R) {
+            const T* p = base + (int64_t)k * ld + r;
+            if (vec) {
+                v = *reinterpret_cast<const X8*>(p);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) if (r + i >= R) v[i] = static_cast<T>(0.f);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) if (r + i < R) v[i] = p[i];
+            }
+        }
+    }
+    return v;
+}
+
+// LDS images of one operand tile (BT rows of the M / N extent x 32 of K):
+//   stored (R, K) [kmajor 0]: [BT][40] - a row's 32 k-elements + 8 pad; the MFMA fragment (row r15, k = 8g .. 8g+7) is one ds_read_b128
+//   stored (K, R) [kmajor 1]: [32][BT + 16] - as it comes from memory (16-byte writes, no scatter); the fragment is two
+//     ds_read_b64_tr_b16 (hardware transpose: a 16-lane group reads 4 k-rows x 16 r-columns and lane i receives column i)
+typedef __attribute__((address_space(3))) s16x4* bmm_lds_s16x4_ptr;
+
+template <typename T, int BT>
+__device__ __forceinline__ void bmm_stash(char* tile, typename Elem<T>::x8 v, int kmajor, int tid, int h) {
+    typedef typename Elem<T>::x8 X8;
+    if (!kmajor) *reinterpret_cast<X8*>(tile + (((tid >> 2) + h * 64) * kBmmLd + (tid & 3) * 8) * 2) = v;
+    else *reinterpret_cast<X8*>(tile + ((tid >> 3) * (BT + 16) + (tid & 7) * 8 + h * 64) * 2) = v;
+}
+
+template <typename T, int BT>
+__device__ __forceinline__ typename Elem<T>::x8 bmm_frag(const char* tile, int kmajor, int row0, int lane) {
+    typedef typename Elem<T>::x8 X8;
+    const int r15 = lane & 15, g = lane >> 4;
+    if (!kmajor) return *reinterpret_cast<const X8*>(tile + ((row0 + r15) * kBmmLd + g * 8) * 2);
+    const int q = r15 >> 2, p = r15 & 3;
+    const char* base = tile + ((8 * g + q) * (BT + 16) + row0 + 4 * p) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bmm_lds_s16x4_ptr)(base));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bmm_lds_s16x4_ptr)(base + 4 * (BT + 16) * 2));
+    s16x8 both;
+    both.s0 = lo.x; both.s1 = lo.y; both.s2 = lo.z; both.s3 = lo.w;
+    both.s4 = hi.x; both.s5 = hi.y; both.s6 = hi.z; both.s7 = hi.w;
+    return __builtin_bit_cast(X8, both);
+}
+
+// F = MFMA tiles per wave and dimension: F = 2 -> 64 x 64 block tile (small products: one head of self-attention is 32 x 32),
+// F = 4 -> 128 x 128 (16 MFMAs per wave between two barriers: the weight gradients and the stacked cross-attention products)
+template <typename T, typename TO, int F>
+__global__ __launch_bounds__(256) void bmm_mfma_kernel(BmmArgs a) {
+    typedef typename Elem<T>::x8 X8;
+    constexpr int BT = 32 * F, H = F / 2;                   // block tile extent; 64-row fetch slabs per operand
+    constexpr int kImg = (BT * kBmmLd > 32 * (BT + 16) ? BT * kBmmLd : 32 * (BT + 16)) * 2;
+    __shared__ __attribute__((aligned(16))) char As[kImg];
+    __shared__ __attribute__((aligned(16))) char Bs[kImg];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r15 = lane & 15, g = lane >> 4, wm = wave >> 1, wn = wave & 1;
+    const int z1 = blockIdx.z / a.nb2, z2 = blockIdx.z % a.nb2;
+    const T* A = reinterpret_cast<const T*>(a.A) + z1 * a.sA1 + z2 * a.sA2;
+    const T* B = reinterpret_cast<const T*>(a.B) + z1 * a.sB1 + z2 * a.sB2;
+    TO* C = reinterpret_cast<TO*>(a.C) + z1 * a.sC1 + z2 * a.sC2;
+    const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
+    const int ka = a.ta, kb = !a.tb;                        // A stored (K, M) when ta = 1; B stored (K, N) when tb = 0
+    f32x4 acc[F][F];
+#pragma unroll
+    for (int i = 0; i < F; ++i)
+#pragma unroll
+        for (int j = 0; j < F; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    X8 ra[H], rb[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        ra[h] = bmm_fetch<T>(A, a.lda, ka, a.M, a.K, m0 + h * 64, 0, a.vecA, tid);
+        rb[h] = bmm_fetch<T>(B, a.ldb, kb, a.N, a.K, n0 + h * 64, 0, a.vecB, tid);
+    }
+    for (int k0 = 0; k0 < a.K; k0 += 32) {
+        __syncthreads();                                     // the previous step's fragment reads are done
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            bmm_stash<T, BT>(As, ra[h], ka, tid, h);
+            bmm_stash<T, BT>(Bs, rb[h], kb, tid, h);
+        }
+        __syncthreads();
+        if (k0 + 32 < a.K) {                                 // next tile's loads fly under this tile's MFMAs
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                ra[h] = bmm_fetch<T>(A, a.lda, ka, a.M, a.K, m0 + h * 64, k0 + 32, a.vecA, tid);
+                rb[h] = bmm_fetch<T>(B, a.ldb, kb, a.N, a.K, n0 + h * 64, k0 + 32, a.vecB, tid);
+            }
+        }
+        X8 af[F], bf[F];
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+            af[i] = bmm_frag<T, BT>(As, ka, wm * 16 * F + i * 16, lane);
+            bf[i] = bmm_frag<T, BT>(Bs, kb, wn * 16 * F + i * 16, lane);
+        }
+#pragma unroll
+        for (int mi = 0; mi < F; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < F; ++ni) acc[mi][ni] = Elem<T>::mfma16(af[mi], bf[ni], acc[mi][ni]);
+    }
+    // lane (r15, g) holds C[m = 4 g + jj][n = r15] of each 16 x 16 tile
+#pragma unroll
+    for (int mi = 0; mi < F; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < F; ++ni) {
+            const int n = n0 + wn * 16 * F + ni * 16 + r15;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int m = m0 + wm * 16 * F + mi * 16 + g * 4 + jj;
+                if (m >= a.M) continue;
+                TO* cp = C + (int64_t)m * a.ldc + n;
+                const float v = a.alpha * acc[mi][ni][jj] + (a.accumulate ? static_cast<float>(*cp) : 0.f);
+                *cp = static_cast<TO>(v);
+            }
+        }
 }
 
 // ---- row softmax with additive key mask and dropout: P = softmax(S * scale + mask), Pd = dropout(P) ----------------------
@@ -123,31 +283,62 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* P, int64_t ld
 }
 
 // ---- LayerNorm backward: y = (x - mean) * rstd * gamma + beta over `cols`; x fp32 (the saved pre-LN sum) -----------------
-// dx fp32 (written), dgamma / dbeta fp32 (atomically accumulated: zero them first).  One wave per row.
+// dx fp32 (written), dgamma / dbeta fp32 (atomically accumulated: zero them first).  One wave per row, 32 rows per block: the
+// per-column sums of those rows are kept in registers (cols <= 64 * kLnCols) and added once per block, not once per row.
+constexpr int kLnCols = 16;      // columns per lane: cols <= 1024
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta,
                                                             int64_t rows, int cols, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* xr = x + row * cols;
-    const float* dr = dy + row * cols;
-    float s = 0.f;
-    for (int c = lane; c < cols; c += 64) s += xr[c];
-    const float mean = wave_sum(s) / cols;
-    float q = 0.f;
-    for (int c = lane; c < cols; c += 64) { const float d = xr[c] - mean; q += d * d; }
-    const float rstd = rsqrtf(wave_sum(q) / cols + eps);
-    float a = 0.f, b = 0.f;           // mean(dy*gamma), mean(dy*gamma*xhat)
-    for (int c = lane; c < cols; c += 64) {
-        const float xh = (xr[c] - mean) * rstd, g = dr[c] * gamma[c];
-        a += g; b += g * xh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float pg[kLnCols], pb[kLnCols];
+#pragma unroll
+    for (int i = 0; i < kLnCols; ++i) { pg[i] = 0.f; pb[i] = 0.f; }
+    for (int it = 0; it < 8; ++it) {
+        const int64_t row = (int64_t)blockIdx.x * 32 + it * 4 + wave;
+        if (row >= rows) break;
+        const float* xr = x + row * cols;
+        const float* dr = dy + row * cols;
+        float xv[kLnCols], dv[kLnCols];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < kLnCols; ++i) {
+            const int c = lane + i * 64;
+            xv[i] = c < cols ? xr[c] : 0.f;
+            dv[i] = c < cols ? dr[c] : 0.f;
+            s += xv[i];
+        }
+        const float mean = wave_sum(s) / cols;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < kLnCols; ++i) { const float d = (lane + i * 64 < cols) ? xv[i] - mean : 0.f; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) / cols + eps);
+        float a = 0.f, b = 0.f;           // mean(dy*gamma), mean(dy*gamma*xhat)
+#pragma unroll
+        for (int i = 0; i < kLnCols; ++i) {
+            const int c = lane + i * 64;
+            if (c < cols) {
+                const float xh = (xv[i] - mean) * rstd, gq = dv[i] * gamma[c];
+                a += gq; b += gq * xh;
+            }
+        }
+        a = wave_sum(a) / cols; b = wave_sum(b) / cols;
+#pragma unroll
+        for (int i = 0; i < kLnCols; ++i) {
+            const int c = lane + i * 64;
+            if (c < cols) {
+                const float xh = (xv[i] - mean) * rstd, gq = dv[i] * gamma[c];
+                dx[row * cols + c] = rstd * (gq - a - xh * b);
+                pg[i] += dv[i] * xh;
+                pb[i] += dv[i];
+            }
+        }
     }
-    a = wave_sum(a) / cols; b = wave_sum(b) / cols;
-    for (int c = lane; c < cols; c += 64) {
-        const float xh = (xr[c] - mean) * rstd, g = dr[c] * gamma[c];
-        dx[row * cols + c] = rstd * (g - a - xh * b);
-        atomicAdd(dgamma + c, dr[c] * xh);
-        atomicAdd(dbeta + c, dr[c]);
+    __shared__ float red[2][4][64 * kLnCols];
+#pragma unroll
+    for (int i = 0; i < kLnCols; ++i) { red[0][wave][lane + i * 64] = pg[i]; red[1][wave][lane + i * 64] = pb[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
     }
 }
 
@@ -160,20 +351,26 @@ __device__ __forceinline__ float gelu_grad(float x) {
 // 6: y = p_drop * z (scale by the factor passed in p_drop)
 template <typename TZ, typename TO>
 __global__ __launch_bounds__(256) void eltwise_kernel(const TZ* z, const float* dy, TO* out, int64_t n, int mode, float p_drop, uint64_t seed) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float v = static_cast<float>(z[i]);
-    float r;
-    switch (mode) {
-        case 0: r = gelu_exact(v); break;
-        case 1: r = dy[i] * gelu_grad(v); break;
-        case 2: r = fmaxf(v, 0.f); break;
-        case 3: r = v > 0.f ? dy[i] : 0.f; break;
-        case 4: r = (p_drop <= 0.f || uniform01(seed, (uint64_t)i) >= p_drop) ? v * (p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f) : 0.f; break;
-        case 5: r = v + dy[i]; break;
-        default: r = v * p_drop; break;
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;         // four consecutive elements per thread
+    if (i0 >= n) return;
+    const float keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int64_t i = i0 + e;
+        if (i >= n) break;
+        const float v = static_cast<float>(z[i]);
+        float r;
+        switch (mode) {
+            case 0: r = gelu_exact(v); break;
+            case 1: r = dy[i] * gelu_grad(v); break;
+            case 2: r = fmaxf(v, 0.f); break;
+            case 3: r = v > 0.f ? dy[i] : 0.f; break;
+            case 4: r = (p_drop <= 0.f || uniform01(seed, (uint64_t)i) >= p_drop) ? v * keep : 0.f; break;
+            case 5: r = v + dy[i]; break;
+            default: r = v * p_drop; break;
+        }
+        out[i] = static_cast<TO>(r);
     }
-    out[i] = static_cast<TO>(r);
 }
 
 // column sums: out[c] += sum_r x[r][c] (fp32 x, atomics: zero `out` first)
@@ -230,19 +427,38 @@ extern "C" int cir_transpose16(const void* src, void* dst, int rows, int cols, i
 }
 
 extern "C" int cir_bmm(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b,
-                       int batch, int64_t sA, int64_t sB, int64_t sC, float alpha, int accumulate, int in_dtype, int out_dtype, void* stream) {
+                       int nb1, int nb2, int64_t sA1, int64_t sA2, int64_t sB1, int64_t sB2, int64_t sC1, int64_t sC2, float alpha, int accumulate,
+                       int in_dtype, int out_dtype, void* stream) {
     CIR_CHECK_PTR(A); CIR_CHECK_PTR(B); CIR_CHECK_PTR(C);
-    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return CIR_EINVAL;
-    if (batch > 65535) return CIR_ESHAPE;
-    dim3 grid((N + 15) / 16, (M + 15) / 16, batch), block(256);
+    if (M <= 0 || N <= 0 || K <= 0 || nb1 <= 0 || nb2 <= 0) return CIR_EINVAL;
+    if ((int64_t)nb1 * nb2 > 65535) return CIR_ESHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#define CIR_BMM(TI, TO) hipLaunchKernelGGL((bmm_kernel<TI, TO>), grid, block, 0, s, reinterpret_cast<const TI*>(A), reinterpret_cast<const TI*>(B), \
-                                           reinterpret_cast<TO*>(C), M, N, K, lda, ldb, ldc, trans_a, trans_b, sA, sB, sC, alpha, accumulate)
-    if (in_dtype == CIR_BF16) { if (out_dtype == CIR_F32) CIR_BMM(__bf16, float); else if (out_dtype == CIR_BF16) CIR_BMM(__bf16, __bf16); else return CIR_EDTYPE; }
-    else if (in_dtype == CIR_F16) { if (out_dtype == CIR_F32) CIR_BMM(_Float16, float); else if (out_dtype == CIR_F16) CIR_BMM(_Float16, _Float16); else return CIR_EDTYPE; }
-    else if (in_dtype == CIR_F32) { if (out_dtype == CIR_F32) CIR_BMM(float, float); else return CIR_EDTYPE; }
-    else return CIR_EDTYPE;
-#undef CIR_BMM
+    if (in_dtype == CIR_F32) {                               // fp32 operands: the plain kernel
+        if (out_dtype != CIR_F32) return CIR_EDTYPE;
+        dim3 grid((N + 15) / 16, (M + 15) / 16, nb1 * nb2), block(256);
+        hipLaunchKernelGGL((bmm_kernel<float, float>), grid, block, 0, s, reinterpret_cast<const float*>(A), reinterpret_cast<const float*>(B),
+                           reinterpret_cast<float*>(C), M, N, K, lda, ldb, ldc, trans_a, trans_b, nb2, sA1, sA2, sB1, sB2, sC1, sC2, alpha, accumulate);
+        CIR_LAUNCH_RESULT();
+    }
+    if (in_dtype != CIR_BF16 && in_dtype != CIR_F16) return CIR_EDTYPE;
+    if (out_dtype != CIR_F32 && out_dtype != in_dtype) return CIR_EDTYPE;
+    auto vec_ok = [](const void* p, int64_t ld, int64_t s1, int64_t s2) {
+        return (reinterpret_cast<uintptr_t>(p) % 16 == 0 && ld % 8 == 0 && s1 % 8 == 0 && s2 % 8 == 0) ? 1 : 0;
+    };
+    BmmArgs a{A, B, C, M, N, K, lda, ldb, ldc, trans_a ? 1 : 0, trans_b ? 1 : 0, nb2, sA1, sA2, sB1, sB2, sC1, sC2, alpha, accumulate,
+              vec_ok(A, lda, sA1, sA2), vec_ok(B, ldb, sB1, sB2)};
+    dim3 block(256);
+    const bool big = M > 64 && N > 64;                       // 128 x 128 tiles unless one extent fits a 64 tile anyway
+    const int bt = big ? 128 : 64;
+    dim3 grid((N + bt - 1) / bt, (M + bt - 1) / bt, nb1 * nb2);
+#define CIR_BMM_F(T, TO) do { if (big) hipLaunchKernelGGL((bmm_mfma_kernel<T, TO, 4>), grid, block, 0, s, a); \
+                              else hipLaunchKernelGGL((bmm_mfma_kernel<T, TO, 2>), grid, block, 0, s, a); } while (0)
+    if (in_dtype == CIR_BF16) {
+        if (out_dtype == CIR_F32) CIR_BMM_F(__bf16, float); else CIR_BMM_F(__bf16, __bf16);
+    } else {
+        if (out_dtype == CIR_F32) CIR_BMM_F(_Float16, float); else CIR_BMM_F(_Float16, _Float16);
+    }
+#undef CIR_BMM_F
     CIR_LAUNCH_RESULT();
 }
 
@@ -274,7 +490,8 @@ extern "C" int cir_layernorm_bwd(const float* x, const float* gamma, const float
                                  float eps, void* stream) {
     CIR_CHECK_PTR(x); CIR_CHECK_PTR(gamma); CIR_CHECK_PTR(dy); CIR_CHECK_PTR(dx); CIR_CHECK_PTR(dgamma); CIR_CHECK_PTR(dbeta);
     if (rows <= 0 || cols <= 0) return CIR_EINVAL;
-    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (cols > 64 * kLnCols) return CIR_ESHAPE;
+    dim3 grid((unsigned)((rows + 31) / 32)), block(256);
     hipLaunchKernelGGL(layernorm_bwd_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), x, gamma, dy, dx, dgamma, dbeta, rows, cols, eps);
     CIR_LAUNCH_RESULT();
 }
@@ -284,7 +501,7 @@ extern "C" int cir_eltwise(const void* z, int z_dtype, const float* dy, void* ou
     CIR_CHECK_PTR(z); CIR_CHECK_PTR(out);
     if (n <= 0 || mode < 0 || mode > 6 || (mode != 6 && (p_drop < 0.f || p_drop >= 1.f))) return CIR_EINVAL;
     if ((mode == 1 || mode == 3 || mode == 5) && dy == nullptr) return CIR_EINVAL;
-    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    dim3 grid((unsigned)((n + 1023) / 1024)), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define CIR_ELT(TZ, TO) hipLaunchKernelGGL((eltwise_kernel<TZ, TO>), grid, block, 0, s, reinterpret_cast<const TZ*>(z), dy, reinterpret_cast<TO*>(out), n, mode, p_drop, seed)
 #define CIR_ELT_OUT(TZ) do { if (out_dtype == CIR_F32) CIR_ELT(TZ, float); else if (out_dtype == CIR_BF16) CIR_ELT(TZ, __bf16); else if (out_dtype == CIR_F16) CIR_ELT(TZ, _Float16); else return CIR_EDTYPE; } while (0)
@@ -300,7 +517,7 @@ extern "C" int cir_eltwise(const void* z, int z_dtype, const float* dy, void* ou
 extern "C" int cir_colsum(const float* x, int64_t ld, float* out, int64_t rows, int cols, void* stream) {
     CIR_CHECK_PTR(x); CIR_CHECK_PTR(out);
     if (rows <= 0 || cols <= 0) return CIR_EINVAL;
-    const int64_t rpb = 256;
+    const int64_t rpb = 32;
     dim3 grid((cols + 255) / 256, (unsigned)((rows + rpb - 1) / rpb)), block(256);
     hipLaunchKernelGGL(colsum_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), x, ld, out, rows, cols, rpb);
     CIR_LAUNCH_RESULT();

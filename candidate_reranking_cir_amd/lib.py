@@ -42,8 +42,8 @@ SIGNATURES = {
     "cir_l2_normalize": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     # training-mode operators
     "cir_transpose16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int, c_int64, c_int64, c_int, c_void_p]),
-    "cir_bmm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int64, c_int64, c_int64,
-                        c_float, c_int, c_int, c_int, c_void_p]),
+    "cir_bmm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int,
+                        c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_int, c_int, c_int, c_void_p]),
     "cir_softmax_dropout": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_float, c_float,
                                     c_uint64, c_int, c_void_p]),
     "cir_softmax_dropout_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_float, c_float, c_uint64, c_int,

@@ -9,9 +9,12 @@ blip_stage2.py:65-99: row i's caption / z_t expanded to B rows against all B tar
 reverse pass - no autograd graph over the kernels: each step of nlvr_encoder.BertLayer.forward (:414-476), BertSelfAttention
 (:140-222), BertSelfOutput (:248-264, incl. the averaging / merge_layer variants), BertIntermediate / BertOutput (:383-409),
 BertEmbeddings (:49-91) and cls_head (blip_stage2.py:50-54) has its hand-written adjoint below.  Arithmetic: dense layers on the
-MFMA GEMM (`ops.gemm`; dgrad over a transposed weight copy, wgrad over transposed activation copies) or, where an extent misses
-the GEMM's tile constraints, on `train_ops.bmm`; attention un-fused per head (scores, softmax + dropout, context) so that its
-adjoint is four small matmuls and one row kernel; LayerNorm / GELU / dropout / embedding adjoints in `train_ops`.
+MFMA GEMM (`ops.gemm`; dgrad over a transposed weight copy) or, where an extent misses its tile constraints, on `train_ops.bmm`
+(MFMA, any extents); weight gradients on `train_ops.bmm` reading dy and x as stored, split over row chunks; attention un-fused
+(scores, softmax + dropout, context: batched `bmm` over (group, head)) so that its adjoint is four batched matmuls and one row
+kernel; LayerNorm / GELU / dropout / embedding adjoints in `train_ops`.  Triplets are ordered candidate-major, so the
+cross-attention keys / values of a target image are projected once per step and their gradients sum over the B queries inside
+the dK / dV products.
 Precision: 16-bit MFMA operands (activations, weights, and the gradients fed to the GEMMs), fp32 accumulation, fp32 residual
 stream, fp32 LayerNorm inputs, fp32 weight gradients - the forward plan of DESIGN.md section 2 with an fp32 stream.
 Dropout is counter-based (seed per site); with p = 0 the pass is deterministic and is what the reference-gradient fixture pins.
@@ -33,6 +36,17 @@ from . import ops, train_ops as T
 
 def _cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return T.eltwise(x.contiguous(), T.MODE_SCALE, out_dtype=dtype, p_drop=1.0)
+
+
+def _row_split(rows: int, out_elems: int) -> int:
+    """Number of row chunks of a weight-gradient product: the largest divisor of `rows` up to 32 that leaves >= 128 rows per chunk
+    and keeps the partial sums under 64 MB."""
+    cap = min(32, max(1, (16 << 20) // max(1, out_elems)))
+    best = 1
+    for nb in range(2, cap + 1):
+        if rows % nb == 0 and rows // nb >= 128:
+            best = nb
+    return best
 
 
 def _gemm_ok(m: int, n: int, k: int) -> bool:
@@ -67,11 +81,14 @@ class _Lin:
         dy16 = _cast(dy, x16.dtype)
         if self.db is not None:
             T.colsum(dy, self.db)
-        if _gemm_ok(n, k, m) and m % 8 == 0:                                        # dW (N, K) = dy^T (N, M) . (x^T (K, M))^T
-            dw = ops.gemm(T.transpose16(dy16), T.transpose16(x16), None, out_dtype=torch.float32)
-            self.dw = T.eltwise(self.dw, T.MODE_ADD, dw)
-        else:
+        # dW (N, K) = dy^T x on cir_bmm (operands read as stored: trans_a), split over row chunks into partial sums so that the
+        # 144-tile products of a 768 x 768 weight fill the chip; the partials are summed into dW by the column-sum kernel
+        nb = _row_split(m, n * k)
+        if nb == 1:
             T.bmm(dy16.unsqueeze(0), x16.unsqueeze(0), True, False, out=self.dw.unsqueeze(0), accumulate=True)
+        else:
+            part = T.bmm(dy16.view(nb, m // nb, n), x16.view(nb, m // nb, k), True, False, out_dtype=torch.float32)
+            T.colsum(part.view(nb, n * k), self.dw.view(-1))
         if not need_dx:
             return None
         if _gemm_ok(m, k, n):                                                       # dx (M, K) = dy (M, N) . (W^T (K, N))^T
@@ -141,58 +158,59 @@ class NlvrTrainer:
         return x if self.p_hidden <= 0 else T.eltwise(x, T.MODE_DROPOUT, p_drop=self.p_hidden, seed=site)
 
     # ------------------------------------------------------------------------------------------------ attention
-    def _attn_fwd(self, q16, k16, v16, t_n, lq, lk, mask, site):
-        """q16 (T*Lq, D), k16 / v16 (T*Lk, D) views (row stride = their parent's); mask (T, Lk) additive fp32 or None."""
-        h_n, d = self.geo.num_attention_heads, self.geo.hidden_size
-        s = torch.empty((t_n, h_n, lq, lk), dtype=torch.float32, device=q16.device)
-        q3, k3, v3 = q16.view(t_n, lq, -1), k16.view(t_n, lk, -1), v16.view(t_n, lk, -1)
-        for h in range(h_n):
-            sl = slice(h * self._hd, (h + 1) * self._hd)
-            T.bmm(q3[:, :, sl], k3[:, :, sl], False, True, out=s[:, h])
-        p, pd = T.softmax_dropout(s.view(-1, lk), mask, h_n * lq, self._scale, self.p_attn, site, q16.dtype)
-        ctx = torch.empty((t_n, lq, d), dtype=q16.dtype, device=q16.device)
-        pd4 = pd.view(t_n, h_n, lq, lk)
-        for h in range(h_n):
-            sl = slice(h * self._hd, (h + 1) * self._hd)
-            T.bmm(pd4[:, h], v3[:, :, sl], False, False, out=ctx[:, :, sl])
-        return ctx.view(t_n * lq, d), (p, pd, site)
+    def _heads(self, x: torch.Tensor, nb1: int, rows: int) -> torch.Tensor:
+        """(nb1 * rows, D) projection -> (nb1, H, rows, head_dim) view of its head slices (no copy)."""
+        return x.view(nb1, rows, self.geo.num_attention_heads, self._hd).permute(0, 2, 1, 3)
 
-    def _attn_bwd(self, dctx, q16, k16, v16, t_n, lq, lk, saved):
-        """dctx fp32 (T*Lq, D) -> (dq (T*Lq, D), dk (T*Lk, D), dv (T*Lk, D)) fp32."""
+    def _attn_fwd(self, q16, k16, v16, nb1, mq, mk, mask, site):
+        """nb1 groups of mq query rows and mk key rows each: q16 (nb1*mq, D), k16 / v16 (nb1*mk, D); mask (groups, mk) additive fp32,
+        one row per mq * H score rows, or None.  Self-attention: a group is a triplet; cross-attention: a group is a CANDIDATE with
+        the B queries scored against it stacked in mq = B * L rows - its keys / values exist once."""
+        h_n, d = self.geo.num_attention_heads, self.geo.hidden_size
+        ld = (mk + 7) // 8 * 8                                                       # padded score rows: 16-byte loads in cir_bmm
+        s = torch.empty((nb1, h_n, mq, ld), dtype=torch.float32, device=q16.device)
+        T.bmm(self._heads(q16, nb1, mq), self._heads(k16, nb1, mk), False, True, out=s[..., :mk])
+        p, pd = T.softmax_dropout(s.view(-1, ld), mask, h_n * mq, self._scale, self.p_attn, site, q16.dtype, cols=mk)
+        ctx = torch.empty((nb1 * mq, d), dtype=q16.dtype, device=q16.device)
+        T.bmm(pd.view(nb1, h_n, mq, ld)[..., :mk], self._heads(v16, nb1, mk), False, False, out=self._heads(ctx, nb1, mq))
+        return ctx, (p, pd, site)
+
+    def _attn_bwd(self, dctx, q16, k16, v16, nb1, mq, mk, saved):
+        """dctx fp32 (nb1*mq, D) -> (dq (nb1*mq, D), dk (nb1*mk, D), dv (nb1*mk, D)) fp32."""
         p, pd, site = saved
         h_n, d = self.geo.num_attention_heads, self.geo.hidden_size
-        dc16 = _cast(dctx, q16.dtype).view(t_n, lq, d)
-        q3, k3, v3 = q16.view(t_n, lq, -1), k16.view(t_n, lk, -1), v16.view(t_n, lk, -1)
-        pd4 = pd.view(t_n, h_n, lq, lk)
-        dpd = torch.empty((t_n, h_n, lq, lk), dtype=torch.float32, device=dctx.device)
-        dq = torch.empty((t_n, lq, d), dtype=torch.float32, device=dctx.device)
-        dk = torch.empty((t_n, lk, d), dtype=torch.float32, device=dctx.device)
-        dv = torch.empty((t_n, lk, d), dtype=torch.float32, device=dctx.device)
-        for h in range(h_n):
-            sl = slice(h * self._hd, (h + 1) * self._hd)
-            T.bmm(dc16[:, :, sl], v3[:, :, sl], False, True, out=dpd[:, h])                       # dPd = dctx . V^T
-            T.bmm(pd4[:, h], dc16[:, :, sl], True, False, out=dv[:, :, sl])                        # dV  = Pd^T . dctx
-        ds = T.softmax_dropout_bwd(p, dpd.view(-1, lk), self._scale, self.p_attn, site).view(t_n, h_n, lq, lk)
-        for h in range(h_n):
-            sl = slice(h * self._hd, (h + 1) * self._hd)
-            T.bmm(ds[:, h], k3[:, :, sl], False, False, out=dq[:, :, sl])                          # dQ = dS . K
-            T.bmm(ds[:, h], q3[:, :, sl], True, False, out=dk[:, :, sl])                           # dK = dS^T . Q
-        return dq.view(-1, d), dk.view(-1, d), dv.view(-1, d)
+        ld = p.shape[1]
+        dev = dctx.device
+        dc = self._heads(_cast(dctx, q16.dtype), nb1, mq)
+        q4, k4, v4 = self._heads(q16, nb1, mq), self._heads(k16, nb1, mk), self._heads(v16, nb1, mk)
+        pd4 = pd.view(nb1, h_n, mq, ld)[..., :mk]
+        dpd = torch.empty((nb1, h_n, mq, ld), dtype=torch.float32, device=dev)
+        dq = torch.empty((nb1 * mq, d), dtype=torch.float32, device=dev)
+        dk = torch.empty((nb1 * mk, d), dtype=torch.float32, device=dev)
+        dv = torch.empty((nb1 * mk, d), dtype=torch.float32, device=dev)
+        T.bmm(dc, v4, False, True, out=dpd[..., :mk])                                # dPd = dctx . V^T
+        T.bmm(pd4, dc, True, False, out=self._heads(dv, nb1, mk))                    # dV  = Pd^T . dctx
+        ds = T.softmax_dropout_bwd(p, dpd.view(-1, ld), self._scale, self.p_attn, site, cols=mk).view(nb1, h_n, mq, ld)[..., :mk]
+        T.bmm(ds, k4, False, False, out=self._heads(dq, nb1, mq))                    # dQ = dS . K
+        T.bmm(ds, q4, True, False, out=self._heads(dk, nb1, mk))                     # dK = dS^T . Q
+        return dq, dk, dv
 
     # ------------------------------------------------------------------------------------------------ forward
     @torch.no_grad()
     def forward(self, z_t: torch.Tensor, feats: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
         """z_t (B, L, D) fp32, feats (B, N, Dv), ids / mask (B, L) with [ENC] set -> logits (B, B) fp32; keeps what backward needs."""
         self._pack()
-        self.model._engines = None                                                  # a training step is about to change the parameters: the
-        self.step_no += 1                                                           # inference engines repack on their next use
+        self.model._text_stale = True                                               # a training step is about to change text_encoder / cls_head:
+        self.step_no += 1                                                           # the inference engine of that part repacks on its next use
         g, dt, dev = self.geo, self.dtype, z_t.device
         b_n, l = input_ids.shape
         n, d = feats.shape[1], g.hidden_size
         t_n = b_n * b_n
         r = t_n * l
-        qi = torch.arange(b_n, device=dev).repeat_interleave(b_n)                   # row i's text / z_t for items i*B .. i*B+B-1
-        ci = torch.arange(b_n, device=dev).repeat(b_n)                              # against candidate j
+        # triplet t = j * B + i scores query i (caption, z_t) against target j - candidate-major, so that the B queries of one
+        # target are consecutive rows and its cross-attention keys / values are projected ONCE (the reference recomputes them
+        # for every query, blip_stage2.py:80-92; same values); the (B_j, B_i) result is transposed on the way out
+        qi = torch.arange(b_n, device=dev).repeat(b_n)
         ids_t = input_ids.to(dev)[qi].contiguous()                                  # (T, L)
         self.sv = sv = {"ids": ids_t, "t_n": t_n, "l": l, "n": n, "b_n": b_n}
         # embeddings (BertEmbeddings: LayerNorm(word + pos), dropout) -> branch 1; z_t -> branch 0 (nlvr_encoder.py:880-892)
@@ -204,7 +222,7 @@ class NlvrTrainer:
         e32 = self._drop(e32, self._site(9000))
         h32 = [ops.gather_rows(z_t.to(dev).float().contiguous().view(b_n, l * d), qi, torch.float32).view(r, d), e32]
         h16 = [_cast(x, dt) for x in h32]
-        cand16 = ops.gather_rows(feats.to(dev).contiguous().view(b_n, -1), ci, dt).view(t_n * n, -1)      # (T*N, Dv)
+        cand16 = _cast(feats.to(dev).float().contiguous(), dt).view(b_n * n, -1)                          # (B*N, Dv): each target once
         sv["cand16"] = cand16
         smask = ((1.0 - attention_mask.to(dev).float()) * -10000.0)[qi].contiguous()                      # (T, L), nlvr_encoder.py:773-774
         sv["layers"] = []
@@ -220,7 +238,7 @@ class NlvrTrainer:
                 a, a16 = ly[f"ln1{b}"].fwd(pre1, dt)
                 cq = ly[f"cq{b}"].fwd(a16, dt)
                 ck, cv = ly[f"ck{b}"].fwd(cand16, dt), ly[f"cv{b}"].fwd(cand16, dt)
-                c, ca = self._attn_fwd(cq, ck, cv, t_n, l, n, None, self._site(i, b, 3))
+                c, ca = self._attn_fwd(cq, ck, cv, b_n, b_n * l, n, None, self._site(i, b, 3))
                 dd.append(ly[f"d{b}"].fwd(c, torch.float32))
                 a32.append(a)
                 for key, val in (("q", q), ("k", k), ("v", v), ("sa", sa), ("ctx", ctx), ("pre1", pre1), ("a16", a16), ("cq", cq), ("ck", ck),
@@ -254,7 +272,12 @@ class NlvrTrainer:
         y16 = T.eltwise(z1, T.MODE_RELU, out_dtype=dt)
         logits2 = self.c2.fwd(y16, torch.float32)                                   # (T, 2)
         sv.update(hid16=hid16, z1=z1, y16=y16, cls_rows=cls_rows)
-        return logits2[:, 0].contiguous().view(b_n, b_n)
+        return logits2[:, 0].contiguous().view(b_n, b_n).t().contiguous()           # (B_j, B_i) -> (B_i, B_j)
+
+    def head_mask(self) -> torch.Tensor:
+        """(B*B, hidden) bool: which cls_head.0 units were active in the last forward, rows in the reference's order (i * B + j)."""
+        b = self.sv["b_n"]
+        return (self.sv["z1"] > 0).view(b, b, -1).transpose(0, 1).reshape(b * b, -1)
 
     # ------------------------------------------------------------------------------------------------ backward
     @torch.no_grad()
@@ -271,7 +294,7 @@ class NlvrTrainer:
         amax = float(dlogits.abs().max())
         self.grad_scale = 2.0 ** round(math.log2(512.0 / amax)) if amax > 0 and math.isfinite(amax) else 1.0
         dl2 = torch.zeros((t_n, 2), dtype=torch.float32, device=dev)
-        dl2[:, 0] = T.eltwise(dlogits.reshape(-1).float().contiguous(), T.MODE_SCALE, p_drop=self.grad_scale)
+        dl2[:, 0] = T.eltwise(dlogits.float().t().contiguous().view(-1), T.MODE_SCALE, p_drop=self.grad_scale)
         dy1 = self.c2.bwd(sv["y16"], dl2)
         dz1 = T.eltwise(sv["z1"], T.MODE_RELU_BWD, dy1)
         dhid = self.c0.bwd(sv["hid16"], dz1)                                        # (T, 2D)
@@ -302,7 +325,7 @@ class NlvrTrainer:
             dh_in = []
             for b in (0, 1):
                 dc = ly[f"d{b}"].bwd(s["c"][b], dd[b])
-                dcq, dck, dcv = self._attn_bwd(dc, s["cq"][b], s["ck"][b], s["cv"][b], t_n, l, n, s["ca"][b])
+                dcq, dck, dcv = self._attn_bwd(dc, s["cq"][b], s["ck"][b], s["cv"][b], sv["b_n"], sv["b_n"] * l, n, s["ca"][b])
                 ly[f"ck{b}"].bwd(sv["cand16"], dck, need_dx=False)                  # image tokens are inputs: no gradient beyond the weights
                 ly[f"cv{b}"].bwd(sv["cand16"], dcv, need_dx=False)
                 da = add(ly[f"cq{b}"].bwd(s["a16"][b], dcq), dpre2[b])

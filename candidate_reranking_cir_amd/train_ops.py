@@ -29,49 +29,60 @@ def transpose16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Te
 
 def bmm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False, out: Optional[torch.Tensor] = None,
         out_dtype: Optional[torch.dtype] = None, alpha: float = 1.0, accumulate: bool = False) -> torch.Tensor:
-    """out[i] = alpha * op(a[i]) @ op(b[i]) (+ out[i]); a, b (B, ., .) views with unit last stride and any row / batch strides."""
+    """out[z] = alpha * op(a[z]) @ op(b[z]) (+ out[z]); a, b, out are (B, ., .) or (B1, B2, ., .) views with unit last stride and
+    any row / batch strides (0 = broadcast over that batch level).  16-bit operands run on the MFMA kernel."""
     _need_cuda(a, b, out)
-    assert a.dim() == 3 and b.dim() == 3 and a.shape[0] == b.shape[0] and a.stride(2) == 1 and b.stride(2) == 1 and a.dtype == b.dtype
-    nb = a.shape[0]
-    m, k = (a.shape[2], a.shape[1]) if trans_a else (a.shape[1], a.shape[2])
-    k2, n = (b.shape[2], b.shape[1]) if trans_b else (b.shape[1], b.shape[2])
+    assert a.dim() == b.dim() and a.dim() in (3, 4) and a.shape[:-2] == b.shape[:-2] and a.stride(-1) == 1 and b.stride(-1) == 1 and a.dtype == b.dtype
+    was3 = a.dim() == 3
+    if was3:
+        a, b = a.unsqueeze(1), b.unsqueeze(1)
+        out4 = None if out is None else out.unsqueeze(1)
+    else:
+        out4 = out
+    nb1, nb2 = a.shape[0], a.shape[1]
+    m, k = (a.shape[3], a.shape[2]) if trans_a else (a.shape[2], a.shape[3])
+    k2, n = (b.shape[3], b.shape[2]) if trans_b else (b.shape[2], b.shape[3])
     assert k == k2, (a.shape, b.shape, trans_a, trans_b)
     out_dtype = out_dtype or (out.dtype if out is not None else a.dtype)
-    if out is None:
-        out = torch.empty((nb, m, n), dtype=out_dtype, device=a.device)
-    assert out.shape == (nb, m, n) and out.stride(2) == 1 and out.dtype == out_dtype
+    if out4 is None:
+        out4 = torch.empty((nb1, nb2, m, n), dtype=out_dtype, device=a.device)
+    assert out4.shape == (nb1, nb2, m, n) and out4.stride(3) == 1 and out4.dtype == out_dtype
     lib = _lib.load()
-    for b0 in range(0, nb, 65535):                                   # grid.z limit
-        b1 = min(nb, b0 + 65535)
-        _lib.check(lib.cir_bmm(a[b0:b1].data_ptr(), b[b0:b1].data_ptr(), out[b0:b1].data_ptr(), m, n, k, a.stride(1), b.stride(1), out.stride(1),
-                               int(trans_a), int(trans_b), b1 - b0, a.stride(0), b.stride(0), out.stride(0), float(alpha), int(accumulate),
-                               _DT[a.dtype], _DT[out_dtype], _stream()), "cir_bmm")
-    return out
+    step = max(1, 65535 // nb2)                                       # grid.z limit
+    for z0 in range(0, nb1, step):
+        z1 = min(nb1, z0 + step)
+        _lib.check(lib.cir_bmm(a[z0:z1].data_ptr(), b[z0:z1].data_ptr(), out4[z0:z1].data_ptr(), m, n, k, a.stride(2), b.stride(2), out4.stride(2),
+                               int(trans_a), int(trans_b), z1 - z0, nb2, a.stride(0), a.stride(1), b.stride(0), b.stride(1), out4.stride(0),
+                               out4.stride(1), float(alpha), int(accumulate), _DT[a.dtype], _DT[out_dtype], _stream()), "cir_bmm")
+    return out4.squeeze(1) if was3 else out4
 
 
-def softmax_dropout(s: torch.Tensor, mask: Optional[torch.Tensor], rows_per_mask: int, scale: float, p_drop: float, seed: int, dtype: torch.dtype):
-    """s fp32 (rows, cols) contiguous; mask fp32 (groups, cols) additive, one row per `rows_per_mask` consecutive rows of s, or None
-    -> (P, dropout(P)) in `dtype`."""
+def softmax_dropout(s: torch.Tensor, mask: Optional[torch.Tensor], rows_per_mask: int, scale: float, p_drop: float, seed: int, dtype: torch.dtype,
+                    cols: Optional[int] = None):
+    """s fp32 (rows, ld) contiguous, the first `cols` (default ld) entries of a row are scores; mask fp32 (groups, cols) additive, one
+    row per `rows_per_mask` consecutive rows of s, or None -> (P, dropout(P)) in `dtype`, same (rows, ld) layout."""
     _need_cuda(s, mask)
-    rows, cols = s.shape
-    assert s.dtype == torch.float32 and s.is_contiguous()
-    p = torch.empty((rows, cols), dtype=dtype, device=s.device)
+    rows, ld = s.shape
+    cols = ld if cols is None else int(cols)
+    assert s.dtype == torch.float32 and s.is_contiguous() and 0 < cols <= ld
+    p = torch.empty((rows, ld), dtype=dtype, device=s.device)
     pd = torch.empty_like(p)
     if mask is not None:
         assert mask.dtype == torch.float32 and mask.stride(-1) == 1 and mask.shape[-1] == cols
-    _lib.check(_lib.load().cir_softmax_dropout(s.data_ptr(), cols, _ptr(mask), int(rows_per_mask), mask.stride(0) if mask is not None else 0,
-                                               p.data_ptr(), pd.data_ptr(), cols, rows, cols, float(scale), float(p_drop), int(seed) & (2 ** 63 - 1),
+    _lib.check(_lib.load().cir_softmax_dropout(s.data_ptr(), ld, _ptr(mask), int(rows_per_mask), mask.stride(0) if mask is not None else 0,
+                                               p.data_ptr(), pd.data_ptr(), ld, rows, cols, float(scale), float(p_drop), int(seed) & (2 ** 63 - 1),
                                                _DT[dtype], _stream()), "cir_softmax_dropout")
     return p, pd
 
 
-def softmax_dropout_bwd(p: torch.Tensor, dpd: torch.Tensor, scale: float, p_drop: float, seed: int) -> torch.Tensor:
-    """P 16-bit (rows, cols), dPd fp32 (rows, cols) -> dS 16-bit (rows, cols)."""
+def softmax_dropout_bwd(p: torch.Tensor, dpd: torch.Tensor, scale: float, p_drop: float, seed: int, cols: Optional[int] = None) -> torch.Tensor:
+    """P 16-bit (rows, ld), dPd fp32 (rows, ld), scores in the first `cols` entries -> dS 16-bit (rows, ld)."""
     _need_cuda(p, dpd)
-    rows, cols = p.shape
-    assert p.is_contiguous() and dpd.is_contiguous() and dpd.dtype == torch.float32 and dpd.shape == p.shape
+    rows, ld = p.shape
+    cols = ld if cols is None else int(cols)
+    assert p.is_contiguous() and dpd.is_contiguous() and dpd.dtype == torch.float32 and dpd.shape == p.shape and 0 < cols <= ld
     ds = torch.empty_like(p)
-    _lib.check(_lib.load().cir_softmax_dropout_bwd(p.data_ptr(), cols, dpd.data_ptr(), cols, ds.data_ptr(), cols, rows, cols, float(scale), float(p_drop),
+    _lib.check(_lib.load().cir_softmax_dropout_bwd(p.data_ptr(), ld, dpd.data_ptr(), ld, ds.data_ptr(), ld, rows, cols, float(scale), float(p_drop),
                                                    int(seed) & (2 ** 63 - 1), _DT[p.dtype], _stream()), "cir_softmax_dropout_bwd")
     return ds
 

@@ -195,18 +195,23 @@ int cir_l2_normalize(const float* x, float* y, int64_t rows, int cols, void* str
 /* ------------------------------------------------------------------------------------------------------------------------
  * Training-mode operators: what BLIP_NLVR.img_txt_fusion in train() mode and its backward need
  * besides the operators above (blip_stage2.py:65-99 driven by stage2_train.py:202-216; dropout nlvr_encoder.py:86-90, 207,
- * 250-264, 397).  The dense layers' dgrad / wgrad run on cir_gemm_bias_act over transposed copies (cir_transpose16).
+ * 250-264, 397).  The dense layers' forward and dgrad run on cir_gemm_bias_act (dgrad over a transposed weight copy, cir_transpose16),
+ * the weight gradients on cir_bmm.
  * Dropout is counter-based: element i of a launch is kept iff hash(seed, i) >= p, scaled by 1 / (1 - p); the backward
  * operators regenerate the same mask from the same (seed, p) - no mask tensor exists.  None of these is on the inference path.
  */
 /* dst[b][c][r] = src[b][r][c], 16-bit elements (dtype CIR_BF16 / CIR_F16 names the payload only). */
 int cir_transpose16(const void* src, void* dst, int rows, int cols, int64_t ld_src, int64_t ld_dst, int batch, int64_t s_src, int64_t s_dst,
                     int dtype, void* stream);
-/* C[b] = alpha * op(A[b]) * op(B[b]) (+ C[b] if accumulate): op(A) (M,K) from A (M,K) [trans_a 0] or (K,M) [1]; op(B) (K,N) from B
- * (K,N) [trans_b 0] or (N,K) [1].  Any extents; fp32 accumulate.  in_dtype CIR_BF16 / CIR_F16 / CIR_F32; out_dtype = in_dtype or
- * CIR_F32.  The attention pieces of the backward pass (Q K^T, P V, dP, dQ, dK, dV: 32 x 32 / 32 x 197 tiles per head). */
-int cir_bmm(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b, int batch,
-            int64_t sA, int64_t sB, int64_t sC, float alpha, int accumulate, int in_dtype, int out_dtype, void* stream);
+/* C[z] = alpha * op(A[z]) * op(B[z]) (+ C[z] if accumulate): op(A) (M,K) from A stored (M,K) [trans_a 0] or (K,M) [1]; op(B) (K,N)
+ * from B stored (K,N) [trans_b 0] or (N,K) [1].  Any extents, fp32 accumulate.  Two batch levels: z = z1 * nb2 + z2 with a stride per
+ * level and operand (element units; 0 broadcasts), nb1 * nb2 <= 65535.  in_dtype CIR_BF16 / CIR_F16: MFMA kernel (64 x 64 tiles,
+ * edges predicated, 16-byte loads when base / ld / strides allow, 2-byte loads otherwise), out_dtype = in_dtype or CIR_F32;
+ * in_dtype CIR_F32: plain kernel, fp32 out.  Used for the un-fused attention of the training pass (Q K^T, P V and their four
+ * adjoints per (candidate or triplet, head)) and, with trans_a = 1 and a batch over row chunks, for the weight gradients. */
+int cir_bmm(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b,
+            int nb1, int nb2, int64_t sA1, int64_t sA2, int64_t sB1, int64_t sB2, int64_t sC1, int64_t sC2, float alpha, int accumulate,
+            int in_dtype, int out_dtype, void* stream);
 /* P = softmax(S * scale + mask) per row (S fp32 (rows, cols); mask fp32 (cols) shared by each group of rows_per_mask rows, or
  * NULL), Pd = dropout(P, p_drop, seed); both 16-bit (dtype).  nlvr_encoder.py:183-207. */
 int cir_softmax_dropout(const float* S, int64_t ld_s, const float* mask, int64_t rows_per_mask, int64_t ld_mask, void* P, void* Pd, int64_t ld_p,

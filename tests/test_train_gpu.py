@@ -106,7 +106,7 @@ def test_training_step_matches_reference(cuda, dtype):
         w[k].requires_grad_(True)
     torch.set_num_threads(8)
     o_logits = O.img_txt_fusion_train(w, torch.from_numpy(z["z_t"]), torch.from_numpy(z["feats"]), torch.from_numpy(z["input_ids"]),
-                                      torch.from_numpy(z["attention_mask"]), relu_mask=(m2._trainer.sv["z1"] > 0).cpu())
+                                      torch.from_numpy(z["attention_mask"]), relu_mask=m2._trainer.head_mask().cpu())
     F.cross_entropy(o_logits, torch.arange(4)).backward()
     w_e, tot, cnt = (0.0, ""), 0.0, 0
     for n in names:
@@ -143,7 +143,7 @@ def test_tiny_gradients_match_oracle_autograd(cuda, dtype):
         w[k].requires_grad_(True)
     tr = NlvrTrainer(m2, 0.0, 0.0)
     logits = tr.forward(z_t.cuda(), feats.cuda(), ids.cuda(), mask.cuda())
-    ref_logits = O.img_txt_fusion_train(w, z_t, feats, ids, mask, relu_mask=(tr.sv["z1"] > 0).cpu())
+    ref_logits = O.img_txt_fusion_train(w, z_t, feats, ids, mask, relu_mask=tr.head_mask().cpu())
     dl = torch.randn((b, b), generator=rng)
     (ref_logits * dl).sum().backward()
     grads = tr.backward(dl.cuda())

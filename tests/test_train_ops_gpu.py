@@ -46,6 +46,37 @@ def test_bmm(T, ta, tb, dtype):
     torch.testing.assert_close(s, q.float() @ kk.float().transpose(1, 2), atol=1e-3, rtol=1e-4)
 
 
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("dtype", [BF, HF])
+@pytest.mark.parametrize("m,n,k", [(1, 1, 1), (70, 33, 45), (512, 577, 64), (577, 64, 512), (64, 64, 100)])
+def test_bmm_mfma_two_level_batches(T, ta, tb, dtype, m, n, k):
+    """The MFMA kernel at ragged extents (odd leading dimensions -> 2-byte loads; aligned ones -> 16-byte loads with masked
+    edges), both storage orders of both operands, two batch levels with a broadcast stride, 16-bit and fp32 outputs."""
+    b1, b2 = 3, 2
+    a = _r((b1, b2, k, m) if ta else (b1, b2, m, k), 7, dtype=dtype)
+    w = _r((b1, 1, n, k) if tb else (b1, 1, k, n), 8, dtype=dtype).expand(b1, b2, -1, -1)          # level-2 stride 0
+    ref = (a.float().transpose(2, 3) if ta else a.float()) @ (w.float().transpose(2, 3) if tb else w.float())
+    out = T.bmm(a, w, ta, tb, out_dtype=torch.float32)
+    torch.testing.assert_close(out, ref, atol=1e-3 * max(1.0, k ** 0.5 / 8), rtol=1e-4)
+    out16 = T.bmm(a, w, ta, tb)
+    assert out16.dtype == dtype
+    torch.testing.assert_close(out16.float(), ref, atol=(0.06 if dtype == BF else 0.008) * max(1.0, k ** 0.5 / 4), rtol=2e-2)
+    # padded leading dimensions (what the attention score tensors use): same numbers through the 16-byte path
+    pad = lambda t: torch.nn.functional.pad(t.contiguous(), (0, (-t.shape[-1]) % 8 + 8))[..., :t.shape[-1]]
+    out_p = T.bmm(pad(a), pad(w), ta, tb, out_dtype=torch.float32)
+    torch.testing.assert_close(out_p, out, atol=1e-5, rtol=1e-5)
+
+
+def test_bmm_split_k_weight_gradient(T):
+    """dW = dy^T x as cir_bmm sees it in train.py: trans_a = 1, a batch over row chunks into partial sums, then column sums."""
+    rows, n, k, nb = 16 * 37, 96, 128, 16
+    dy, x = _r((rows, n), 9, dtype=BF), _r((rows, k), 10, dtype=BF)
+    part = T.bmm(dy.view(nb, rows // nb, n), x.view(nb, rows // nb, k), True, False, out_dtype=torch.float32)
+    dw = torch.zeros((n * k,), device="cuda")
+    T.colsum(part.view(nb, n * k), dw)
+    torch.testing.assert_close(dw.view(n, k), dy.float().t() @ x.float(), atol=2e-3, rtol=1e-4)
+
+
 @pytest.mark.parametrize("p_drop", [0.0, 0.1])
 def test_softmax_dropout_fwd_bwd(T, p_drop):
     groups, rpm, cols = 6, 32, 197

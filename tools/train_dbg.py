@@ -22,7 +22,7 @@ m2 = BLIP_NLVR(med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer()
 m2 = m2.cuda().float().set_compute_dtype(dtype)
 tr = NlvrTrainer(m2, 0.0, 0.0)
 mine = tr.forward(zt.cuda(), feats.cuda(), ids.cuda(), mask.cuda())
-logits = O.img_txt_fusion_train(w, zt, feats, ids, mask, relu_mask=None if "nomask" in sys.argv else (tr.sv["z1"] > 0).cpu())
+logits = O.img_txt_fusion_train(w, zt, feats, ids, mask, relu_mask=None if "nomask" in sys.argv else tr.head_mask().cpu())
 loss = F.cross_entropy(logits, torch.arange(4)); loss.backward()
 dl = torch.autograd.grad(F.cross_entropy(logits.detach().requires_grad_(True), torch.arange(4)), [])if False else None
 lg = logits.detach().clone().requires_grad_(True); F.cross_entropy(lg, torch.arange(4)).backward(); dl = lg.grad
