@@ -340,6 +340,42 @@ def loop_mode(args, m2, m1, dev, dt):
         "logits_max_abs_diff_bank_vs_loop": float((lg[0] - lg_b[0]).abs().max()) if ns else float((lg - lg_b).abs().max())}), flush=True)
 
 
+def train_gflop(b: int, l: int, n: int, d: int = 768, layers: int = 12, merge_from: int = 6):
+    """Algorithmic GFLOP of one training step's fusion part as THIS library runs it (each target's cross-attention K/V projected
+    once per step; the reference's loop projects them B times): (forward, backward).  Backward = dgrad + wgrad of every Linear
+    (K/V projections: wgrad only - the image tokens are inputs) + the four adjoint products of each attention."""
+    r = b * b * l
+    lin = 6 * 2 * r * d * d + 16 * r * d * d                      # q k v o cq d + the shared FFN, per branch
+    att = 4 * r * l * d + 4 * r * n * d                            # QK^T + PV, self and cross, per branch
+    kv = 2 * 2 * (b * n) * d * d                                   # cross K, V of the B targets, per branch
+    fwd = layers * 2 * (lin + att + kv) + (layers - merge_from) * 4 * r * d * d + 2 * b * b * (2 * d * d + 2 * d)
+    bwd = layers * 2 * (2 * lin + 2 * att + kv) + (layers - merge_from) * 8 * r * d * d + 4 * b * b * (2 * d * d + 2 * d)
+    return fwd / 1e9, bwd / 1e9
+
+
+def train_cpu_baseline(threads: int, sd, l: int, n_tok: int, b: int = 8):
+    """The fp32 oracle's training step (forward + torch-autograd backward, no optimizer) on the host cores, on a bounded sample:
+    B = 8 (64 triplets, ~10 s) at the same caption / image token counts."""
+    import torch.nn.functional as F
+    from candidate_reranking_cir_amd import synthetic
+    from oracle import cir_oracle as O
+    torch.set_num_threads(threads)
+    w = {k: t.detach().float().cpu().clone() for k, t in sd.items()}
+    for k, t in w.items():
+        if k.startswith(("text_encoder.", "cls_head.")) and t.is_floating_point():
+            t.requires_grad_(True)
+    gen = torch.Generator().manual_seed(3)
+    z_t, feats = torch.randn((b, l, 768), generator=gen), torch.randn((b, n_tok, 768), generator=gen)
+    ids = torch.stack([synthetic.caption_ids(q, l) for q in range(b)])
+    t0 = time.perf_counter()
+    logits = O.img_txt_fusion_train(w, z_t, feats, ids, torch.ones_like(ids))
+    F.cross_entropy(logits, torch.arange(b)).backward()
+    dt_s = time.perf_counter() - t0
+    return {"value": round(b * b / dt_s, 3), "unit": "triplets/s", "cores": threads, "kind": "port",
+            "sample": f"one training step (fp32 forward + autograd backward, no optimizer, ViT and stage I excluded) of oracle/cir_oracle.py at B = {b} "
+                      f"({b * b} triplets, {l} caption tokens, {n_tok} image tokens): {dt_s:.1f} s"}
+
+
 def train_mode(args, m2, m1, dev, dt):
     """One stage-II TRAINING step (stage2_train.py:176-218 with the default frozen ViT), timed end to end:
     reference + target images through the ViT (no grad), z_t from the frozen stage-I model, `img_txt_fusion` in .train() mode
@@ -393,13 +429,21 @@ def train_mode(args, m2, m1, dev, dt):
     dt_s = (time.perf_counter() - t0) / args.steps
     step(True)
     n_tok = (args.image_size // 16) ** 2 + 1
+    gf, gb = train_gflop(b, l, n_tok)
+    fb_s = legs["fusion_forward"] + legs["backward"]
+    cpu = None if args.no_cpu_baseline else train_cpu_baseline(usable_cpus(), m2.state_dict(), l, n_tok)
     print(json.dumps({
         "metric": "stage-II training step, query-target pairs (B x B) forward+backward per second (stage2_train.py loop; not the headline metric)",
         "value": round(b * b / dt_s, 1), "unit": "triplets/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt_s * 1e3, 2), "higher_is_better": True, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"batch {b} (B x B = {b * b} triplets), {l} caption tokens, {n_tok} image tokens ({args.image_size} px), ViT frozen, "
                                f"dropout 0.1, AdamW; fp32 residual stream"},
-        "legs_ms": {k: round(v * 1e3, 2) for k, v in legs.items()}, "loss": round(float(loss.detach()), 4)}), flush=True)
+        "legs_ms": {k: round(v * 1e3, 2) for k, v in legs.items()}, "loss": round(float(loss.detach()), 4),
+        "algorithmic_gflop_per_step": {"fusion_forward": round(gf, 1), "backward": round(gb, 1)},
+        "roofline": {"bound": "mfma", "achieved": round((gf + gb) / fb_s / 1e3, 1), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                     "frac": round((gf + gb) / fb_s / 1e3 / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                     "note": "fusion forward + backward legs (synchronised) over their algorithmic flops; first-version kernels, see DESIGN section 9"},
+        "cpu_baseline": cpu}), flush=True)
 
 
 def main():

@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256) void bmm_mfma_kernel(BmmArgs a) {
     typedef typename Elem<T>::x8 X8;
     constexpr int BT = 32 * F, H = F / 2;                   // block tile extent; 64-row fetch slabs per operand
     constexpr int kImg = (BT * kBmmLd > 32 * (BT + 16) ? BT * kBmmLd : 32 * (BT + 16)) * 2;
-    __shared__ __attribute__((aligned(16))) char As[kImg];
-    __shared__ __attribute__((aligned(16))) char Bs[kImg];
+    __shared__ __attribute__((aligned(16))) char As[2][kImg];     // two images per operand: tile k+1 is written while tile k is read,
+    __shared__ __attribute__((aligned(16))) char Bs[2][kImg];     // one barrier per K step
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r15 = lane & 15, g = lane >> 4, wm = wave >> 1, wn = wave & 1;
     const int z1 = blockIdx.z / a.nb2, z2 = blockIdx.z % a.nb2;
@@ -191,31 +191,46 @@ __global__ __launch_bounds__(256) void bmm_mfma_kernel(BmmArgs a) {
         ra[h] = bmm_fetch<T>(A, a.lda, ka, a.M, a.K, m0 + h * 64, 0, a.vecA, tid);
         rb[h] = bmm_fetch<T>(B, a.ldb, kb, a.N, a.K, n0 + h * 64, 0, a.vecB, tid);
     }
-    for (int k0 = 0; k0 < a.K; k0 += 32) {
-        __syncthreads();                                     // the previous step's fragment reads are done
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        bmm_stash<T, BT>(As[0], ra[h], ka, tid, h);
+        bmm_stash<T, BT>(Bs[0], rb[h], kb, tid, h);
+    }
+    if (32 < a.K) {
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-            bmm_stash<T, BT>(As, ra[h], ka, tid, h);
-            bmm_stash<T, BT>(Bs, rb[h], kb, tid, h);
+            ra[h] = bmm_fetch<T>(A, a.lda, ka, a.M, a.K, m0 + h * 64, 32, a.vecA, tid);
+            rb[h] = bmm_fetch<T>(B, a.ldb, kb, a.N, a.K, n0 + h * 64, 32, a.vecB, tid);
         }
-        __syncthreads();
-        if (k0 + 32 < a.K) {                                 // next tile's loads fly under this tile's MFMAs
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                ra[h] = bmm_fetch<T>(A, a.lda, ka, a.M, a.K, m0 + h * 64, k0 + 32, a.vecA, tid);
-                rb[h] = bmm_fetch<T>(B, a.ldb, kb, a.N, a.K, n0 + h * 64, k0 + 32, a.vecB, tid);
-            }
-        }
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < a.K; k0 += 32, buf ^= 1) {
         X8 af[F], bf[F];
 #pragma unroll
         for (int i = 0; i < F; ++i) {
-            af[i] = bmm_frag<T, BT>(As, ka, wm * 16 * F + i * 16, lane);
-            bf[i] = bmm_frag<T, BT>(Bs, kb, wn * 16 * F + i * 16, lane);
+            af[i] = bmm_frag<T, BT>(As[buf], ka, wm * 16 * F + i * 16, lane);
+            bf[i] = bmm_frag<T, BT>(Bs[buf], kb, wn * 16 * F + i * 16, lane);
+        }
+        if (k0 + 32 < a.K) {                                 // tile k+1 (in registers since the last step) into the other image,
+#pragma unroll
+            for (int h = 0; h < H; ++h) {                    // tile k+2's loads fly under this tile's MFMAs
+                bmm_stash<T, BT>(As[buf ^ 1], ra[h], ka, tid, h);
+                bmm_stash<T, BT>(Bs[buf ^ 1], rb[h], kb, tid, h);
+            }
+            if (k0 + 64 < a.K) {
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    ra[h] = bmm_fetch<T>(A, a.lda, ka, a.M, a.K, m0 + h * 64, k0 + 64, a.vecA, tid);
+                    rb[h] = bmm_fetch<T>(B, a.ldb, kb, a.N, a.K, n0 + h * 64, k0 + 64, a.vecB, tid);
+                }
+            }
         }
 #pragma unroll
         for (int mi = 0; mi < F; ++mi)
 #pragma unroll
             for (int ni = 0; ni < F; ++ni) acc[mi][ni] = Elem<T>::mfma16(af[mi], bf[ni], acc[mi][ni]);
+        __syncthreads();                                     // image buf^1 complete; image buf free for the step after next
     }
     // lane (r15, g) holds C[m = 4 g + jj][n = r15] of each 16 x 16 tile
 #pragma unroll
@@ -237,6 +252,8 @@ __global__ __launch_bounds__(256) void bmm_mfma_kernel(BmmArgs a) {
 
 // ---- row softmax with additive key mask and dropout: P = softmax(S * scale + mask), Pd = dropout(P) ----------------------
 // one wave per row; S fp32 (rows, cols) with leading dimension lds_; mask fp32 (cols) per group of `rows_per_mask` rows or NULL.
+// Rows up to 64 * kSmCols columns are held in registers (one pass over S / dPd); longer rows take the re-reading loops.
+constexpr int kSmCols = 12;      // 768 columns: the 577 / 197 image tokens and any caption length
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* S, int64_t ld_s, const float* mask, int64_t rows_per_mask, int64_t ld_mask,
                                                           T* P, T* Pd, int64_t ld_p, int64_t rows, int cols, float scale, float p_drop, uint64_t seed) {
@@ -245,13 +262,40 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* S, int64_
     if (row >= rows) return;
     const float* sr = S + row * ld_s;
     const float* mr = mask ? mask + (row / rows_per_mask) * ld_mask : nullptr;
+    const float keep = 1.0f / (1.0f - p_drop);
+    if (cols <= 64 * kSmCols) {
+        float v[kSmCols];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < kSmCols; ++i) {
+            const int c = lane + i * 64;
+            v[i] = c < cols ? fmaf(sr[c], scale, mr ? mr[c] : 0.f) : -INFINITY;
+            mx = fmaxf(mx, v[i]);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < kSmCols; ++i) { v[i] = (lane + i * 64 < cols) ? __expf(v[i] - mx) : 0.f; sum += v[i]; }
+        const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+        for (int i = 0; i < kSmCols; ++i) {
+            const int c = lane + i * 64;
+            if (c < cols) {
+                const float p = v[i] * inv;
+                P[row * ld_p + c] = static_cast<T>(p);
+                const bool kept = p_drop <= 0.f || uniform01(seed, (uint64_t)row * (uint64_t)cols + c) >= p_drop;
+                Pd[row * ld_p + c] = static_cast<T>(kept ? p * (p_drop > 0.f ? keep : 1.0f) : 0.f);
+            }
+        }
+        return;
+    }
     float mx = -INFINITY;
     for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, fmaf(sr[c], scale, mr ? mr[c] : 0.f));
     mx = wave_max(mx);
     float sum = 0.f;
     for (int c = lane; c < cols; c += 64) sum += __expf(fmaf(sr[c], scale, mr ? mr[c] : 0.f) - mx);
     sum = wave_sum(sum);
-    const float inv = 1.0f / sum, keep = 1.0f / (1.0f - p_drop);
+    const float inv = 1.0f / sum;
     for (int c = lane; c < cols; c += 64) {
         const float p = __expf(fmaf(sr[c], scale, mr ? mr[c] : 0.f) - mx) * inv;
         P[row * ld_p + c] = static_cast<T>(p);
@@ -268,6 +312,28 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* P, int64_t ld
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    if (cols <= 64 * kSmCols) {
+        float dp[kSmCols], pv[kSmCols];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < kSmCols; ++i) {
+            const int c = lane + i * 64;
+            dp[i] = 0.f; pv[i] = 0.f;
+            if (c < cols) {
+                const bool kept = p_drop <= 0.f || uniform01(seed, (uint64_t)row * (uint64_t)cols + c) >= p_drop;
+                dp[i] = kept ? dPd[row * ld_d + c] * keep : 0.f;
+                pv[i] = static_cast<float>(P[row * ld_p + c]);
+                dot += dp[i] * pv[i];
+            }
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int i = 0; i < kSmCols; ++i) {
+            const int c = lane + i * 64;
+            if (c < cols) dS[row * ld_ds + c] = static_cast<T>(scale * pv[i] * (dp[i] - dot));
+        }
+        return;
+    }
     float dot = 0.f;
     for (int c = lane; c < cols; c += 64) {
         const bool kept = p_drop <= 0.f || uniform01(seed, (uint64_t)row * (uint64_t)cols + c) >= p_drop;

@@ -291,8 +291,11 @@ class NlvrTrainer:
         # every adjoint below is linear in the incoming gradient, so the pass runs on S * dlogits with S a power of two that
         # puts the largest entry near 512 - the 16-bit copies fed to the dgrad / wgrad GEMMs then sit in fp16's normal range
         # (hidden-state gradients are ~1e-5 per element unscaled, fp16's smallest normal is 6e-5) - and `_collect` divides by S.
-        amax = float(dlogits.abs().max())
-        self.grad_scale = 2.0 ** round(math.log2(512.0 / amax)) if amax > 0 and math.isfinite(amax) else 1.0
+        # bf16 has fp32's exponent range and needs none of this: scale 1, no unscaling pass.
+        self.grad_scale = 1.0
+        if dt == torch.float16:
+            amax = float(dlogits.abs().max())
+            self.grad_scale = 2.0 ** round(math.log2(512.0 / amax)) if amax > 0 and math.isfinite(amax) else 1.0
         dl2 = torch.zeros((t_n, 2), dtype=torch.float32, device=dev)
         dl2[:, 0] = T.eltwise(dlogits.float().t().contiguous().view(-1), T.MODE_SCALE, p_drop=self.grad_scale)
         dy1 = self.c2.bwd(sv["y16"], dl2)
@@ -402,7 +405,7 @@ class _FusionTrainFn(torch.autograd.Function):
             if name == tr.anchor_name:
                 anchor_grad = gq
             else:
-                p.grad = gq.clone() if p.grad is None else T.eltwise(p.grad.contiguous(), T.MODE_ADD, gq.contiguous())
+                p.grad = gq if p.grad is None else T.eltwise(p.grad.contiguous(), T.MODE_ADD, gq.contiguous())   # (gq is this step's own buffer)
         return anchor_grad, None, None, None, None, None
 
 

@@ -100,6 +100,23 @@ def test_argument_validation_happens_before_any_launch():
     assert clsx(P, 0, None, P, P, 1, 4, 1024, 0.125, BF16, None) == ESHAPE and clsx(P, 0, None, P, P, 1, 4, 192, 0.125, BF16, None) == ESHAPE
     assert clsx(P, 4, None, P, P, 1, 4, 128, 0.125, BF16, None) == EALIGN and clsx(P, 0, None, P + 2, P, 1, 4, 128, 0.125, BF16, None) == EALIGN
     assert clsx(P, 0, None, P, P, 1, 4, 128, 0.125, F32, None) == EDTYPE
+    # training-mode operators: the same contract
+    bmm = lambda **o: c.cir_bmm(*[{**dict(A=P, B=P, C=P, M=4, N=4, K=4, lda=4, ldb=4, ldc=4, ta=0, tb=0, nb1=1, nb2=1, sA1=0, sA2=0, sB1=0, sB2=0,
+                                          sC1=0, sC2=0, alpha=1.0, acc=0, it=BF16, ot=F32, st=None), **o}[k]
+                                  for k in ("A", "B", "C", "M", "N", "K", "lda", "ldb", "ldc", "ta", "tb", "nb1", "nb2", "sA1", "sA2", "sB1", "sB2", "sC1",
+                                            "sC2", "alpha", "acc", "it", "ot", "st")])
+    assert bmm(A=None) == EINVAL and bmm(K=0) == EINVAL and bmm(nb2=0) == EINVAL and bmm(nb1=300, nb2=300) == ESHAPE
+    assert bmm(it=BF16, ot=F16) == EDTYPE and bmm(it=F32, ot=BF16) == EDTYPE and bmm(it=7) == EDTYPE
+    assert c.cir_transpose16(None, P, 4, 4, 4, 4, 1, 0, 0, BF16, None) == EINVAL and c.cir_transpose16(P, P, 4, 4, 4, 4, 1, 0, 0, F32, None) == EDTYPE
+    assert c.cir_softmax_dropout(P, 8, None, 0, 0, P, P, 8, 4, 8, 0.125, 1.0, 1, BF16, None) == EINVAL              # p_drop = 1
+    assert c.cir_softmax_dropout(P, 8, None, 0, 0, P, P, 8, 4, 8, 0.125, 0.1, 1, F32, None) == EDTYPE
+    assert c.cir_softmax_dropout_bwd(P, 8, None, 8, P, 8, 4, 8, 0.125, 0.1, 1, BF16, None) == EINVAL
+    assert c.cir_layernorm_bwd(P, P, P, P, P, None, 4, 64, 1e-12, None) == EINVAL and c.cir_layernorm_bwd(P, P, P, P, P, P, 4, 2048, 1e-12, None) == ESHAPE
+    assert c.cir_eltwise(P, F32, None, P, F32, 8, 1, 0.0, 0, None) == EINVAL                                          # GELU' without dy
+    assert c.cir_eltwise(P, F32, None, P, F32, 8, 9, 0.0, 0, None) == EINVAL and c.cir_eltwise(P, 7, None, P, F32, 8, 0, 0.0, 0, None) == EDTYPE
+    assert c.cir_colsum(P, 8, None, 4, 8, None) == EINVAL and c.cir_embed_bwd(P, P, P, None, 4, 2, 8, None) == EINVAL
+    assert c.cir_adamw_step(P, P, P, None, 8, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, None) == EINVAL
+    assert c.cir_adamw_step(P, P, P, P, 8, 1e-3, 0.9, 0.999, 1e-8, 0.01, 0, None) == EINVAL                           # step counts from 1
     # kernel-selection overrides: range-checked, default automatic, and the library reads no environment variables
     assert c.cir_set_tuning(7, 0) == EINVAL and c.cir_set_tuning(0, 64) == EINVAL and c.cir_set_tuning(2, 9000) == EINVAL
     assert c.cir_set_tuning(0, 128) == 0 and c.cir_set_tuning(0, 0) == 0 and c.cir_set_tuning(2, -1) == 0 and c.cir_set_tuning(2, 0) == 0

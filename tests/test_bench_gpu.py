@@ -93,3 +93,18 @@ def test_loop_mode_line():
     d = _last_json(r.stdout)
     assert d["value"] > 0 and "scoring loop" in d["metric"] and d["host_overhead_frac"] < 1
     assert d["recall"] == d["recall_kv_bank"] and d["logits_max_abs_diff_bank_vs_loop"] == 0.0 and d["level1_ms_per_query"] > 0
+
+
+def test_train_mode_line():
+    """`--mode train`: one stage2_train.py-shaped step (ViT, z_t, fusion forward in .train() mode, backward, AdamW) on a small
+    batch; the line carries the per-leg times, the flop model's roofline fraction and the CPU oracle's training step beside it."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--train-batch", "4", "--image-size", "64", "--tokens", "12",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["value"] > 0 and "training step" in d["metric"] and d["unit"] == "triplets/s"
+    assert set(d["legs_ms"]) == {"vit", "z_t", "fusion_forward", "backward", "adamw"} and all(v > 0 for v in d["legs_ms"].values())
+    assert 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    assert 0 < d["loss"] < 10

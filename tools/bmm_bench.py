@@ -1,0 +1,37 @@
+"""Stand-alone timings of cir_bmm on the training step's shapes: weight gradients (trans_a, split over row chunks) and the
+stacked cross-attention products.  python tools/bmm_bench.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from candidate_reranking_cir_amd import train_ops as T
+
+dt = torch.bfloat16
+def timeit(fn, reps=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e6
+
+# keep the clocks up
+warm = torch.randn(8192, 8192, device="cuda", dtype=dt)
+for _ in range(30): warm @ warm
+for rows, n, k in ((8192, 768, 768), (8192, 3072, 768), (8192, 768, 3072), (9232, 768, 768)):
+    dy = torch.randn(rows, n, device="cuda", dtype=dt); x = torch.randn(rows, k, device="cuda", dtype=dt)
+    for nb in (1, 2, 4, 8, 16, 32):
+        if rows % nb: continue
+        us = timeit(lambda: T.bmm(dy.view(nb, rows // nb, n), x.view(nb, rows // nb, k), True, False, out_dtype=torch.float32))
+        print(f"wgrad rows {rows} N {n} K {k} nb {nb:2d}: {us:8.1f} us  {2 * rows * n * k / us / 1e6:7.1f} TFLOP/s")
+b, h, l, n_tok, d = 16, 12, 32, 577, 768
+q = torch.randn(b * b * l, d, device="cuda", dtype=dt); kk = torch.randn(b * n_tok, d, device="cuda", dtype=dt)
+heads = lambda x, g, r: x.view(g, r, h, 64).permute(0, 2, 1, 3)
+ld = 584
+s = torch.empty(b, h, b * l, ld, device="cuda")
+us = timeit(lambda: T.bmm(heads(q, b, b * l), heads(kk, b, n_tok), False, True, out=s[..., :n_tok]))
+print(f"cross QK^T (16 x 12 x 512 x 577 x 64): {us:8.1f} us  {2 * b * h * b * l * n_tok * 64 / us / 1e6:7.1f} TFLOP/s")
+p = torch.randn(b, h, b * l, ld, device="cuda").to(dt)
+ctx = torch.empty(b * b * l, d, device="cuda", dtype=dt)
+us = timeit(lambda: T.bmm(p[..., :n_tok], heads(kk, b, n_tok), False, False, out=heads(ctx, b, b * l)))
+print(f"cross P V   (16 x 12 x 512 x 64 x 577): {us:8.1f} us  {2 * b * h * b * l * n_tok * 64 / us / 1e6:7.1f} TFLOP/s")
+dv = torch.empty(b * n_tok, d, device="cuda")
+us = timeit(lambda: T.bmm(p[..., :n_tok], heads(ctx, b, b * l), True, False, out=heads(dv, b, n_tok)))
+print(f"cross dV    (16 x 12 x 577 x 64 x 512): {us:8.1f} us  {2 * b * h * b * l * n_tok * 64 / us / 1e6:7.1f} TFLOP/s")

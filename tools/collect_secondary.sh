@@ -14,6 +14,9 @@ python bench.py --k 200 --dtype f16 --queries 32 --steps 10 --warmup 3 --no-cpu-
 python bench.py --image-size 384 --queries 16 --steps 6 --warmup 2 --no-cpu-baseline --no-precision-table > $O/bench_384px.json 2>> $O/err.txt
 python bench.py --mode bank --steps 10 --warmup 3 > $O/bench_bank_mode.json 2>> $O/err.txt
 python bench.py --mode loop > $O/bench_loop_mode.json 2>> $O/err.txt
+python bench.py --mode train --image-size 384 --steps 10 --warmup 3 > $O/bench_train_mode.json 2>> $O/err.txt                    # stage2_train.py step, B = 16
+python bench.py --mode train --image-size 384 --dtype f16 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_train_mode_f16.json 2>> $O/err.txt
+python bench.py --mode train --image-size 224 --train-batch 32 --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_train_mode_b32_224.json 2>> $O/err.txt
 Q=64 python tools/gemm_shapes.py $O/gemm_shapes.json > $O/gemm_shapes.txt 2>> $O/err.txt
 python tools/gemm_ab.py > $O/gemm_ab.txt 2>> $O/err.txt
 python tools/attn_bench.py > $O/attn_bench.txt 2>> $O/err.txt
