@@ -221,3 +221,30 @@ def test_adamw_training_loop_reduces_loss(cuda):
     print(f"\n[adamw loop] loss {losses[0]:.4f} -> {losses[-1]:.4f}; eval-mode loss after {l_eval:.4f}")
     assert losses[-1] < losses[0] - 0.3 and l_eval < losses[0] - 0.3
     assert not torch.allclose(before, after)
+
+
+def test_reference_loop_with_autocast_and_gradscaler(cuda):
+    """stage2_train.py:202-218 verbatim: torch.optim.AdamW, torch.cuda.amp.autocast around forward + loss, GradScaler around
+    backward / step (loss scaled by 65536: the backward's internal scale adapts, unscale_ sees finite fp32 gradients)."""
+    z = H.load("train768.npz")
+    g, v = H.geometry(json.loads(str(z["bert_cfg"])), json.loads(str(z["vit_cfg"])))
+    m2, _ = build(g, v, int(z["seed"]), str(z["profile"]), HF)
+    freeze_vit(m2)
+    m2.train()
+    caps = [str(c) for c in z["caps"]]
+    zt, feats = torch.from_numpy(z["z_t"]).cuda(), torch.from_numpy(z["feats"]).cuda()
+    opt = torch.optim.AdamW(filter(lambda p: p.requires_grad, m2.parameters()), lr=2e-5, weight_decay=0.05)
+    scaler = torch.cuda.amp.GradScaler()
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        with torch.cuda.amp.autocast():
+            logits = m2.img_txt_fusion(zt, feats, caps, train=True)
+            loss = F.cross_entropy(logits, torch.arange(4, device=cuda))
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        losses.append(loss.item())
+    assert scaler.get_scale() >= 65536.0                      # no step was skipped for inf / nan gradients
+    assert losses[-1] < losses[0] - 0.1, losses
+    m2.eval()
