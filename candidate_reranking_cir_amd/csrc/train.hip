@@ -1,10 +1,10 @@
 // Training-mode operators of the two-branch encoder (BLIP_NLVR.img_txt_fusion in train() mode + backward,
 // blip_stage2.py:65-99 driven by stage2_train.py:202-216).  The dense Linear layers keep running on the MFMA GEMM
 // (cir_gemm_bias_act: dgrad through a transposed weight copy, wgrad through transposed activation copies); this file holds
-// what the backward pass needs besides: 16-bit transposes, a general small batched matmul for the attention pieces
-// (32 x 32 / 32 x 197 tiles whose extents fit no MFMA tile constraint), row softmax with additive mask and counter-based dropout
-// (+ backward), LayerNorm backward, GELU / ReLU forward-backward, dropout, column sums, embedding scatter-add, AdamW.
-// First version: every kernel is HBM- or latency-bound by design and correct first; none is on the inference path.
+// what the training pass needs besides: 16-bit transposes, a batched matmul on the matrix cores for products of any extents and
+// storage orders (weight gradients dy^T x read as stored; the un-fused attention and its four adjoints per (candidate or
+// triplet, head)), row softmax with additive mask and counter-based dropout (+ backward), LayerNorm backward, GELU / ReLU
+// forward-backward, dropout, column sums, embedding scatter-add, AdamW.  None of it is on the inference path.
 
 #include "common.hpp"
 
@@ -415,27 +415,53 @@ __device__ __forceinline__ float gelu_grad(float x) {
 }
 // mode 0: y = gelu(z); 1: dz = dy * gelu'(z); 2: y = relu(z); 3: dz = dy * (z > 0); 4: y = dropout(z) [dy unused]; 5: y = z + dy (add);
 // 6: y = p_drop * z (scale by the factor passed in p_drop)
+__device__ __forceinline__ float eltwise_op(float v, float d, int mode, float p_drop, float keep, uint64_t seed, int64_t i) {
+    switch (mode) {
+        case 0: return gelu_exact(v);
+        case 1: return d * gelu_grad(v);
+        case 2: return fmaxf(v, 0.f);
+        case 3: return v > 0.f ? d : 0.f;
+        case 4: return (p_drop <= 0.f || uniform01(seed, (uint64_t)i) >= p_drop) ? v * keep : 0.f;
+        case 5: return v + d;
+        default: return v * p_drop;
+    }
+}
+
 template <typename TZ, typename TO>
-__global__ __launch_bounds__(256) void eltwise_kernel(const TZ* z, const float* dy, TO* out, int64_t n, int mode, float p_drop, uint64_t seed) {
+__global__ __launch_bounds__(256) void eltwise_kernel(const TZ* z, const float* dy, TO* out, int64_t n, int mode, float p_drop, uint64_t seed, int vec) {
     const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;         // four consecutive elements per thread
     if (i0 >= n) return;
     const float keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const bool use_dy = mode == 1 || mode == 3 || mode == 5;
+    if (vec && i0 + 4 <= n) {                                                   // 16-byte fp32 accesses (host checked the alignment)
+        float v[4], d[4] = {0.f, 0.f, 0.f, 0.f}, r[4];
+        if constexpr (sizeof(TZ) == 4) {
+            const float4 z4 = *reinterpret_cast<const float4*>(z + i0);
+            v[0] = z4.x; v[1] = z4.y; v[2] = z4.z; v[3] = z4.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = static_cast<float>(z[i0 + e]);
+        }
+        if (use_dy) {
+            const float4 d4 = *reinterpret_cast<const float4*>(dy + i0);
+            d[0] = d4.x; d[1] = d4.y; d[2] = d4.z; d[3] = d4.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = eltwise_op(v[e], d[e], mode, p_drop, keep, seed, i0 + e);
+        if constexpr (sizeof(TO) == 4) {
+            *reinterpret_cast<float4*>(out + i0) = make_float4(r[0], r[1], r[2], r[3]);
+        } else {
+            typedef __attribute__((ext_vector_type(4))) TO to4;
+            to4 o = {static_cast<TO>(r[0]), static_cast<TO>(r[1]), static_cast<TO>(r[2]), static_cast<TO>(r[3])};
+            *reinterpret_cast<to4*>(out + i0) = o;
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int64_t i = i0 + e;
         if (i >= n) break;
-        const float v = static_cast<float>(z[i]);
-        float r;
-        switch (mode) {
-            case 0: r = gelu_exact(v); break;
-            case 1: r = dy[i] * gelu_grad(v); break;
-            case 2: r = fmaxf(v, 0.f); break;
-            case 3: r = v > 0.f ? dy[i] : 0.f; break;
-            case 4: r = (p_drop <= 0.f || uniform01(seed, (uint64_t)i) >= p_drop) ? v * keep : 0.f; break;
-            case 5: r = v + dy[i]; break;
-            default: r = v * p_drop; break;
-        }
-        out[i] = static_cast<TO>(r);
+        out[i] = static_cast<TO>(eltwise_op(static_cast<float>(z[i]), use_dy ? dy[i] : 0.f, mode, p_drop, keep, seed, i));
     }
 }
 
@@ -569,7 +595,8 @@ extern "C" int cir_eltwise(const void* z, int z_dtype, const float* dy, void* ou
     if ((mode == 1 || mode == 3 || mode == 5) && dy == nullptr) return CIR_EINVAL;
     dim3 grid((unsigned)((n + 1023) / 1024)), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#define CIR_ELT(TZ, TO) hipLaunchKernelGGL((eltwise_kernel<TZ, TO>), grid, block, 0, s, reinterpret_cast<const TZ*>(z), dy, reinterpret_cast<TO*>(out), n, mode, p_drop, seed)
+    const int vec = (reinterpret_cast<uintptr_t>(z) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0 && reinterpret_cast<uintptr_t>(dy) % 16 == 0) ? 1 : 0;
+#define CIR_ELT(TZ, TO) hipLaunchKernelGGL((eltwise_kernel<TZ, TO>), grid, block, 0, s, reinterpret_cast<const TZ*>(z), dy, reinterpret_cast<TO*>(out), n, mode, p_drop, seed, vec)
 #define CIR_ELT_OUT(TZ) do { if (out_dtype == CIR_F32) CIR_ELT(TZ, float); else if (out_dtype == CIR_BF16) CIR_ELT(TZ, __bf16); else if (out_dtype == CIR_F16) CIR_ELT(TZ, _Float16); else return CIR_EDTYPE; } while (0)
     if (z_dtype == CIR_F32) CIR_ELT_OUT(float);
     else if (z_dtype == CIR_BF16) CIR_ELT_OUT(__bf16);

@@ -40,8 +40,8 @@ def _cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 def _row_split(rows: int, out_elems: int) -> int:
     """Number of row chunks of a weight-gradient product: the largest divisor of `rows` up to 32 that leaves >= 128 rows per chunk
-    and keeps the partial sums under 64 MB."""
-    cap = min(32, max(1, (16 << 20) // max(1, out_elems)))
+    and keeps the partial sums under 256 MB."""
+    cap = min(32, max(1, (64 << 20) // max(1, out_elems)))
     best = 1
     for nb in range(2, cap + 1):
         if rows % nb == 0 and rows // nb >= 128:
