@@ -522,9 +522,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* x, int64_t ld,
     if (c >= cols) return;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += x[r * ld + c];
-    atomicAdd(out + c, s);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // four independent loads in flight per thread
+    int64_t r = r0;
+    for (; r + 3 < r1; r += 4) {
+        s0 += x[r * ld + c]; s1 += x[(r + 1) * ld + c]; s2 += x[(r + 2) * ld + c]; s3 += x[(r + 3) * ld + c];
+    }
+    for (; r < r1; ++r) s0 += x[r * ld + c];
+    atomicAdd(out + c, (s0 + s1) + (s2 + s3));
 }
 
 // embedding backward: dword[ids[r]][c] += dy[r][c], dpos[r % L][c] += dy[r][c]  (fp32, atomics: zero first)

@@ -77,13 +77,14 @@ def test_bmm_split_k_weight_gradient(T):
     torch.testing.assert_close(dw.view(n, k), dy.float().t() @ x.float(), atol=2e-3, rtol=1e-4)
 
 
+@pytest.mark.parametrize("cols", [197, 900], ids=["row-in-registers", "long-row-loops"])
 @pytest.mark.parametrize("p_drop", [0.0, 0.1])
-def test_softmax_dropout_fwd_bwd(T, p_drop):
-    groups, rpm, cols = 6, 32, 197
+def test_softmax_dropout_fwd_bwd(T, p_drop, cols):
+    groups, rpm = 6, 32
     rows = groups * rpm
     s = _r((rows, cols), 6, 3.0)
     mask = torch.zeros((groups, cols), device="cuda")
-    mask[:, 190:] = -10000.0
+    mask[:, cols - 7:] = -10000.0
     p, pd = T.softmax_dropout(s, mask, rpm, 0.125, p_drop, 1234, BF)
     ref = torch.softmax(s * 0.125 + mask.repeat_interleave(rpm, 0), -1)
     torch.testing.assert_close(p.float(), ref, atol=4e-3, rtol=0)
@@ -107,8 +108,22 @@ def test_softmax_dropout_fwd_bwd(T, p_drop):
     torch.testing.assert_close(ds.float(), sx.grad, atol=3e-3, rtol=2e-2)
 
 
-def test_layernorm_bwd(T):
-    rows, cols = 203, 768
+def test_softmax_padded_rows(T):
+    """Score rows padded to a multiple of 8 (what train.py allocates for 577 / 197 keys): only the first `cols` entries are read
+    and written; dropout indices follow (row, col), not the padded offset."""
+    rows, cols, ld = 70, 197, 200
+    s = _r((rows, ld), 21, 3.0)
+    p, pd = T.softmax_dropout(s, None, 1, 0.125, 0.1, 77, HF, cols=cols)
+    pc, pdc = T.softmax_dropout(s[:, :cols].contiguous(), None, 1, 0.125, 0.1, 77, HF)
+    assert torch.equal(p[:, :cols], pc) and torch.equal(pd[:, :cols], pdc)
+    dpd = _r((rows, ld), 22)
+    ds = T.softmax_dropout_bwd(p, dpd, 0.125, 0.1, 77, cols=cols)
+    dsc = T.softmax_dropout_bwd(pc, dpd[:, :cols].contiguous(), 0.125, 0.1, 77)
+    assert torch.equal(ds[:, :cols], dsc)
+
+
+@pytest.mark.parametrize("rows,cols", [(203, 768), (5, 128), (64, 1024)])
+def test_layernorm_bwd(T, rows, cols):
     x, dy = _r((rows, cols), 8, 2.0) + 0.3, _r((rows, cols), 9)
     g, b = _r((cols,), 10) * 0.1 + 1.0, _r((cols,), 11)
     dg, db = torch.zeros(cols, device="cuda"), torch.zeros(cols, device="cuda")
