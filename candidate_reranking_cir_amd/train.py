@@ -38,12 +38,14 @@ def _cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return T.eltwise(x.contiguous(), T.MODE_SCALE, out_dtype=dtype, p_drop=1.0)
 
 
-def _row_split(rows: int, out_elems: int) -> int:
-    """Number of row chunks of a weight-gradient product: the largest divisor of `rows` up to 32 that leaves >= 128 rows per chunk
-    and keeps the partial sums under 256 MB."""
-    cap = min(32, max(1, (64 << 20) // max(1, out_elems)))
+def _row_split(rows: int, n: int, k: int) -> int:
+    """Number of row chunks of a weight-gradient product dW (n, k) over `rows` rows: enough 128 x 128 tiles x chunks for two
+    waves of workgroups on 256 CUs (measured, tools/bmm_bench.py: 16 chunks for a 768 x 768 weight, 8 for the 3072-wide ones;
+    32 is slower again), as a divisor of `rows` that leaves >= 128 rows per chunk."""
+    tiles = ((n + 127) // 128) * ((k + 127) // 128)
+    want = min(16, max(8, 576 // tiles))
     best = 1
-    for nb in range(2, cap + 1):
+    for nb in range(2, want + 1):
         if rows % nb == 0 and rows // nb >= 128:
             best = nb
     return best
@@ -83,7 +85,7 @@ class _Lin:
             T.colsum(dy, self.db)
         # dW (N, K) = dy^T x on cir_bmm (operands read as stored: trans_a), split over row chunks into partial sums so that the
         # 144-tile products of a 768 x 768 weight fill the chip; the partials are summed into dW by the column-sum kernel
-        nb = _row_split(m, n * k)
+        nb = _row_split(m, n, k)
         if nb == 1:
             T.bmm(dy16.unsqueeze(0), x16.unsqueeze(0), True, False, out=self.dw.unsqueeze(0), accumulate=True)
         else:
