@@ -55,16 +55,56 @@ def _gemm_ok(m: int, n: int, k: int) -> bool:
     return k % 64 == 0 and n % 16 == 0
 
 
-class _Lin:
-    """One nn.Linear of the reference (weight (N, K), bias (N)) with the copies the kernels want, refreshed per step."""
+class _Slab:
+    """The trained parameters as ONE flat fp32 buffer (each nn.Parameter's `.data` re-pointed to its slice: optimizers update the
+    buffer in place), their 16-bit operand copies as one flat buffer refreshed by one cast per step, and their gradients as one
+    flat fp32 buffer zeroed once per step - three launches where per-tensor copies took ~900.  Slices start at multiples of 8
+    elements (16-byte rows for the 16-bit views)."""
 
-    def __init__(self, w: torch.Tensor, b: Optional[torch.Tensor], dtype: torch.dtype):
-        self.w32, self.b32 = w, b
-        self.w16 = _cast(w.detach(), dtype)                         # (N, K): forward operand
+    def __init__(self, params: Dict[str, torch.nn.Parameter], names: List[str], dtype: torch.dtype):
+        self.params, self.names, self.dtype = params, names, dtype
+        self.off, o = {}, 0
+        for n in names:
+            self.off[n] = o
+            o += (params[n].numel() + 7) // 8 * 8
+        self.total = o
+        dev = params[names[0]].device
+        self.flat32 = torch.zeros((o,), dtype=torch.float32, device=dev)
+        for n in names:
+            p = params[n]
+            v = self._view(self.flat32, n)
+            v.copy_(p.data)
+            p.data = v
+        self.flat16 = self.gflat = None
+
+    def _view(self, flat: torch.Tensor, n: str) -> torch.Tensor:
+        p = self.params[n]
+        return flat[self.off[n]:self.off[n] + p.numel()].view(p.shape)
+
+    def valid(self) -> bool:
+        base = self.flat32.data_ptr()
+        return all(self.params[n].data_ptr() == base + 4 * self.off[n] for n in self.names)
+
+    def begin_step(self):
+        self.flat16 = _cast(self.flat32, self.dtype)
+        self.gflat = torch.zeros_like(self.flat32)
+
+    def w32(self, n): return self._view(self.flat32, n)
+    def w16(self, n): return self._view(self.flat16, n)
+    def grad(self, n): return self._view(self.gflat, n)
+
+
+class _Lin:
+    """One nn.Linear of the reference (weight (N, K), bias (N)): views of the slab's 16-bit weights / fp32 bias / gradient slices,
+    plus the transposed 16-bit weight copy the dgrad GEMM reads, made per step."""
+
+    def __init__(self, slab: _Slab, name: str):
+        has_bias = (name + ".bias") in slab.off
+        self.w16 = slab.w16(name + ".weight")                                       # (N, K): forward operand
         self.w16t = T.transpose16(self.w16)                                         # (K, N): dgrad operand
-        self.bias = None if b is None else b.detach().float().contiguous()
-        self.dw = torch.zeros_like(self.w16, dtype=torch.float32)
-        self.db = None if b is None else torch.zeros_like(self.bias)
+        self.bias = slab.w32(name + ".bias") if has_bias else None
+        self.dw = slab.grad(name + ".weight")
+        self.db = slab.grad(name + ".bias") if has_bias else None
 
     def fwd(self, x16: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
         m, k = x16.shape
@@ -84,7 +124,7 @@ class _Lin:
         if self.db is not None:
             T.colsum(dy, self.db)
         # dW (N, K) = dy^T x on cir_bmm (operands read as stored: trans_a), split over row chunks into partial sums so that the
-        # 144-tile products of a 768 x 768 weight fill the chip; the partials are summed into dW by the column-sum kernel
+        # 36-tile products of a 768 x 768 weight fill the chip; the partials are summed into dW by the column-sum kernel
         nb = _row_split(m, n, k)
         if nb == 1:
             T.bmm(dy16.unsqueeze(0), x16.unsqueeze(0), True, False, out=self.dw.unsqueeze(0), accumulate=True)
@@ -99,10 +139,10 @@ class _Lin:
 
 
 class _LN:
-    def __init__(self, g: torch.Tensor, b: torch.Tensor, eps: float):
-        self.g32, self.b32, self.eps = g, b, eps
-        self.g, self.b = g.detach().float().contiguous(), b.detach().float().contiguous()
-        self.dg, self.db = torch.zeros_like(self.g), torch.zeros_like(self.b)
+    def __init__(self, slab: _Slab, name: str, eps: float):
+        self.eps = eps
+        self.g, self.b = slab.w32(name + ".weight"), slab.w32(name + ".bias")
+        self.dg, self.db = slab.grad(name + ".weight"), slab.grad(name + ".bias")
 
     def fwd(self, pre: torch.Tensor, dtype: torch.dtype):
         return ops.layernorm(pre, self.g, self.b, self.eps, want32=True, dtype16=dtype, stream_dtype=torch.float32)
@@ -123,14 +163,27 @@ class NlvrTrainer:
         self._scale = self._hd ** -0.5
 
     # ------------------------------------------------------------------------------------------------ parameters
+    _EMB = "text_encoder.embeddings."
+
+    def _trained(self, name: str) -> bool:
+        """The parameters the reference's step gives a gradient (tests/golden/train768.npz: 572 of them): every encoder-layer and
+        cls_head tensor, word / position embeddings and the embedding LayerNorm (token-type embeddings and the pooler are unused)."""
+        e = self._EMB
+        return name.startswith(("text_encoder.encoder.layer.", "cls_head.")) or name in (
+            e + "word_embeddings.weight", e + "position_embeddings.weight", e + "LayerNorm.weight", e + "LayerNorm.bias")
+
     def _pack(self):
         P = dict(self.model.named_parameters())
-        g, dt = self.geo, self.dtype
-        lin = lambda name: _Lin(P[name + ".weight"], P.get(name + ".bias"), dt)
-        ln = lambda name: _LN(P[name + ".weight"], P[name + ".bias"], g.layer_norm_eps)
-        e = "text_encoder.embeddings."
-        self.word, self.pos = P[e + "word_embeddings.weight"], P[e + "position_embeddings.weight"]
-        self.dword, self.dpos = torch.zeros_like(self.word, dtype=torch.float32), torch.zeros_like(self.pos, dtype=torch.float32)
+        slab = getattr(self, "slab", None)
+        if slab is None or slab.dtype != self.dtype or not slab.valid():           # first step, or the model was moved / re-cast
+            slab = self.slab = _Slab(P, [n for n in P if self._trained(n)], self.dtype)
+        slab.begin_step()
+        g = self.geo
+        lin = lambda name: _Lin(slab, name)
+        ln = lambda name: _LN(slab, name, g.layer_norm_eps)
+        e = self._EMB
+        self.word, self.pos = slab.w32(e + "word_embeddings.weight"), slab.w32(e + "position_embeddings.weight")
+        self.dword, self.dpos = slab.grad(e + "word_embeddings.weight"), slab.grad(e + "position_embeddings.weight")
         self.ln_e = ln(e + "LayerNorm")
         self.layers: List[Dict] = []
         for i in range(g.num_hidden_layers):
@@ -145,7 +198,7 @@ class NlvrTrainer:
                 ly[f"ln1{b}"] = ln(p + f"attention.output.LayerNorm{c}")
                 ly[f"ln2{b}"] = ln(p + f"crossattention.output.LayerNorm{c}")
             mk = p + "crossattention.output.merge_layer"
-            ly["merge"] = lin(mk) if (mk + ".weight") in P else None
+            ly["merge"] = lin(mk) if (mk + ".weight") in slab.off else None
             ly["w1"], ly["w2"], ly["ln3"] = lin(p + "intermediate.dense"), lin(p + "output.dense"), ln(p + "output.LayerNorm")
             self.layers.append(ly)
         self.c0, self.c2 = lin("cls_head.0"), lin("cls_head.2")
@@ -217,8 +270,8 @@ class NlvrTrainer:
         self.sv = sv = {"ids": ids_t, "t_n": t_n, "l": l, "n": n, "b_n": b_n}
         # embeddings (BertEmbeddings: LayerNorm(word + pos), dropout) -> branch 1; z_t -> branch 0 (nlvr_encoder.py:880-892)
         pos_idx = torch.arange(l, device=dev).repeat(t_n)
-        pre_e = T.eltwise(ops.gather_rows(self.word.detach().float(), ids_t.view(-1), torch.float32), T.MODE_ADD,
-                          ops.gather_rows(self.pos.detach().float(), pos_idx, torch.float32))
+        pre_e = T.eltwise(ops.gather_rows(self.word, ids_t.view(-1), torch.float32), T.MODE_ADD,
+                          ops.gather_rows(self.pos, pos_idx, torch.float32))
         sv["pre_e"] = pre_e
         e32, _ = self.ln_e.fwd(pre_e, dt)
         e32 = self._drop(e32, self._site(9000))
@@ -350,45 +403,18 @@ class NlvrTrainer:
         return self._collect()
 
     def _collect(self) -> Dict[str, torch.Tensor]:
-        out = self._collect_scaled()
-        inv = 1.0 / self.grad_scale
-        return out if inv == 1.0 else {k: T.eltwise(g, T.MODE_SCALE, p_drop=inv) for k, g in out.items()}
-
-    def _collect_scaled(self) -> Dict[str, torch.Tensor]:
-        out = {}
-        e = "text_encoder.embeddings."
-        out[e + "word_embeddings.weight"], out[e + "position_embeddings.weight"] = self.dword, self.dpos
-        out[e + "LayerNorm.weight"], out[e + "LayerNorm.bias"] = self.ln_e.dg, self.ln_e.db
-
-        def put(name, lin):
-            out[name + ".weight"] = lin.dw
-            if lin.db is not None:
-                out[name + ".bias"] = lin.db
-        for i, ly in enumerate(self.layers):
-            p = f"text_encoder.encoder.layer.{i}."
-            for b in (0, 1):
-                for nm, ref in (("q", "query"), ("k", "key"), ("v", "value")):
-                    put(p + f"attention.self{b}.{ref}", ly[f"{nm}{b}"])
-                    put(p + f"crossattention.self{b}.{ref}", ly[f"c{nm}{b}"])
-                put(p + f"attention.output.dense{b}", ly[f"o{b}"])
-                put(p + f"crossattention.output.dense{b}", ly[f"d{b}"])
-            for c, b in (("A", 0), ("B", 1)):
-                out[p + f"attention.output.LayerNorm{c}.weight"], out[p + f"attention.output.LayerNorm{c}.bias"] = ly[f"ln1{b}"].dg, ly[f"ln1{b}"].db
-                out[p + f"crossattention.output.LayerNorm{c}.weight"], out[p + f"crossattention.output.LayerNorm{c}.bias"] = ly[f"ln2{b}"].dg, ly[f"ln2{b}"].db
-            if ly["merge"] is not None:
-                put(p + "crossattention.output.merge_layer", ly["merge"])
-            put(p + "intermediate.dense", ly["w1"])
-            put(p + "output.dense", ly["w2"])
-            out[p + "output.LayerNorm.weight"], out[p + "output.LayerNorm.bias"] = ly["ln3"].dg, ly["ln3"].db
-        put("cls_head.0", self.c0)
-        put("cls_head.2", self.c2)
-        return out
+        """{name: gradient}: views of the flat gradient buffer (unscaled in one launch when the pass ran on S * dlogits)."""
+        slab = self.slab
+        if self.grad_scale != 1.0:
+            slab.gflat = T.eltwise(slab.gflat, T.MODE_SCALE, p_drop=1.0 / self.grad_scale)
+        return {n: slab.grad(n) for n in slab.names}
 
 
 class _FusionTrainFn(torch.autograd.Function):
     """One autograd node around NlvrTrainer.forward / backward: `loss.backward()` of the reference's training step reaches
-    the hand-written reverse pass through it.  `anchor` is a trainable parameter (it makes the node differentiable); every
-    other parameter's gradient is accumulated into `.grad` directly, as autograd's AccumulateGrad would."""
+    the hand-written reverse pass through it.  `anchor` is a one-element leaf that only makes the node differentiable; the
+    parameters' gradients are accumulated into `.grad` directly, as autograd's AccumulateGrad would (a first gradient is the
+    trainer's own slice of its flat gradient buffer - no copy; later ones are added)."""
 
     @staticmethod
     def forward(ctx, anchor, trainer, z_t, feats, ids, mask):
@@ -399,43 +425,75 @@ class _FusionTrainFn(torch.autograd.Function):
     def backward(ctx, dlogits):
         tr = ctx.trainer
         grads = tr.backward(dlogits.contiguous().float())
-        anchor_grad = None
         for name, p in tr.model.named_parameters():
-            if name not in grads:
-                continue
-            gq = grads[name].view_as(p)
-            if name == tr.anchor_name:
-                anchor_grad = gq
-            else:
-                p.grad = gq if p.grad is None else T.eltwise(p.grad.contiguous(), T.MODE_ADD, gq.contiguous())   # (gq is this step's own buffer)
-        return anchor_grad, None, None, None, None, None
+            if name in grads and p.requires_grad:
+                gq = grads[name]
+                p.grad = gq if p.grad is None else T.eltwise(p.grad.contiguous(), T.MODE_ADD, gq.contiguous())
+        return None, None, None, None, None, None
 
 
 def fusion_train(model, z_t, feats, ids, mask, p_hidden: float = 0.1, p_attn: float = 0.1, seed: int = 0) -> torch.Tensor:
     """(B, B) logits of `img_txt_fusion` in training mode, differentiable w.r.t. the model's text_encoder / cls_head parameters."""
     tr = getattr(model, "_trainer", None)
-    if tr is None or (tr.p_hidden, tr.p_attn) != (float(p_hidden), float(p_attn)):
+    if tr is None or (tr.p_hidden, tr.p_attn) != (float(p_hidden), float(p_attn)) or tr.dtype != model.compute_dtype:
         tr = model._trainer = NlvrTrainer(model, p_hidden, p_attn, seed)
-    tr.anchor_name = "cls_head.2.bias"
-    anchor = dict(model.named_parameters())[tr.anchor_name]
-    return _FusionTrainFn.apply(anchor, tr, z_t, feats, ids, mask)
+        tr.anchor = torch.zeros((1,), device=z_t.device, requires_grad=True)
+    return _FusionTrainFn.apply(tr.anchor, tr, z_t, feats, ids, mask)
 
 
 class AdamW:
-    """torch.optim.AdamW's update rule on cir_adamw_step (stage2_train.py:138 builds that optimizer), fp32 master parameters."""
+    """torch.optim.AdamW's update rule on cir_adamw_step (stage2_train.py:138 builds that optimizer), fp32 master parameters.
+    When the parameters and their gradients are the trainer's flat buffers (the normal case after `fusion_train`), one launch
+    updates all of them; otherwise one launch per tensor."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         self.params = [p for p in params if p.requires_grad]
         self.lr, self.betas, self.eps, self.wd, self.t = lr, betas, eps, weight_decay, 0
-        self.m = [torch.zeros_like(p, dtype=torch.float32) for p in self.params]
-        self.v = [torch.zeros_like(p, dtype=torch.float32) for p in self.params]
+        self.m: Dict[int, torch.Tensor] = {}
+        self.v: Dict[int, torch.Tensor] = {}
+        self._flat = None                                     # (param storage ptr, m flat, v flat)
+
+    @staticmethod
+    def _flat_range(tensors):
+        """(base pointer, elements) when `tensors` tile ONE storage completely in slices padded to 8 elements, else None."""
+        st = tensors[0].untyped_storage()
+        if any(t.untyped_storage().data_ptr() != st.data_ptr() or not t.is_contiguous() for t in tensors):
+            return None
+        if sum((t.numel() + 7) // 8 * 8 for t in tensors) * 4 != st.nbytes():
+            return None
+        return st.data_ptr(), st.nbytes() // 4
 
     @torch.no_grad()
     def step(self):
         self.t += 1
-        for p, m, v in zip(self.params, self.m, self.v):
-            if p.grad is not None:
-                T.adamw_step(p.data, p.grad.contiguous(), m, v, self.lr, self.betas, self.eps, self.wd, self.t)
+        ps = [p for p in self.params if p.grad is not None]
+        if not ps:
+            return
+        fp, fg = self._flat_range([p.data for p in ps]), self._flat_range([p.grad for p in ps])
+        if fp is not None and fg is not None and fp[1] == fg[1] and all(p.data_ptr() - fp[0] == p.grad.data_ptr() - fg[0] for p in ps):
+            n = fp[1]
+            if self._flat is None or self._flat[0] != fp[0]:
+                mf, vf = (torch.zeros((n,), dtype=torch.float32, device=ps[0].device) for _ in range(2))
+                for p in ps:                                  # carry over moments from per-tensor steps, then keep views
+                    o = (p.data_ptr() - fp[0]) // 4
+                    for store, flat in ((self.m, mf), (self.v, vf)):
+                        view = flat[o:o + p.numel()].view(p.shape)
+                        if id(p) in store:
+                            view.copy_(store[id(p)])
+                        store[id(p)] = view
+                self._flat = (fp[0], mf, vf)
+            base = ps[0].data.untyped_storage()
+            pflat = torch.empty(0, dtype=torch.float32, device=ps[0].device).set_(base, 0, (n,))
+            gflat = torch.empty(0, dtype=torch.float32, device=ps[0].device).set_(ps[0].grad.untyped_storage(), 0, (n,))
+            T.adamw_step(pflat, gflat, self._flat[1], self._flat[2], self.lr, self.betas, self.eps, self.wd, self.t)
+            return
+        for p in ps:
+            if id(p) not in self.m:
+                self.m[id(p)], self.v[id(p)] = torch.zeros_like(p, dtype=torch.float32), torch.zeros_like(p, dtype=torch.float32)
+            m, v = self.m[id(p)], self.v[id(p)]
+            if not (m.is_contiguous() and v.is_contiguous()):
+                m, v = self.m[id(p)], self.v[id(p)] = m.contiguous(), v.contiguous()
+            T.adamw_step(p.data, p.grad.contiguous(), m, v, self.lr, self.betas, self.eps, self.wd, self.t)
 
     def zero_grad(self):
         for p in self.params:
