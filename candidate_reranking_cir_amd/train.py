@@ -434,6 +434,9 @@ class _FusionTrainFn(torch.autograd.Function):
 
 def fusion_train(model, z_t, feats, ids, mask, p_hidden: float = 0.1, p_attn: float = 0.1, seed: int = 0) -> torch.Tensor:
     """(B, B) logits of `img_txt_fusion` in training mode, differentiable w.r.t. the model's text_encoder / cls_head parameters."""
+    if (torch.is_tensor(feats) and feats.requires_grad) or (torch.is_tensor(z_t) and z_t.requires_grad):
+        raise NotImplementedError("the image tokens / z_t require a gradient (blip_img_tune, stage2_train.py:183-199): the backward pass stops at "
+                                  "the two-branch encoder's inputs - compute them under torch.no_grad() as the reference's default does")
     tr = getattr(model, "_trainer", None)
     if tr is None or (tr.p_hidden, tr.p_attn) != (float(p_hidden), float(p_attn)) or tr.dtype != model.compute_dtype:
         tr = model._trainer = NlvrTrainer(model, p_hidden, p_attn, seed)

@@ -285,3 +285,19 @@ def test_flat_adamw_matches_torch_adamw(cuda):
     print(f"\n[adamw vs torch, 3 steps] largest update {moved:.3e}; flat path max diff {e_flat:.3e}, per-tensor path {e_each:.3e}")
     assert moved > 2e-3 and e_flat < 2e-6 and e_each < 2e-6
     m.eval()
+
+
+def test_inputs_requiring_grad_are_refused(cuda):
+    """blip_img_tune (a gradient into the ViT / stage I) is not built: asking for it fails loudly instead of returning no gradient."""
+    zf, g, v, _, _ = H.tiny_setup()
+    m = build(g, v, int(zf["seed"]), str(zf["profile"]), BF)[0]
+    m.train()
+    caps = [synthetic.caption_text(90, 4), synthetic.caption_text(91, 6)]
+    l = H.tokenize(caps)[0].shape[1]
+    z_t = torch.randn((2, l, g.hidden_size), device=cuda)
+    feats = torch.randn((2, 17, g.encoder_width), device=cuda, requires_grad=True)
+    with pytest.raises(NotImplementedError, match="blip_img_tune"):
+        m.img_txt_fusion(z_t, feats, caps)
+    with torch.no_grad():                                       # no graph asked for: the inference path, whatever the mode
+        assert m.img_txt_fusion(z_t, feats, caps).shape == (2, 2)
+    m.eval()
