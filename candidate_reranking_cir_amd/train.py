@@ -93,18 +93,34 @@ class _Slab:
     def w16(self, n): return self._view(self.flat16, n)
     def grad(self, n): return self._view(self.gflat, n)
 
+    def span(self, flat: torch.Tensor, names: List[str]) -> torch.Tensor:
+        """The slices of `names` as ONE tensor stacked along dim 0 (they must be adjacent in the buffer: `NlvrTrainer._order` lays
+        the q / k / v weights - and biases - of one attention out that way, so the three projections are one 2304-wide Linear)."""
+        o = self.off[names[0]]
+        rows = 0
+        for n in names:
+            assert self.off[n] == o + rows * (self.params[n].numel() // self.params[n].shape[0]), "group not adjacent in the slab"
+            rows += self.params[n].shape[0]
+        tail = tuple(self.params[names[0]].shape[1:])
+        numel = rows
+        for t in tail:
+            numel *= t
+        return flat[o:o + numel].view((rows,) + tail)
+
 
 class _Lin:
     """One nn.Linear of the reference (weight (N, K), bias (N)): views of the slab's 16-bit weights / fp32 bias / gradient slices,
     plus the transposed 16-bit weight copy the dgrad GEMM reads, made per step."""
 
-    def __init__(self, slab: _Slab, name: str):
-        has_bias = (name + ".bias") in slab.off
-        self.w16 = slab.w16(name + ".weight")                                       # (N, K): forward operand
+    def __init__(self, slab: _Slab, name, group: bool = False):
+        names = list(name) if group else [name]                                     # a group: several Linears of one input, stacked
+        has_bias = (names[0] + ".bias") in slab.off
+        ws, bs = [n + ".weight" for n in names], [n + ".bias" for n in names]
+        self.w16 = slab.span(slab.flat16, ws)                                       # (N, K): forward operand
         self.w16t = T.transpose16(self.w16)                                         # (K, N): dgrad operand
-        self.bias = slab.w32(name + ".bias") if has_bias else None
-        self.dw = slab.grad(name + ".weight")
-        self.db = slab.grad(name + ".bias") if has_bias else None
+        self.bias = slab.span(slab.flat32, bs) if has_bias else None
+        self.dw = slab.span(slab.gflat, ws)
+        self.db = slab.span(slab.gflat, bs) if has_bias else None
 
     def fwd(self, x16: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
         m, k = x16.shape
@@ -172,14 +188,37 @@ class NlvrTrainer:
         return name.startswith(("text_encoder.encoder.layer.", "cls_head.")) or name in (
             e + "word_embeddings.weight", e + "position_embeddings.weight", e + "LayerNorm.weight", e + "LayerNorm.bias")
 
+    @staticmethod
+    def _order(names: List[str]) -> List[str]:
+        """Slab order: the weights of an attention's q, k, v (cross-attention: k, v) adjacent, then their biases - what `_Slab.span`
+        stacks into one Linear - and everything else in the model's own order."""
+        out, seen = [], set()
+        for n in names:
+            if n in seen:
+                continue
+            if n.endswith(".query.weight") and ".attention.self" in n:
+                stem = n[:-len("query.weight")]
+                grp = [stem + f"{x}.{y}" for y in ("weight", "bias") for x in ("query", "key", "value")]
+            elif n.endswith(".key.weight") and ".crossattention.self" in n:
+                stem = n[:-len("key.weight")]
+                grp = [stem + f"{x}.{y}" for y in ("weight", "bias") for x in ("key", "value")]
+            else:
+                grp = [n]
+            for m in grp:
+                if m not in seen:
+                    out.append(m); seen.add(m)
+        assert sorted(out) == sorted(names)
+        return out
+
     def _pack(self):
         P = dict(self.model.named_parameters())
         slab = getattr(self, "slab", None)
         if slab is None or slab.dtype != self.dtype or not slab.valid():           # first step, or the model was moved / re-cast
-            slab = self.slab = _Slab(P, [n for n in P if self._trained(n)], self.dtype)
+            slab = self.slab = _Slab(P, self._order([n for n in P if self._trained(n)]), self.dtype)
         slab.begin_step()
         g = self.geo
         lin = lambda name: _Lin(slab, name)
+        grp = lambda names: _Lin(slab, names, group=True)
         ln = lambda name: _LN(slab, name, g.layer_norm_eps)
         e = self._EMB
         self.word, self.pos = slab.w32(e + "word_embeddings.weight"), slab.w32(e + "position_embeddings.weight")
@@ -190,9 +229,10 @@ class NlvrTrainer:
             p = f"text_encoder.encoder.layer.{i}."
             ly = {}
             for b in (0, 1):
-                ly[f"q{b}"], ly[f"k{b}"], ly[f"v{b}"] = (lin(p + f"attention.self{b}.{n}") for n in ("query", "key", "value"))
+                ly[f"qkv{b}"] = grp([p + f"attention.self{b}.{n}" for n in ("query", "key", "value")])     # one 2304-wide Linear
                 ly[f"o{b}"] = lin(p + f"attention.output.dense{b}")
-                ly[f"cq{b}"], ly[f"ck{b}"], ly[f"cv{b}"] = (lin(p + f"crossattention.self{b}.{n}") for n in ("query", "key", "value"))
+                ly[f"cq{b}"] = lin(p + f"crossattention.self{b}.query")
+                ly[f"ckv{b}"] = grp([p + f"crossattention.self{b}.{n}" for n in ("key", "value")])           # one 1536-wide Linear
                 ly[f"d{b}"] = lin(p + f"crossattention.output.dense{b}")
             for c, b in (("A", 0), ("B", 1)):
                 ly[f"ln1{b}"] = ln(p + f"attention.output.LayerNorm{c}")
@@ -213,42 +253,39 @@ class NlvrTrainer:
         return x if self.p_hidden <= 0 else T.eltwise(x, T.MODE_DROPOUT, p_drop=self.p_hidden, seed=site)
 
     # ------------------------------------------------------------------------------------------------ attention
-    def _heads(self, x: torch.Tensor, nb1: int, rows: int) -> torch.Tensor:
-        """(nb1 * rows, D) projection -> (nb1, H, rows, head_dim) view of its head slices (no copy)."""
-        return x.view(nb1, rows, self.geo.num_attention_heads, self._hd).permute(0, 2, 1, 3)
+    def _heads(self, x: torch.Tensor, nb1: int, rows: int, part: int = 0, parts: int = 1) -> torch.Tensor:
+        """(nb1 * rows, parts * D) projection(s) -> (nb1, H, rows, head_dim) view of the head slices of projection `part` (no copy)."""
+        return x.view(nb1, rows, parts, self.geo.num_attention_heads, self._hd)[:, :, part].permute(0, 2, 1, 3)
 
-    def _attn_fwd(self, q16, k16, v16, nb1, mq, mk, mask, site):
-        """nb1 groups of mq query rows and mk key rows each: q16 (nb1*mq, D), k16 / v16 (nb1*mk, D); mask (groups, mk) additive fp32,
-        one row per mq * H score rows, or None.  Self-attention: a group is a triplet; cross-attention: a group is a CANDIDATE with
-        the B queries scored against it stacked in mq = B * L rows - its keys / values exist once."""
-        h_n, d = self.geo.num_attention_heads, self.geo.hidden_size
+    def _attn_fwd(self, q4, k4, v4, mask, site):
+        """q4 (G, H, mq, hd), k4 / v4 (G, H, mk, hd) head views of 16-bit projections: G groups of mq query rows and mk key rows;
+        mask (groups, mk) additive fp32, one row per mq * H score rows, or None.  Self-attention: a group is a triplet;
+        cross-attention: a group is a CANDIDATE with the B queries scored against it stacked in mq = B * L rows - its keys /
+        values exist once."""
+        nb1, h_n, mq, _ = q4.shape
+        mk, d = k4.shape[2], self.geo.hidden_size
         ld = (mk + 7) // 8 * 8                                                       # padded score rows: 16-byte loads in cir_bmm
-        s = torch.empty((nb1, h_n, mq, ld), dtype=torch.float32, device=q16.device)
-        T.bmm(self._heads(q16, nb1, mq), self._heads(k16, nb1, mk), False, True, out=s[..., :mk])
-        p, pd = T.softmax_dropout(s.view(-1, ld), mask, h_n * mq, self._scale, self.p_attn, site, q16.dtype, cols=mk)
-        ctx = torch.empty((nb1 * mq, d), dtype=q16.dtype, device=q16.device)
-        T.bmm(pd.view(nb1, h_n, mq, ld)[..., :mk], self._heads(v16, nb1, mk), False, False, out=self._heads(ctx, nb1, mq))
+        s = torch.empty((nb1, h_n, mq, ld), dtype=torch.float32, device=q4.device)
+        T.bmm(q4, k4, False, True, out=s[..., :mk])
+        p, pd = T.softmax_dropout(s.view(-1, ld), mask, h_n * mq, self._scale, self.p_attn, site, q4.dtype, cols=mk)
+        ctx = torch.empty((nb1 * mq, d), dtype=q4.dtype, device=q4.device)
+        T.bmm(pd.view(nb1, h_n, mq, ld)[..., :mk], v4, False, False, out=self._heads(ctx, nb1, mq))
         return ctx, (p, pd, site)
 
-    def _attn_bwd(self, dctx, q16, k16, v16, nb1, mq, mk, saved):
-        """dctx fp32 (nb1*mq, D) -> (dq (nb1*mq, D), dk (nb1*mk, D), dv (nb1*mk, D)) fp32."""
+    def _attn_bwd(self, dctx, q4, k4, v4, saved, dq4, dk4, dv4):
+        """dctx fp32 (G*mq, D) -> dq4 / dk4 / dv4: fp32 head views the gradients are written into (slices of the buffer the fused
+        projection's backward reads)."""
         p, pd, site = saved
-        h_n, d = self.geo.num_attention_heads, self.geo.hidden_size
-        ld = p.shape[1]
-        dev = dctx.device
-        dc = self._heads(_cast(dctx, q16.dtype), nb1, mq)
-        q4, k4, v4 = self._heads(q16, nb1, mq), self._heads(k16, nb1, mk), self._heads(v16, nb1, mk)
+        nb1, h_n, mq, _ = q4.shape
+        mk, ld = k4.shape[2], p.shape[1]
+        dc = self._heads(_cast(dctx, q4.dtype), nb1, mq)
         pd4 = pd.view(nb1, h_n, mq, ld)[..., :mk]
-        dpd = torch.empty((nb1, h_n, mq, ld), dtype=torch.float32, device=dev)
-        dq = torch.empty((nb1 * mq, d), dtype=torch.float32, device=dev)
-        dk = torch.empty((nb1 * mk, d), dtype=torch.float32, device=dev)
-        dv = torch.empty((nb1 * mk, d), dtype=torch.float32, device=dev)
+        dpd = torch.empty((nb1, h_n, mq, ld), dtype=torch.float32, device=dctx.device)
         T.bmm(dc, v4, False, True, out=dpd[..., :mk])                                # dPd = dctx . V^T
-        T.bmm(pd4, dc, True, False, out=self._heads(dv, nb1, mk))                    # dV  = Pd^T . dctx
+        T.bmm(pd4, dc, True, False, out=dv4)                                         # dV  = Pd^T . dctx
         ds = T.softmax_dropout_bwd(p, dpd.view(-1, ld), self._scale, self.p_attn, site, cols=mk).view(nb1, h_n, mq, ld)[..., :mk]
-        T.bmm(ds, k4, False, False, out=self._heads(dq, nb1, mq))                    # dQ = dS . K
-        T.bmm(ds, q4, True, False, out=self._heads(dk, nb1, mk))                     # dK = dS^T . Q
-        return dq, dk, dv
+        T.bmm(ds, k4, False, False, out=dq4)                                         # dQ = dS . K
+        T.bmm(ds, q4, True, False, out=dk4)                                          # dK = dS^T . Q
 
     # ------------------------------------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -282,22 +319,23 @@ class NlvrTrainer:
         smask = ((1.0 - attention_mask.to(dev).float()) * -10000.0)[qi].contiguous()                      # (T, L), nlvr_encoder.py:773-774
         sv["layers"] = []
         for i, ly in enumerate(self.layers):
-            s = {"h16": h16, "q": [], "k": [], "v": [], "sa": [], "ctx": [], "pre1": [], "a16": [], "cq": [], "ck": [], "cv": [], "ca": [],
+            s = {"h16": h16, "qkv": [], "sa": [], "ctx": [], "pre1": [], "a16": [], "cq": [], "ckv": [], "ca": [],
                  "c": [], "pre2": [], "x16": [], "z": [], "f16": [], "pre3": []}
             a32, dd = [], []
             for b in (0, 1):
-                q, k, v = (ly[f"{nm}{b}"].fwd(h16[b], dt) for nm in ("q", "k", "v"))
-                ctx, sa = self._attn_fwd(q, k, v, t_n, l, l, smask, self._site(i, b, 1))
+                qkv = ly[f"qkv{b}"].fwd(h16[b], dt)                                   # (R, 3D)
+                ctx, sa = self._attn_fwd(*(self._heads(qkv, t_n, l, j, 3) for j in range(3)), smask, self._site(i, b, 1))
                 t = self._drop(ly[f"o{b}"].fwd(ctx, torch.float32), self._site(i, b, 2))
                 pre1 = T.eltwise(t, T.MODE_ADD, h32[b])
                 a, a16 = ly[f"ln1{b}"].fwd(pre1, dt)
                 cq = ly[f"cq{b}"].fwd(a16, dt)
-                ck, cv = ly[f"ck{b}"].fwd(cand16, dt), ly[f"cv{b}"].fwd(cand16, dt)
-                c, ca = self._attn_fwd(cq, ck, cv, b_n, b_n * l, n, None, self._site(i, b, 3))
+                ckv = ly[f"ckv{b}"].fwd(cand16, dt)                                   # (B*N, 2D): each target's keys | values, once
+                c, ca = self._attn_fwd(self._heads(cq, b_n, b_n * l), self._heads(ckv, b_n, n, 0, 2), self._heads(ckv, b_n, n, 1, 2), None,
+                                       self._site(i, b, 3))
                 dd.append(ly[f"d{b}"].fwd(c, torch.float32))
                 a32.append(a)
-                for key, val in (("q", q), ("k", k), ("v", v), ("sa", sa), ("ctx", ctx), ("pre1", pre1), ("a16", a16), ("cq", cq), ("ck", ck),
-                                 ("cv", cv), ("ca", ca), ("c", c)):
+                for key, val in (("qkv", qkv), ("sa", sa), ("ctx", ctx), ("pre1", pre1), ("a16", a16), ("cq", cq), ("ckv", ckv), ("ca", ca),
+                                 ("c", c)):
                     s[key].append(val)
             if ly["merge"] is None:                                                 # layers < 6: average (nlvr_encoder.py:257-260)
                 m = T.eltwise(T.eltwise(dd[0], T.MODE_ADD, dd[1]), T.MODE_SCALE, p_drop=0.5)
@@ -383,17 +421,22 @@ class NlvrTrainer:
             dh_in = []
             for b in (0, 1):
                 dc = ly[f"d{b}"].bwd(s["c"][b], dd[b])
-                dcq, dck, dcv = self._attn_bwd(dc, s["cq"][b], s["ck"][b], s["cv"][b], sv["b_n"], sv["b_n"] * l, n, s["ca"][b])
-                ly[f"ck{b}"].bwd(sv["cand16"], dck, need_dx=False)                  # image tokens are inputs: no gradient beyond the weights
-                ly[f"cv{b}"].bwd(sv["cand16"], dcv, need_dx=False)
+                b_n = sv["b_n"]
+                cq, ckv = s["cq"][b], s["ckv"][b]
+                dcq = torch.empty((r, d), dtype=torch.float32, device=dev)
+                dckv = torch.empty((b_n * n, 2 * d), dtype=torch.float32, device=dev)
+                self._attn_bwd(dc, self._heads(cq, b_n, b_n * l), self._heads(ckv, b_n, n, 0, 2), self._heads(ckv, b_n, n, 1, 2), s["ca"][b],
+                               self._heads(dcq, b_n, b_n * l), self._heads(dckv, b_n, n, 0, 2), self._heads(dckv, b_n, n, 1, 2))
+                ly[f"ckv{b}"].bwd(sv["cand16"], dckv, need_dx=False)                # image tokens are inputs: no gradient beyond the weights
                 da = add(ly[f"cq{b}"].bwd(s["a16"][b], dcq), dpre2[b])
                 dpre1 = ly[f"ln1{b}"].bwd(s["pre1"][b], da)
                 dt_ = undrop(dpre1, self._site(i, b, 2))
                 dctx = ly[f"o{b}"].bwd(s["ctx"][b], dt_)
-                dq, dk, dv = self._attn_bwd(dctx, s["q"][b], s["k"][b], s["v"][b], t_n, l, l, s["sa"][b])
-                dhb = dpre1
-                for nm, gr in (("q", dq), ("k", dk), ("v", dv)):
-                    dhb = add(dhb, ly[f"{nm}{b}"].bwd(s["h16"][b], gr))
+                qkv = s["qkv"][b]
+                dqkv = torch.empty((r, 3 * d), dtype=torch.float32, device=dev)
+                self._attn_bwd(dctx, *(self._heads(qkv, t_n, l, j, 3) for j in range(3)), s["sa"][b],
+                               *(self._heads(dqkv, t_n, l, j, 3) for j in range(3)))
+                dhb = add(dpre1, ly[f"qkv{b}"].bwd(s["h16"][b], dqkv))
                 dh_in.append(dhb)
             dh = dh_in
         # branch 1 entered through BertEmbeddings; branch 0 is z_t (frozen stage I)
