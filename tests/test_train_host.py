@@ -1,0 +1,60 @@
+"""Host-side logic of the training step that needs no GPU: slab ordering (stacked q|k|v projections), the row-chunk choice of
+the weight gradients, flat-buffer detection of train.AdamW, bench.py's flop model."""
+import torch
+
+from candidate_reranking_cir_amd import config, weights
+from candidate_reranking_cir_amd.train import AdamW, NlvrTrainer, _row_split
+
+
+def _trained_names():
+    g, v = config.BertGeometry(), config.VitGeometry(image_size=64, depth=1)
+    names = list(weights.nlvr_param_spec(g, v))
+    tr = NlvrTrainer.__new__(NlvrTrainer)
+    return [n for n in names if tr._trained(n)], weights.nlvr_param_spec(g, v)
+
+
+def test_trained_set_and_slab_order():
+    names, spec = _trained_names()
+    assert len(names) == 572                                     # the parameters the reference's step gives a gradient (train768.npz)
+    assert not any("token_type" in n or "pooler" in n or n.startswith("visual_encoder.") for n in names)
+    order = NlvrTrainer._order(names)
+    assert sorted(order) == sorted(names) and len(set(order)) == len(order)
+    pos = {n: i for i, n in enumerate(order)}
+    for layer in (0, 6, 11):
+        for b in (0, 1):
+            s = f"text_encoder.encoder.layer.{layer}.attention.self{b}."
+            i = pos[s + "query.weight"]
+            assert [order[i + j] for j in range(6)] == [s + f"{x}.{y}" for y in ("weight", "bias") for x in ("query", "key", "value")]
+            c = f"text_encoder.encoder.layer.{layer}.crossattention.self{b}."
+            i = pos[c + "key.weight"]
+            assert [order[i + j] for j in range(4)] == [c + f"{x}.{y}" for y in ("weight", "bias") for x in ("key", "value")]
+    # every slice of a stacked group is a multiple of 8 elements: adjacency survives the slab's 8-element padding
+    assert all(torch.Size(spec[n][0]).numel() % 8 == 0 for n in order if ".self" in n)
+
+
+def test_row_split():
+    assert _row_split(8192, 768, 768) == 16 and _row_split(9232, 768, 768) == 16          # 36 tiles x 16 chunks
+    assert _row_split(8192, 3072, 768) == 8 and _row_split(8192, 2304, 768) == 8           # FFN / stacked q|k|v
+    assert _row_split(176, 768, 768) == 1 and _row_split(16, 2, 768) == 1                   # too few rows to split
+    for rows in (275, 1000, 8191, 12288):
+        nb = _row_split(rows, 768, 768)
+        assert rows % nb == 0 and (nb == 1 or rows // nb >= 128)
+
+
+def test_adamw_flat_detection():
+    flat = torch.zeros(8 * 5)
+    a, b = flat[0:12].view(3, 4), flat[16:40].view(24)                                       # 12 -> padded 16, 24 -> 24: tiles the storage
+    assert AdamW._flat_range([a, b]) == (flat.untyped_storage().data_ptr(), 40)
+    assert AdamW._flat_range([a, torch.zeros(24)]) is None                                   # different storages
+    assert AdamW._flat_range([a]) is None                                                     # does not cover the storage
+    assert AdamW._flat_range([a, flat[16:40].view(4, 6).t()]) is None                        # not contiguous
+
+
+def test_train_flop_model():
+    import bench
+    b, l, n, d = 2, 8, 17, 768
+    fwd, bwd = bench.train_gflop(b, l, n)
+    r = b * b * l
+    per_branch = 6 * 2 * r * d * d + 16 * r * d * d + 4 * r * l * d + 4 * r * n * d + 4 * (b * n) * d * d
+    want = 12 * 2 * per_branch + 6 * 4 * r * d * d + 2 * b * b * (2 * d * d + 2 * d)
+    assert abs(fwd * 1e9 - want) < 1e-6 * want and 1.8 * fwd < bwd < 2.0 * fwd
