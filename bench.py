@@ -446,6 +446,39 @@ def train_mode(args, m2, m1, dev, dt):
         "cpu_baseline": cpu}), flush=True)
 
 
+def launch_ranks(n: int) -> int:
+    """Start one child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment, rendezvous on 127.0.0.1)
+    running this same command line, let them write to this process's stdout / stderr (rank 0 alone prints the JSON line) and
+    return the first non-zero exit code (0 if every rank succeeded).  The launcher itself makes no GPU call."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, failed_at = 0, None
+    while any(p.poll() is None for p in procs):
+        for p in procs:
+            if p.poll() not in (None, 0) and rc == 0:
+                rc, failed_at = p.returncode, time.time()
+        if failed_at is not None and time.time() - failed_at > 20.0:      # a rank died: its peers would wait in a collective forever
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()                                         # exactly the PIDs started above
+            failed_at = time.time() + 1e9
+        time.sleep(0.2)
+    for p in procs:
+        if p.returncode != 0 and rc == 0:
+            rc = p.returncode
+    if rc != 0:
+        print(f"bench.py launcher: a rank exited with code {rc}", file=sys.stderr)
+    return rc if rc > 0 else (1 if rc else 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -473,12 +506,15 @@ def main():
     ap.add_argument("--index-size", type=int, default=2297, help="bank mode: number of index images (CIRR val: 2297)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It has not touched the GPU (no HIP
+        # call precedes this line) and never does; it starts one CHILD per GPU and relays rank 0's line - nothing is exec'ed.
+        raise SystemExit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one process per GPU (drop the launcher and `--gpus N` starts its own ranks)")
     # (dry-run knobs for a box with ONE GPU: CIR_BENCH_DEVICE pins every rank to that device and CIR_BENCH_BACKEND=gloo
     #  replaces RCCL, which refuses two ranks on one device - exercises the launch / gather / timing logic only)
     dev_index = int(os.environ.get("CIR_BENCH_DEVICE", local_rank))

@@ -27,3 +27,26 @@ def test_usable_cpus_is_positive_and_bounded():
     b = _bench()
     n = b.usable_cpus()
     assert 1 <= n <= (os.cpu_count() or 1)
+
+
+def test_launcher_starts_one_child_per_rank_and_relays_failure(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE becomes a launcher (bench.launch_ranks): N children with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR=127.0.0.1 / one shared MASTER_PORT, the same argument vector, exit code = a failed rank's."""
+    import sys
+    b = _bench()
+    script = tmp_path / "child.py"
+    script.write_text(
+        "import os, sys\n"
+        "r = os.environ['RANK']\n"
+        "open(os.path.join(os.path.dirname(__file__), 'rank' + r), 'w').write(' '.join([os.environ[k] for k in "
+        "('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')] + sys.argv[1:]))\n"
+        "sys.exit(int(os.environ.get('FAIL_RANK', '-1')) == int(r) and 7 or 0)\n")
+    monkeypatch.setattr(b, "__file__", str(script))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3", "--steps", "1"])
+    assert b.launch_ranks(3) == 0
+    got = [(tmp_path / f"rank{r}").read_text().split() for r in range(3)]
+    assert [g[0] for g in got] == ["0", "1", "2"] and [g[1] for g in got] == ["0", "1", "2"]
+    assert all(g[2] == "3" and g[3] == "127.0.0.1" and g[5:] == ["--gpus", "3", "--steps", "1"] for g in got)
+    assert len({g[4] for g in got}) == 1 and int(got[0][4]) > 0
+    monkeypatch.setenv("FAIL_RANK", "1")
+    assert b.launch_ranks(3) == 7

@@ -37,13 +37,22 @@ def test_single_rank_contract_line():
     assert d["executed_gflop_per_triplet"] > 0 and d["device"]["compute_units"] == 256
 
 
-def test_two_rank_dry_run_on_one_gpu():
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_two_rank_dry_run_on_one_gpu(launcher):
+    """Both launch forms: `python bench.py --gpus 2` (bench.py starts its own two ranks as child processes before any GPU
+    call) and the driver's `python -m torch.distributed.run ... bench.py --gpus 2`."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     env = dict(os.environ, CIR_BENCH_BACKEND="gloo", CIR_BENCH_DEVICE="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--queries", "3", "--skip-rate", "0.34"]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--queries", "3", "--skip-rate", "0.34",
+            "--no-precision-table"]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29533"] + tail
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _last_json(r.stdout)
@@ -52,6 +61,8 @@ def test_two_rank_dry_run_on_one_gpu():
     # 6 queries, skip rate 0.34: skipped queries score only their 5 subset members, and only scored pairs count
     assert d["config"]["triplets_per_step_rank0"] in (5 + 2 * 105, 2 * 5 + 105, 3 * 105, 15)
     assert r.stdout.count('{"metric"') == 1          # rank 0 alone prints the line
+    c = d["collective"]
+    assert c["ranks"] == 2 and c["own_block_bit_identical"] and c["checksum_equal_on_all_ranks"] and len(c["per_rank_triplets_per_step"]) == 2
 
 
 def test_bank_mode_line():
