@@ -18,6 +18,7 @@ from typing import Optional, Sequence, Union
 import torch
 from torch import nn
 
+from . import lib as _lib
 from . import ops
 from .config import BertGeometry, VitGeometry
 from .engine import NlvrEngine, VitEngine
@@ -76,6 +77,7 @@ class _EngineHost(nn.Module):
     def __init__(self):
         super().__init__()
         self._engines = None
+        self._packed_epoch = 0
         self._text_stale = False               # set by a training step (train.py): text_encoder / cls_head changed, the ViT did not
         self.compute_dtype = torch.bfloat16
         self._stream_dtype = None              # None = automatic (see `stream_dtype`)
@@ -142,10 +144,14 @@ class BLIP_NLVR(_EngineHost):
             self._engines = (VitEngine(sd, self.vit_geometry, self.compute_dtype, dev, stream_dtype=self.stream_dtype),
                              NlvrEngine(sd, self.bert_geometry, self.compute_dtype, dev, fold_merge=self.fold_merge, stream_dtype=self.stream_dtype))
             self._text_stale = False
-        elif self._text_stale and text:        # after training steps: repack the two-branch encoder only (the ViT is frozen there),
+            self._packed_epoch = _lib.PARAM_EPOCH[0]
+        elif text and (self._text_stale or (getattr(self, "_trainer", None) is not None and self._packed_epoch != _lib.PARAM_EPOCH[0])):
+            # after training steps (the forward marks it; every cir_adamw_step launch moves lib.PARAM_EPOCH, so an eval call made
+            # between backward() and step() cannot leave the engine on the pre-step weights): repack the two-branch encoder only (the ViT is frozen there),
             self._engines = (self._engines[0], NlvrEngine(self.state_dict(), self.bert_geometry, self.compute_dtype, self.device,
                                                           fold_merge=self.fold_merge, stream_dtype=self.stream_dtype))
             self._text_stale = False           # and only when a caller needs it (`text`): img_embed between steps does not
+            self._packed_epoch = _lib.PARAM_EPOCH[0]
         return self._engines
 
     @torch.no_grad()

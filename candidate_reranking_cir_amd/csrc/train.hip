@@ -1,6 +1,6 @@
 // Training-mode operators of the two-branch encoder (BLIP_NLVR.img_txt_fusion in train() mode + backward,
 // blip_stage2.py:65-99 driven by stage2_train.py:202-216).  The dense Linear layers keep running on the MFMA GEMM
-// (cir_gemm_bias_act: dgrad through a transposed weight copy, wgrad through transposed activation copies); this file holds
+// (cir_gemm_bias_act: forward and dgrad, the latter through a transposed weight copy; wgrad is cir_bmm reading dy and x as stored); this file holds
 // what the training pass needs besides: 16-bit transposes, a batched matmul on the matrix cores for products of any extents and
 // storage orders (weight gradients dy^T x read as stored; the un-fused attention and its four adjoints per (candidate or
 // triplet, head)), row softmax with additive mask and counter-based dropout (+ backward), LayerNorm backward, GELU / ReLU

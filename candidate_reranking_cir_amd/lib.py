@@ -56,6 +56,7 @@ SIGNATURES = {
 }
 
 _lib = None
+PARAM_EPOCH = [0]     # moved by every cir_adamw_step launch (train_ops.adamw_step): packed inference engines of a trained model compare it
 
 
 class CirrankError(RuntimeError):

@@ -17,7 +17,8 @@ cross-attention keys / values of a target image are projected once per step and 
 the dK / dV products.
 Precision: 16-bit MFMA operands (activations, weights, and the gradients fed to the GEMMs), fp32 accumulation, fp32 residual
 stream, fp32 LayerNorm inputs, fp32 weight gradients - the forward plan of DESIGN.md section 2 with an fp32 stream.
-Dropout is counter-based (seed per site); with p = 0 the pass is deterministic and is what the reference-gradient fixture pins.
+Dropout is counter-based (seed per site); with p = 0 the pass has no random state - reproducible up to the order of the fp32 atomic adds in
+the column sums / LayerNorm and embedding adjoints - and is what the reference-gradient fixture pins.
 
 `fusion_train(model, ...)` wraps the pair as ONE `torch.autograd.Function`, so the reference's training step runs unchanged:
 `logits = model.img_txt_fusion(z_t, feats, captions)` in `.train()` mode, `loss = F.cross_entropy(logits, gt)`, `loss.backward()`
@@ -462,11 +463,24 @@ class _FusionTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, trainer, z_t, feats, ids, mask):
         ctx.trainer = trainer
-        return trainer.forward(z_t, feats, ids, mask)
+        out = trainer.forward(z_t, feats, ids, mask)
+        # The saved activations, the dropout site counter and the flat gradient buffer are single slots on the trainer: this
+        # node may only be differentiated while they still belong to ITS forward, and only once.
+        trainer.generation = ctx.generation = getattr(trainer, "generation", 0) + 1
+        trainer.consumed = False
+        return out
 
     @staticmethod
     def backward(ctx, dlogits):
         tr = ctx.trainer
+        if tr.generation != ctx.generation:
+            raise RuntimeError("img_txt_fusion (train mode): another training-mode forward ran before this one's backward - the saved "
+                               "activations belong to the later forward.  Call backward() after each forward (gradients accumulate "
+                               "in .grad across steps), or run the other forward under torch.no_grad() / in .eval() mode")
+        if tr.consumed:
+            raise RuntimeError("img_txt_fusion (train mode): second backward through the same forward (retain_graph): the hand-written "
+                               "reverse pass keeps one gradient buffer per forward; run the forward again")
+        tr.consumed = True
         grads = tr.backward(dlogits.contiguous().float())
         for name, p in tr.model.named_parameters():
             if name in grads and p.requires_grad:
@@ -492,7 +506,10 @@ class AdamW:
     When the parameters and their gradients are the trainer's flat buffers (the normal case after `fusion_train`), one launch
     updates all of them; otherwise one launch per tensor."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, model=None):
+        """`model`: the BLIP_NLVR whose parameters these are - its packed inference engine is marked stale by every step()
+        (without it the training forward marks it, which misses an eval call made between backward() and step())."""
+        self.model = model
         self.params = [p for p in params if p.requires_grad]
         self.lr, self.betas, self.eps, self.wd, self.t = lr, betas, eps, weight_decay, 0
         self.m: Dict[int, torch.Tensor] = {}
@@ -515,6 +532,8 @@ class AdamW:
         ps = [p for p in self.params if p.grad is not None]
         if not ps:
             return
+        if self.model is not None:
+            self.model._text_stale = True                     # the weights change HERE: the next eval / score call repacks
         fp, fg = self._flat_range([p.data for p in ps]), self._flat_range([p.grad for p in ps])
         if fp is not None and fg is not None and fp[1] == fg[1] and all(p.data_ptr() - fp[0] == p.grad.data_ptr() - fg[0] for p in ps):
             n = fp[1]

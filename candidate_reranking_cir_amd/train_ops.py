@@ -131,3 +131,4 @@ def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tenso
     assert all(t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel() for t in (p, g, m, v))
     _lib.check(_lib.load().cir_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(betas[0]), float(betas[1]),
                                           float(eps), float(weight_decay), int(step), _stream()), "cir_adamw_step")
+    _lib.PARAM_EPOCH[0] += 1

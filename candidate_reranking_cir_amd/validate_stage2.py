@@ -147,12 +147,92 @@ def generate_val_predictions(blip_model, model_stage1, ds: RelativeValSet, index
     return (logits, glogits) if glogits is not None else logits
 
 
-def generate_fiq_val_predictions(blip_model, model_stage1, relative_val_dataset: RelativeValSet, index_features, **kw):
-    return generate_val_predictions(blip_model, model_stage1, relative_val_dataset, index_features, **kw)
+# ------------------------------------------------------------------------------------------------ reference signatures
+def relative_val_set_from_dataset(relative_val_dataset, index_names: Sequence[str]):
+    """The reference's 'relative' validation dataset (any object with its duck type: `K`, `K_labels`, `__len__`, and items
+    laid out as data_utils.py:204-208 (FashionIQ: reference, target, [cap1, cap2], top-K names, K_labels) or :332-336 (CIRR:
+    reference, target_hard, caption, 6 group members incl. the reference, top-K names, K_labels, K_group_labels)) ->
+    (RelativeValSet, reference names, target names, group members without the reference or None).  Names become rows of
+    `index_names` ONCE here (the reference looks every name up in a dict per query, validate_stage2.py:91/115, 232/251);
+    a name that is not in the index raises KeyError, as there."""
+    row = {str(n): i for i, n in enumerate(index_names)}
+    if len(row) != len(index_names):
+        raise ValueError("index_names holds duplicates")
+    n_q, k = len(relative_val_dataset), int(relative_val_dataset.K)
+    refs, targets, caps, members_no_ref = [], [], [], []
+    ref_index, cand_index = np.empty(n_q, dtype=np.int64), np.empty((n_q, k), dtype=np.int64)
+    labels = np.empty((n_q, k), dtype=bool)
+    cirr = None
+    for q in range(n_q):
+        item = relative_val_dataset[q]
+        if cirr is None:
+            if len(item) not in (5, 7):
+                raise TypeError(f"a stage-II relative-val item has 5 (FashionIQ) or 7 (CIRR) fields, got {len(item)} "
+                                "(was the dataset built with load_topk= / K= ?)")
+            cirr = len(item) == 7
+        if cirr:
+            ref, tgt, cap, members, k_names, k_lab, _ = item
+            caps.append(str(cap))
+            members_no_ref.append([str(m) for m in members if str(m) != str(ref)])         # validate_stage2.py:266, 274
+        else:
+            ref, tgt, cap, k_names, k_lab = item
+            caps.append(fiq_caption(str(cap[0]), str(cap[1])))                             # validate_stage2.py:97-100
+        refs.append(str(ref)); targets.append(str(tgt))
+        ref_index[q] = row[str(ref)]
+        cand_index[q] = [row[str(n)] for n in k_names]
+        labels[q] = np.asarray(k_lab, dtype=bool)
+    group_index = target_index = None
+    if cirr:
+        if any(len(m) != 5 for m in members_no_ref):
+            raise ValueError("every CIRR subset has 5 members besides the reference (validate_stage2.py:186)")
+        group_index = np.array([[row[m] for m in ms] for ms in members_no_ref], dtype=np.int64).reshape(n_q, 5)
+        target_index = np.array([row[t] for t in targets], dtype=np.int64)
+    ds = RelativeValSet(ref_index=ref_index, cand_index=cand_index, labels=labels, captions=caps, group_index=group_index, target_index=target_index)
+    return ds, refs, targets, (members_no_ref if cirr else None)
 
 
-def generate_cirr_val_predictions(blip_model, model_stage1, relative_val_dataset: RelativeValSet, index_features, **kw):
-    return generate_val_predictions(blip_model, model_stage1, relative_val_dataset, index_features, **kw)
+def _bank16(blip_model, index_features: torch.Tensor) -> torch.Tensor:
+    """The reference hands fp32 index features (utils.py:43-55); the scoring path reads the 16-bit bank: one conversion launch."""
+    dt = blip_model.compute_dtype
+    feats = index_features.to(blip_model.device)
+    return feats if feats.dtype == dt else ops.gather_rows(feats, None, dt)
+
+
+def generate_fiq_val_predictions(blip_model, model_stage1, relative_val_dataset, *args, **kw):
+    """Two call forms.  Native: (blip_model, model_stage1, RelativeValSet, index_features, query_batch=..., rows=..., kv_bank=...)
+    -> logits (Q, K).  The reference's own (validate_stage2.py:69-71; what compute_fiq_val_metrics and stage2_train.py reach):
+    (blip_model, model_stage1, relative_val_dataset, index_names, index_features) with the reference's dataset duck type
+    -> (predicted_logits (Q, K), target_names), validate_stage2.py:129."""
+    if isinstance(relative_val_dataset, RelativeValSet):
+        return generate_val_predictions(blip_model, model_stage1, relative_val_dataset, *args, **kw)
+    index_names, index_features = _names_and_features(args, kw)
+    ds, _, targets, _ = relative_val_set_from_dataset(relative_val_dataset, index_names)
+    logits = generate_val_predictions(blip_model, model_stage1, ds, _bank16(blip_model, index_features), **kw)
+    return logits, targets
+
+
+def generate_cirr_val_predictions(blip_model, model_stage1, relative_val_dataset, *args, **kw):
+    """Native form as above -> (logits (Q, K), subset logits (Q, 5)).  Reference form (validate_stage2.py:209-211) ->
+    (predicted_logits, group_predicted_logits, reference_names, target_names, group_members_noRef), validate_stage2.py:278."""
+    if isinstance(relative_val_dataset, RelativeValSet):
+        return generate_val_predictions(blip_model, model_stage1, relative_val_dataset, *args, **kw)
+    index_names, index_features = _names_and_features(args, kw)
+    ds, refs, targets, members = relative_val_set_from_dataset(relative_val_dataset, index_names)
+    if ds.group_index is None:
+        raise TypeError("generate_cirr_val_predictions needs CIRR items (7 fields, data_utils.py:332-336)")
+    logits, glogits = generate_val_predictions(blip_model, model_stage1, ds, _bank16(blip_model, index_features), **kw)
+    return logits, glogits, refs, targets, members
+
+
+def _names_and_features(args, kw):
+    """(index_names, index_features) of a reference-form call, positional or by keyword."""
+    names = args[0] if len(args) > 0 else kw.pop("index_names")
+    feats = args[1] if len(args) > 1 else kw.pop("index_features")
+    if len(args) > 2:
+        raise TypeError("reference form: (blip_model, model_stage1, relative_val_dataset, index_names, index_features)")
+    if isinstance(names, torch.Tensor) or not isinstance(feats, torch.Tensor):
+        raise TypeError("reference form takes index_names (list of str) BEFORE index_features (tensor), validate_stage2.py:69-71")
+    return list(names), feats
 
 
 # ------------------------------------------------------------------------------------------------ metrics
@@ -166,15 +246,40 @@ def recall_at(lab: torch.Tensor, k: int) -> float:
     return (torch.sum(lab[:, :k]) / len(lab)).item() * 100
 
 
-def compute_fiq_val_metrics(logits: torch.Tensor, ds: RelativeValSet) -> Tuple[float, float]:
-    """(R@10, R@50), validate_stage2.py:53-66."""
-    lab = sorted_labels(logits, ds.labels)
-    return recall_at(lab, 10), recall_at(lab, 50)
+def compute_fiq_val_metrics(*args, **kw) -> Tuple[float, float]:
+    """(R@10, R@50), validate_stage2.py:53-66.  Native form: (logits, RelativeValSet).  Reference form (validate_stage2.py:33-37,
+    called stage2_train.py:270): (relative_val_dataset, blip_model, model_stage1, index_features, index_names)."""
+    if isinstance(args[0], torch.Tensor):
+        logits, ds = args
+        lab = sorted_labels(logits, ds.labels)
+        return recall_at(lab, 10), recall_at(lab, 50)
+    relative_val_dataset, blip_model, model_stage1, index_features, index_names = _metric_args(args, kw)
+    ds, _, _, _ = relative_val_set_from_dataset(relative_val_dataset, index_names)
+    logits = generate_val_predictions(blip_model, model_stage1, ds, _bank16(blip_model, index_features), **kw)
+    return compute_fiq_val_metrics(logits, ds)
 
 
-def compute_cirr_val_metrics(logits: torch.Tensor, group_logits: torch.Tensor, ds: RelativeValSet):
-    """(Rs@1, Rs@2, Rs@3, R@1, R@5, R@10, R@50), validate_stage2.py:174-206."""
-    lab = sorted_labels(logits, ds.labels)
-    glab = sorted_labels(group_logits, ds.group_index == ds.target_index[:, None])
-    return (recall_at(glab, 1), recall_at(glab, 2), recall_at(glab, 3),
-            recall_at(lab, 1), recall_at(lab, 5), recall_at(lab, 10), recall_at(lab, 50))
+def compute_cirr_val_metrics(*args, **kw):
+    """(Rs@1, Rs@2, Rs@3, R@1, R@5, R@10, R@50), validate_stage2.py:174-206.  Native form: (logits, group_logits, RelativeValSet).
+    Reference form (validate_stage2.py:153-156, called stage2_train.py:513): (relative_val_dataset, blip_model, model_stage1,
+    index_features, index_names)."""
+    if isinstance(args[0], torch.Tensor):
+        logits, group_logits, ds = args
+        lab = sorted_labels(logits, ds.labels)
+        glab = sorted_labels(group_logits, ds.group_index == ds.target_index[:, None])
+        return (recall_at(glab, 1), recall_at(glab, 2), recall_at(glab, 3),
+                recall_at(lab, 1), recall_at(lab, 5), recall_at(lab, 10), recall_at(lab, 50))
+    relative_val_dataset, blip_model, model_stage1, index_features, index_names = _metric_args(args, kw)
+    ds, _, _, _ = relative_val_set_from_dataset(relative_val_dataset, index_names)
+    if ds.group_index is None:
+        raise TypeError("compute_cirr_val_metrics needs CIRR items (7 fields, data_utils.py:332-336)")
+    logits, glogits = generate_val_predictions(blip_model, model_stage1, ds, _bank16(blip_model, index_features), **kw)
+    return compute_cirr_val_metrics(logits, glogits, ds)
+
+
+def _metric_args(args, kw):
+    names = ("relative_val_dataset", "blip_model", "model_stage1", "index_features", "index_names")
+    if len(args) > len(names):
+        raise TypeError("reference form: (relative_val_dataset, blip_model, model_stage1, index_features, index_names)")
+    vals = list(args) + [kw.pop(n) for n in names[len(args):]]
+    return vals

@@ -64,3 +64,36 @@ def tokenize(texts):
 def grad_sample_index(numel: int, n: int = 64) -> np.ndarray:
     """The positions of a flattened gradient kept by tests/golden/train768.npz (oracle/make_golden.py: grad_sample_index)."""
     return (np.arange(n, dtype=np.int64) * 2654435761 + 12345) % numel
+
+
+class DuckFIQ:
+    """A FashionIQ 'relative' val dataset with a top-K file, as the reference's callers see it (data_utils.py:166-179: `K`,
+    `K_labels`, `K_sorted_index_names`, `dress_types`; items as data_utils.py:204-208) - built from fixture arrays."""
+
+    def __init__(self, names, refs, targets, captions, cand_idx, labels):
+        self.names, self.refs, self.targets, self.captions = list(names), refs, targets, captions
+        self.K_sorted_index_names = np.array(self.names)[cand_idx]
+        self.K_labels, self.K = labels, cand_idx.shape[1]
+        self.dress_types, self.split = ["dress"], "val"
+
+    def __len__(self):
+        return len(self.refs)
+
+    def __getitem__(self, i):
+        return (self.names[self.refs[i]], self.names[self.targets[i]], [str(c) for c in self.captions[i]],
+                self.K_sorted_index_names[i].tolist(), self.K_labels[i])
+
+
+class DuckCIRR(DuckFIQ):
+    """CIRR 'relative' val items (data_utils.py:332-336): the 6 subset members INCLUDE the reference image."""
+
+    def __init__(self, names, refs, targets, captions, cand_idx, labels, groups, ref_slot=0):
+        super().__init__(names, refs, targets, captions, cand_idx, labels)
+        self.groups, self.ref_slot = groups, ref_slot
+        self.K_group_labels = np.zeros((len(refs), 5), dtype=bool)
+
+    def __getitem__(self, i):
+        members = [self.names[j] for j in self.groups[i]]
+        members.insert(self.ref_slot % 6, self.names[self.refs[i]])
+        return (self.names[self.refs[i]], self.names[self.targets[i]], str(self.captions[i]), members,
+                self.K_sorted_index_names[i].tolist(), self.K_labels[i], self.K_group_labels[i])

@@ -135,6 +135,39 @@ def test_scoring_loop_tiny(tiny, flavour, query_batch):
         np.testing.assert_allclose(ref_metrics, z["fiq_metrics"], atol=1e-4)
 
 
+def test_reference_signatures(tiny):
+    """The reference's own call forms (stage2_train.py:270, :513; validate_stage2.py:69-71, 153-156, 209-211): duck-typed
+    FashionIQ / CIRR datasets with NAMES, fp32 index features as extract_index_features returns them -> the reference's
+    tuples, equal to the native form bit for bit and to the reference's outputs (tiny_loop.npz) within the bound."""
+    from candidate_reranking_cir_amd import validate_stage2 as V
+    z, g, v, m2, m1, dt = tiny
+    names = ["n%03d" % (7 * i % 100) for i in range(14)]
+    feats32 = m2.img_embed(H.fixture_images(z, range(14), v.image_size).cuda())          # (14, N, D) fp32, utils.py:51
+    fiq = H.DuckFIQ(names, z["refs"], z["targets"], z["fiq_caps"], z["cand_idx"], z["labels"])
+    cirr = H.DuckCIRR(names, z["refs"], z["targets"], z["cirr_caps"], z["cand_idx"], z["labels"], z["groups"], ref_slot=2)
+    skipped = ~z["labels"].any(1)
+    lg, tn = V.generate_fiq_val_predictions(m2, m1, fiq, names, feats32)
+    assert tn == [names[i] for i in z["targets"]] and lg.shape == (8, 6) and lg.dtype == torch.float32
+    clg, cgl, rn, ctn, mem = V.generate_cirr_val_predictions(m2, m1, cirr, names, feats32)
+    assert rn == [names[i] for i in z["refs"]] and mem == [[names[j] for j in row] for row in z["groups"]]
+    bank = V.extract_index_features(H.fixture_images(z, range(14), v.image_size), m2)
+    caps = [V.fiq_caption(str(p[0]), str(p[1])) for p in z["fiq_caps"]]
+    nat = V.generate_val_predictions(m2, m1, V.RelativeValSet(ref_index=z["refs"], cand_index=z["cand_idx"], labels=z["labels"], captions=caps), bank)
+    assert torch.equal(nat, lg)                                                           # same path underneath
+    for ours, ref in ((lg.cpu().numpy(), z["fiq_logits"]), (clg.cpu().numpy(), z["cirr_logits"])):
+        assert np.all(ours[skipped] == np.float32(-99999.99))
+        sig = ref[~skipped].std(axis=1, keepdims=True)
+        assert (np.abs(ours[~skipped] - ref[~skipped]) / sig).max() < REL_TOL[dt]
+    gref = z["cirr_group_logits"]
+    assert (np.abs(cgl.cpu().numpy() - gref) / gref.std(axis=1, keepdims=True)).max() < 2 * REL_TOL[dt]
+    m_f = V.compute_fiq_val_metrics(fiq, m2, m1, feats32, names)
+    m_c = V.compute_cirr_val_metrics(cirr, m2, m1, feats32, names)
+    assert m_f == V.compute_fiq_val_metrics(lg, V.relative_val_set_from_dataset(fiq, names)[0])
+    assert len(m_f) == 2 and len(m_c) == 7 and all(0.0 <= x <= 100.0 for x in m_f + m_c)
+    print(f"\n[reference signatures {dt}] fiq {np.round(m_f, 2)} (reference {np.round(z['fiq_metrics'], 2)})  cirr {np.round(m_c, 2)} "
+          f"(reference {np.round(z['cirr_metrics'], 2)})")
+
+
 def test_padded_masks(tiny):
     """Padded captions (attention_mask zeros) through both text encoders, batch of 3 ragged rows."""
     z, g, v, m2, m1, dt = tiny

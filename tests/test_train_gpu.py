@@ -301,3 +301,36 @@ def test_inputs_requiring_grad_are_refused(cuda):
     with torch.no_grad():                                       # no graph asked for: the inference path, whatever the mode
         assert m.img_txt_fusion(z_t, feats, caps).shape == (2, 2)
     m.eval()
+
+
+def test_backward_guards_and_engine_staleness(cuda):
+    """The trainer keeps ONE set of saved activations / one gradient buffer: a backward through a forward that is no longer the
+    latest one, or a second backward through the same forward, raises instead of returning another forward's gradients; and an
+    eval call between backward() and step() does not leave the inference engine on the pre-step weights."""
+    from candidate_reranking_cir_amd.train import AdamW
+    zf, g, v, _, _ = H.tiny_setup()
+    m = build(g, v, int(zf["seed"]), str(zf["profile"]), BF)[0]
+    freeze_vit(m)
+    m.train()
+    caps = [synthetic.caption_text(90 + i, n) for i, n in enumerate((4, 8, 6))]
+    rng = torch.Generator().manual_seed(5)
+    l = H.tokenize(caps)[0].shape[1]
+    z_t = torch.randn((3, l, g.hidden_size), generator=rng).cuda()
+    feats = torch.randn((3, 17, g.encoder_width), generator=rng).cuda()
+    gt = torch.arange(3, device=cuda)
+    loss_a = F.cross_entropy(m.img_txt_fusion(z_t, feats, caps), gt)
+    loss_b = F.cross_entropy(m.img_txt_fusion(z_t.flip(0), feats, caps), gt)
+    with pytest.raises(RuntimeError, match="another training-mode forward"):
+        loss_a.backward()
+    loss_b.backward(retain_graph=True)                                           # the latest forward: fine, once
+    with pytest.raises(RuntimeError, match="second backward"):
+        loss_b.backward()
+    # eval between backward and step, then step: the next eval must see the stepped weights
+    opt = AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-2, weight_decay=0.0)
+    opt.zero_grad()
+    F.cross_entropy(m.img_txt_fusion(z_t, feats, caps), gt).backward()
+    m.eval()
+    before = m.img_txt_fusion(z_t, feats, caps).clone()                          # repacks the engine and clears the forward's mark
+    opt.step()
+    after = m.img_txt_fusion(z_t, feats, caps)
+    assert (after - before).abs().max().item() > 1e-3, "the inference engine still holds the pre-step weights"
