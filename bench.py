@@ -506,6 +506,7 @@ def main():
     ap.add_argument("--index-size", type=int, default=2297, help="bank mode: number of index images (CIRR val: 2297)")
     args = ap.parse_args()
 
+    torch.set_num_threads(min(16, usable_cpus()))   # the box shows every host core but grants a cgroup quota: the default pool thrashes
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It has not touched the GPU (no HIP
         # call precedes this line) and never does; it starts one CHILD per GPU and relays rank 0's line - nothing is exec'ed.

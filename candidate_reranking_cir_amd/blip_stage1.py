@@ -47,8 +47,8 @@ class BLIP_Retrieval(_EngineHost):
                 raise RuntimeError("BLIP_Retrieval runs on an MI355X only: move the model to 'cuda' (no CPU path)")
             sd = self.state_dict()
             f32 = lambda k: sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()
-            self._engines = (MedEngine(sd, self.bert_geometry, self.compute_dtype, dev, stream_dtype=self.stream_dtype),
-                             VitEngine(sd, self.vit_geometry, self.compute_dtype, dev, stream_dtype=self.stream_dtype),
+            self._engines = (MedEngine(sd, self.bert_geometry, self.compute_dtype, dev, stream_dtype=self.stream_dtype, cross_dtype=self.token_dtype),
+                             VitEngine(sd, self.vit_geometry, self.token_dtype, dev, stream_dtype=self.vit_stream_dtype),
                              dict(vw=f32("vision_proj.weight"), vb=f32("vision_proj.bias"), tw=f32("text_proj.weight"), tb=f32("text_proj.bias")))
         return self._engines
 
@@ -68,8 +68,8 @@ class BLIP_Retrieval(_EngineHost):
     def z_t(self, ref_tokens: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> EncoderOutput:
         """Batched z_t: reference-image tokens (Q, N, D), ids/mask (Q, L) with [ENC] set."""
         t = ref_tokens.to(self.device)
-        if t.dtype != self.compute_dtype:
-            t = ops.gather_rows(t if t.dtype == torch.float32 else t.float(), None, self.compute_dtype)
+        if t.dtype != self.token_dtype:
+            t = ops.gather_rows(t, None, self.token_dtype)
         h32, h16 = self.engines()[0].forward(input_ids, attention_mask, t)
         return EncoderOutput(h32, h16)
 

@@ -79,8 +79,10 @@ class _EngineHost(nn.Module):
         self._engines = None
         self._packed_epoch = 0
         self._text_stale = False               # set by a training step (train.py): text_encoder / cls_head changed, the ViT did not
-        self.compute_dtype = torch.bfloat16
+        self.compute_dtype = torch.bfloat16    # operand type of the text side (self-attention, FFN, cls_head)
+        self.image_dtype = None                # operand type of the ViT and the cross-attention block (None: = compute_dtype)
         self._stream_dtype = None              # None = automatic (see `stream_dtype`)
+        self._vit_stream_dtype = None          # the ViT's own residual-stream storage (None = automatic)
 
     @property
     def stream_dtype(self) -> torch.dtype:
@@ -92,19 +94,59 @@ class _EngineHost(nn.Module):
             return self._stream_dtype
         return torch.float16 if self.compute_dtype == torch.bfloat16 else torch.float32
 
-    def set_stream_dtype(self, dtype: Optional[torch.dtype]):
-        if dtype not in (None, torch.float16, torch.float32):
-            raise ValueError("residual-stream dtype must be torch.float16, torch.float32 or None (automatic)")
+    def set_stream_dtype(self, dtype: Optional[torch.dtype], vit: Optional[torch.dtype] = "same"):
+        """Storage of the residual stream: fp16, fp32 or None (automatic per engine: fp16 under bf16 operands, fp32 under fp16
+        operands).  `vit` gives the ViT its own choice (its stream is 6x the text side's rows: the bytes are there, the
+        rank sensitivity is on the text side - DESIGN.md section 2)."""
+        for d in (dtype,) + (() if vit == "same" else (vit,)):
+            if d not in (None, torch.float16, torch.float32):
+                raise ValueError("residual-stream dtype must be torch.float16, torch.float32 or None (automatic)")
         self._stream_dtype = dtype
+        self._vit_stream_dtype = dtype if vit == "same" else vit
         self._engines = None
         return self
 
-    def set_compute_dtype(self, dtype: torch.dtype):
-        if dtype not in (torch.bfloat16, torch.float16):
-            raise ValueError("compute dtype must be torch.bfloat16 or torch.float16 (fp32 accumulate either way)")
+    @property
+    def vit_stream_dtype(self) -> torch.dtype:
+        if self._vit_stream_dtype is not None:
+            return self._vit_stream_dtype
+        return torch.float16 if self.token_dtype == torch.bfloat16 else torch.float32
+
+    def set_compute_dtype(self, dtype: torch.dtype, image_dtype: Optional[torch.dtype] = None):
+        """Operand type of every MFMA product (bf16 or fp16; fp32 accumulate either way).  `image_dtype` gives the ViT and the
+        image-facing cross-attention block of the text encoders their own operand type (engine.py, "MIXED")."""
+        for d in (dtype, image_dtype):
+            if d not in (None, torch.bfloat16, torch.float16) or dtype is None:
+                raise ValueError("compute dtype must be torch.bfloat16 or torch.float16 (fp32 accumulate either way)")
         self.compute_dtype = dtype
+        self.image_dtype = None if image_dtype == dtype else image_dtype
         self._engines = None
         return self
+
+    PRECISIONS = ("bf16", "f16", "mixed")
+
+    def set_precision(self, mode: str):
+        """"bf16" / "f16": one operand type everywhere.  "mixed": bf16 operands for the ViT and the cross-attention block
+        (cross Q / K|V projections, cross-attention, merge projection: 77 % of the path's flops), fp16 operands for the
+        text-side self-attention, FFN and cls_head - where a bf16 run loses the reference's rank order
+        (profiles/r4_precision_attribution_*.json)."""
+        if mode not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {self.PRECISIONS}")
+        if mode == "mixed":
+            return self.set_compute_dtype(torch.float16, torch.bfloat16)
+        return self.set_compute_dtype(torch.bfloat16 if mode == "bf16" else torch.float16)
+
+    @property
+    def precision(self) -> str:
+        if self.image_dtype is not None:
+            return "mixed" if (self.compute_dtype, self.image_dtype) == (torch.float16, torch.bfloat16) else \
+                f"{str(self.compute_dtype)[6:]}+{str(self.image_dtype)[6:]}"
+        return "bf16" if self.compute_dtype == torch.bfloat16 else "f16"
+
+    @property
+    def token_dtype(self) -> torch.dtype:
+        """16-bit type of image tokens on this model's path (ViT output = cross-attention operand)."""
+        return self.image_dtype or self.compute_dtype
 
     def _apply(self, fn, *a, **k):
         self._engines = None
@@ -141,15 +183,16 @@ class BLIP_NLVR(_EngineHost):
             if dev.type != "cuda":
                 raise RuntimeError("BLIP_NLVR runs on an MI355X only: move the model to 'cuda' (no CPU path)")
             sd = self.state_dict()
-            self._engines = (VitEngine(sd, self.vit_geometry, self.compute_dtype, dev, stream_dtype=self.stream_dtype),
-                             NlvrEngine(sd, self.bert_geometry, self.compute_dtype, dev, fold_merge=self.fold_merge, stream_dtype=self.stream_dtype))
+            self._engines = (VitEngine(sd, self.vit_geometry, self.token_dtype, dev, stream_dtype=self.vit_stream_dtype),
+                             NlvrEngine(sd, self.bert_geometry, self.compute_dtype, dev, fold_merge=self.fold_merge, stream_dtype=self.stream_dtype,
+                                        cross_dtype=self.token_dtype))
             self._text_stale = False
             self._packed_epoch = _lib.PARAM_EPOCH[0]
         elif text and (self._text_stale or (getattr(self, "_trainer", None) is not None and self._packed_epoch != _lib.PARAM_EPOCH[0])):
             # after training steps (the forward marks it; every cir_adamw_step launch moves lib.PARAM_EPOCH, so an eval call made
             # between backward() and step() cannot leave the engine on the pre-step weights): repack the two-branch encoder only (the ViT is frozen there),
             self._engines = (self._engines[0], NlvrEngine(self.state_dict(), self.bert_geometry, self.compute_dtype, self.device,
-                                                          fold_merge=self.fold_merge, stream_dtype=self.stream_dtype))
+                                                          fold_merge=self.fold_merge, stream_dtype=self.stream_dtype, cross_dtype=self.token_dtype))
             self._text_stale = False           # and only when a caller needs it (`text`): img_embed between steps does not
             self._packed_epoch = _lib.PARAM_EPOCH[0]
         return self._engines
@@ -164,14 +207,14 @@ class BLIP_NLVR(_EngineHost):
 
     @torch.no_grad()
     def img_embed16(self, image) -> torch.Tensor:
-        """Same tokens in the 16-bit compute dtype (what the fusion GEMMs consume)."""
+        """Same tokens in the 16-bit `token_dtype` (what the cross-attention K|V GEMMs consume)."""
         return self.engines(text=False)[0].forward(image.to(self.device), want32=False)[1]
 
     def _cand16(self, t_image_embeds: torch.Tensor) -> torch.Tensor:
         t = t_image_embeds.to(self.device)
-        if t.dtype == self.compute_dtype:
+        if t.dtype == self.token_dtype:
             return t
-        return ops.gather_rows(t if t.dtype == torch.float32 else t.float(), None, self.compute_dtype)
+        return ops.gather_rows(t, None, self.token_dtype)
 
     @torch.no_grad()
     def score(self, z_t: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor, cand: Optional[torch.Tensor],

@@ -352,6 +352,8 @@ extern "C" int cir_gather_rows(const void* src, int src_dtype, const int64_t* in
     CIR_G(CIR_F16, CIR_F16, _Float16, _Float16)
     CIR_G(CIR_BF16, CIR_F32, __bf16, float)
     CIR_G(CIR_F16, CIR_F32, _Float16, float)
+    CIR_G(CIR_BF16, CIR_F16, __bf16, _Float16)
+    CIR_G(CIR_F16, CIR_BF16, _Float16, __bf16)
 #undef CIR_G
     return CIR_EDTYPE;
 }

@@ -8,6 +8,13 @@ fp32; the RESIDUAL STREAM (x + sublayer(x), and the LayerNorm outputs that feed 
 `stream_dtype`: fp16 by default (sum formed in fp32, rounded once per sublayer to 11 bits - an eighth
 of the bf16 operand rounding that every GEMM input gets anyway) or fp32.
 
+MIXED operand precision (round 4; profiles/r4_precision_attribution_*.json): the text-side engines take a second operand
+type `cross_dtype` for their image-facing block - cross-attention query / key|value projections, the cross-attention itself
+and its output (merge) projection, all of which consume or meet the ViT's tokens - while the self-attention block, the FFN and
+cls_head run in `dtype`.  The per-site rounding attribution shows the rank error of a bf16 run entering through the text-side
+self-attention / FFN / cls_head ACTIVATIONS; the ViT and the cross-attention block are rank-neutral in bf16.  "mixed" =
+ViT + cross block bf16 (77 % of the flops), text self-attention + FFN + cls_head fp16.
+
 Reference arithmetic being scheduled (cited per method): vit.py:180-194, med.py:348-398 / 685-821,
 nlvr_encoder.py:414-476 / 777-908, blip_stage2.py:101-136.
 """
@@ -138,9 +145,10 @@ class MedEngine:
     """Stage-I BERT/MED text encoder with image cross-attention (med.py:348-398, 685-821) -> z_t."""
 
     def __init__(self, sd: SD, geo: BertGeometry, dtype: torch.dtype, device, prefix: str = "text_encoder.",
-                 stream_dtype: Optional[torch.dtype] = None):
+                 stream_dtype: Optional[torch.dtype] = None, cross_dtype: Optional[torch.dtype] = None):
         geo.validate()
         self.geo, self.dtype, self.device, self.stream_dtype = geo, dtype, device, _auto_stream(dtype, stream_dtype)
+        self.xdtype = xdt = cross_dtype or dtype       # operand type of the image-facing block (module docstring)
         e = prefix + "embeddings."
         self.word, self.posemb = _f32(sd[e + "word_embeddings.weight"], device), _f32(sd[e + "position_embeddings.weight"], device)
         self.ge, self.be = _f32(sd[e + "LayerNorm.weight"], device), _f32(sd[e + "LayerNorm.bias"], device)
@@ -153,10 +161,10 @@ class MedEngine:
                 bqkv=_f32(_cat(sd, [sa + "query", sa + "key", sa + "value"], ".bias"), device),
                 wo=_w16(sd[p + "attention.output.dense.weight"], dtype, device), bo=_f32(sd[p + "attention.output.dense.bias"], device),
                 g1=_f32(sd[p + "attention.output.LayerNorm.weight"], device), b1=_f32(sd[p + "attention.output.LayerNorm.bias"], device),
-                wq=_w16(sd[ca + "query.weight"], dtype, device), bq=_f32(sd[ca + "query.bias"], device),
-                wkv=_w16(_cat(sd, [ca + "key", ca + "value"], ".weight"), dtype, device),
+                wq=_w16(sd[ca + "query.weight"], xdt, device), bq=_f32(sd[ca + "query.bias"], device),
+                wkv=_w16(_cat(sd, [ca + "key", ca + "value"], ".weight"), xdt, device),
                 bkv=_f32(_cat(sd, [ca + "key", ca + "value"], ".bias"), device),
-                wco=_w16(sd[p + "crossattention.output.dense.weight"], dtype, device), bco=_f32(sd[p + "crossattention.output.dense.bias"], device),
+                wco=_w16(sd[p + "crossattention.output.dense.weight"], xdt, device), bco=_f32(sd[p + "crossattention.output.dense.bias"], device),
                 g2=_f32(sd[p + "crossattention.output.LayerNorm.weight"], device), b2=_f32(sd[p + "crossattention.output.LayerNorm.bias"], device),
                 w1=_w16(sd[p + "intermediate.dense.weight"], dtype, device), c1=_f32(sd[p + "intermediate.dense.bias"], device),
                 w2=_w16(sd[p + "output.dense.weight"], dtype, device), c2=_f32(sd[p + "output.dense.bias"], device),
@@ -164,8 +172,8 @@ class MedEngine:
 
     def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, enc16: torch.Tensor,
                 enc_mask: Optional[torch.Tensor] = None):
-        """ids/mask (Q, L), image tokens (Q, N, Dv) 16-bit -> last hidden state (Q, L, D): (fp32, 16-bit)."""
-        geo, dt, sdt = self.geo, self.dtype, self.stream_dtype
+        """ids/mask (Q, L), image tokens (Q, N, Dv) 16-bit (in `xdtype`) -> last hidden state (Q, L, D): (fp32, 16-bit)."""
+        geo, dt, sdt, xdt = self.geo, self.dtype, self.stream_dtype, self.xdtype
         q_n, l = input_ids.shape
         d, n = geo.hidden_size, enc16.shape[1]
         r = q_n * l
@@ -176,15 +184,16 @@ class MedEngine:
         emask = additive_encoder_mask(enc_mask).view(q_n, 1, n) if enc_mask is not None else None
         enc2 = enc16.reshape(q_n * n, enc16.shape[2])
         ctx = torch.empty((q_n, 1, l, d), dtype=dt, device=hs.device)
+        ctx_x = ctx if xdt == dt else torch.empty((q_n, 1, l, d), dtype=xdt, device=hs.device)
         for ly in self.layers:
             qkv = ops.gemm(h16, ly["wqkv"], ly["bqkv"]).view(q_n, 1, l, 3 * d)
             ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], ctx, scale, smask)       # med.py:158-240
             t = ops.gemm(ctx.view(r, d), ly["wo"], ly["bo"], residual=hs, out_dtype=sdt)
-            a_s, a16 = _ln(t, ly["g1"], ly["b1"], eps, dt, sdt)                                        # med.py:250-253
+            a_s, a16 = _ln(t, ly["g1"], ly["b1"], eps, xdt, sdt)                                       # med.py:250-253 (operand copy feeds cross-Q only)
             qc = ops.gemm(a16, ly["wq"], ly["bq"]).view(q_n, 1, l, d)
             kv = ops.gemm(enc2, ly["wkv"], ly["bkv"]).view(q_n, 1, n, 2 * d)
-            ops.attention(qc, kv[..., :d], kv[..., d:], ctx, scale, emask)                             # med.py:361-376
-            t = ops.gemm(ctx.view(r, d), ly["wco"], ly["bco"], residual=a_s, out_dtype=sdt)
+            ops.attention(qc, kv[..., :d], kv[..., d:], ctx_x, scale, emask)                           # med.py:361-376
+            t = ops.gemm(ctx_x.view(r, d), ly["wco"], ly["bco"], residual=a_s, out_dtype=sdt)
             c_s, c16 = _ln(t, ly["g2"], ly["b2"], eps, dt, sdt)
             f = ops.gemm(c16, ly["w1"], ly["c1"], act=ops.ACT_GELU)                                    # med.py:319-322
             t = ops.gemm(f, ly["w2"], ly["c2"], residual=c_s, out_dtype=sdt)
@@ -208,9 +217,10 @@ class NlvrEngine:
     """
 
     def __init__(self, sd: SD, geo: BertGeometry, dtype: torch.dtype, device, prefix: str = "text_encoder.", fold_merge: bool = True,
-                 stream_dtype: Optional[torch.dtype] = None):
+                 stream_dtype: Optional[torch.dtype] = None, cross_dtype: Optional[torch.dtype] = None):
         geo.validate()
         self.geo, self.dtype, self.device, self.fold_merge, self.stream_dtype = geo, dtype, device, fold_merge, _auto_stream(dtype, stream_dtype)
+        self.xdtype = xdt = cross_dtype or dtype   # operand type of the cross-attention block = type of the candidate tokens (module docstring)
         self.trim_last = True   # last layer: per-token work on the CLS rows only (results identical for the rows that are used)
         self.kv_chunk = 0       # candidates per K|V + cross-attention chunk (0 = all at once; attribute, for A/B runs)
         self.fold_cls_kv = True  # last layer: fold the cross K / V projections out of the token side (False: K|V GEMM + attention)
@@ -230,10 +240,10 @@ class NlvrEngine:
             ly["bo"] = _f32(torch.stack([sd[p + f"attention.output.dense{b}.bias"].float() for b in (0, 1)]), device)
             ly["g1"] = _f32(torch.stack([sd[p + f"attention.output.LayerNorm{c}.weight"] for c in "AB"]), device)
             ly["b1"] = _f32(torch.stack([sd[p + f"attention.output.LayerNorm{c}.bias"] for c in "AB"]), device)
-            ly["wq"] = _w16(torch.stack([sd[c + "query.weight"].float() for c in ca]), dtype, device)
+            ly["wq"] = _w16(torch.stack([sd[c + "query.weight"].float() for c in ca]), xdt, device)
             ly["bq"] = _f32(torch.stack([sd[c + "query.bias"].float() for c in ca]), device)
             kv_keys = [ca[0] + "key", ca[0] + "value", ca[1] + "key", ca[1] + "value"]
-            ly["wkv"] = _w16(_cat(sd, kv_keys, ".weight"), dtype, device)         # (4D, Dv)
+            ly["wkv"] = _w16(_cat(sd, kv_keys, ".weight"), xdt, device)           # (4D, Dv)
             ly["bkv"] = _f32(_cat(sd, kv_keys, ".bias"), device)
             # one-time weight preparation in fp64 on the host (keeps library GEMMs out of the device timeline)
             w0 = sd[p + "crossattention.output.dense0.weight"].detach().cpu().double()
@@ -244,15 +254,15 @@ class NlvrEngine:
             if mk + ".weight" in sd:                                               # layers >= 6: nlvr_encoder.py:252-256
                 wm, bm = sd[mk + ".weight"].detach().cpu().double(), sd[mk + ".bias"].detach().cpu().double()
                 if fold_merge:
-                    ly["wm"] = _w16(torch.cat([wm[:, :d] @ w0, wm[:, d:] @ w1], dim=1).float(), dtype, device)
+                    ly["wm"] = _w16(torch.cat([wm[:, :d] @ w0, wm[:, d:] @ w1], dim=1).float(), xdt, device)
                     ly["bm"] = _f32((wm[:, :d] @ c0 + wm[:, d:] @ c1 + bm).float(), device)
                 else:
-                    ly["wd"] = _w16(torch.stack([w0, w1]).float(), dtype, device)
+                    ly["wd"] = _w16(torch.stack([w0, w1]).float(), xdt, device)
                     ly["bd"] = _f32(torch.stack([c0, c1]).float(), device)
-                    ly["wm"] = _w16(wm.float(), dtype, device)
+                    ly["wm"] = _w16(wm.float(), xdt, device)
                     ly["bm"] = _f32(bm.float(), device)
             else:                                                                  # layers < 6: nlvr_encoder.py:257-260
-                ly["wm"] = _w16(torch.cat([0.5 * w0, 0.5 * w1], dim=1).float(), dtype, device)
+                ly["wm"] = _w16(torch.cat([0.5 * w0, 0.5 * w1], dim=1).float(), xdt, device)
                 ly["bm"] = _f32((0.5 * (c0 + c1)).float(), device)
             ly["g2"] = _f32(torch.stack([sd[p + f"crossattention.output.LayerNorm{c}.weight"] for c in "AB"]), device)
             ly["b2"] = _f32(torch.stack([sd[p + f"crossattention.output.LayerNorm{c}.bias"] for c in "AB"]), device)
@@ -273,22 +283,23 @@ class NlvrEngine:
             wv = [sd[p + f"self{b}.value.weight"].detach().float() for b in (0, 1)]
             bv = [sd[p + f"self{b}.value.bias"].detach().float() for b in (0, 1)]
             self.cls_fold = dict(
-                wkt=[_w16(w.view(h_n, 64, dv).transpose(1, 2).contiguous(), dtype, device) for w in wk],   # (H, Dv, 64) per branch
-                wv=_w16(torch.cat(wv).view(2 * h_n, 64, dv), dtype, device),                               # (2H, 64, Dv)
+                wkt=[_w16(w.view(h_n, 64, dv).transpose(1, 2).contiguous(), xdt, device) for w in wk],     # (H, Dv, 64) per branch
+                wv=_w16(torch.cat(wv).view(2 * h_n, 64, dv), xdt, device),                                 # (2H, 64, Dv)
                 bv=_f32(torch.cat(bv).view(2 * h_n, 64), device), qp={})
         self.wc0, self.bc0 = _w16(sd["cls_head.0.weight"], dtype, device), _f32(sd["cls_head.0.bias"], device)
         self.wc2, self.bc2 = _w16(sd["cls_head.2.weight"], dtype, device), _f32(sd["cls_head.2.bias"], device)
 
     # ---------------------------------------------------------------------------------------------
     def _self_block(self, ly, h32, h16, items, l, smask):
-        """Twin self-attention + LayerNormA/B on (2, items*L, D) hidden states (nlvr_encoder.py:427-433, 262-264)."""
+        """Twin self-attention + LayerNormA/B on (2, items*L, D) hidden states (nlvr_encoder.py:427-433, 262-264).  The 16-bit
+        copy of the result feeds the cross-attention query projection only: it is written in `xdtype`."""
         d, dt, sdt, eps = self.geo.hidden_size, self.dtype, self.stream_dtype, self.geo.layer_norm_eps
         r = items * l
         qkv = ops.gemm(h16, ly["wqkv"], ly["bqkv"]).view(2, items, l, 3 * d)
         ctx = torch.empty((2, items, l, d), dtype=dt, device=h32.device)
         ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], ctx, 64 ** -0.5, smask.unsqueeze(0).expand(2, items, l))
         t = ops.gemm(ctx.view(2, r, d), ly["wo"], ly["bo"], residual=h32, out_dtype=sdt)
-        return _ln(t, ly["g1"], ly["b1"], eps, dt, sdt)
+        return _ln(t, ly["g1"], ly["b1"], eps, self.xdtype, sdt)
 
     @torch.no_grad()
     def build_kv_bank(self, bank16: torch.Tensor, chunk: int = 512) -> list:
@@ -305,7 +316,7 @@ class NlvrEngine:
             if i == last and self.trim_last and last > 0 and self.cls_fold is not None and self.fold_cls_kv:
                 out.append(None)            # the folded last layer attends the raw tokens: no K|V of this layer is ever formed
                 continue
-            kv = torch.empty((n_idx, n, 4 * d), dtype=self.dtype, device=bank16.device)
+            kv = torch.empty((n_idx, n, 4 * d), dtype=self.xdtype, device=bank16.device)
             for i0 in range(0, n_idx, chunk):
                 rows = bank16[i0:i0 + chunk].reshape(-1, dv)
                 ops.gemm(rows, ly["wkv"], ly["bkv"], out=kv[i0:i0 + chunk].view(-1, 4 * d))
@@ -319,7 +330,7 @@ class NlvrEngine:
         query each candidate belongs to -> logits (T, 2) fp32 (column 0 is the score).
         With `kv_bank` (from build_kv_bank) and `cand_rows` (T,) int64 bank rows, the per-candidate K|V GEMM is
         skipped and cross-attention reads K/V straight from the bank (cand16 is not used)."""
-        geo, dt, sdt = self.geo, self.dtype, self.stream_dtype
+        geo, dt, sdt, xdt = self.geo, self.dtype, self.stream_dtype, self.xdtype
         q_n, l = input_ids.shape
         if kv_bank is not None:
             cand_rows = cand_rows.to(torch.int64).contiguous()
@@ -339,11 +350,11 @@ class NlvrEngine:
         a_sq, a16q = self._self_block(self.layers[0], hq_s, hq16, q_n, l, smask_q)
         both = torch.cat([qidx, qidx + q_n])                                                              # rows of (2*Q, L*D)
         a32 = ops.gather_rows(a_sq.view(2 * q_n, l * d), both, sdt).view(2, r, d)
-        a16 = a32 if dt == sdt else ops.gather_rows(a16q.view(2 * q_n, l * d), both, dt).view(2, r, d)
+        a16 = a32 if xdt == sdt else ops.gather_rows(a16q.view(2 * q_n, l * d), both, xdt).view(2, r, d)
         smask = ops.gather_rows(_pad8(smask_q), qidx, torch.float32)[:, :l]                             # (T, L) view
         emask = additive_encoder_mask(cand_mask).view(t_n, 1, n).expand(t_n, 2, n) if cand_mask is not None else None
         cand2 = cand16.reshape(t_n * n, cand16.shape[2]) if kv_bank is None else None
-        cc = torch.empty((t_n, l, 2, d), dtype=dt, device=z_t32.device)
+        cc = torch.empty((t_n, l, 2, d), dtype=xdt, device=z_t32.device)
         h32 = h16 = None
         last = len(self.layers) - 1
         for i, ly in enumerate(self.layers):
@@ -357,11 +368,11 @@ class NlvrEngine:
                 ctx = torch.empty((2, t_n, 1, d), dtype=dt, device=h32.device)
                 ops.attention(qkv[:, :, :1, :d], qkv[..., d:2 * d], qkv[..., 2 * d:], ctx, scale, smask.unsqueeze(0).expand(2, t_n, l))
                 t = ops.gemm(ctx.view(2, t_n, d), ly["wo"], ly["bo"], residual=h32.view(2, t_n, l, d)[:, :, 0, :], out_dtype=sdt)
-                a32, a16 = _ln(t, ly["g1"], ly["b1"], eps, dt, sdt)
+                a32, a16 = _ln(t, ly["g1"], ly["b1"], eps, xdt, sdt)
             elif i > 0:
                 a32, a16 = self._self_block(ly, h32, h16, t_n, l, smask)
             qc = ops.gemm(a16, ly["wq"], ly["bq"]).view(2, t_n, lq, d).permute(1, 0, 2, 3)              # (T, 2, Lq, D) view
-            ccl = cc if not cls_only else torch.empty((t_n, 1, 2, d), dtype=dt, device=cc.device)
+            ccl = cc if not cls_only else torch.empty((t_n, 1, 2, d), dtype=xdt, device=cc.device)
             fold = cls_only and emask is None and self.cls_fold is not None and self.fold_cls_kv and (kv_bank is None or kv_bank[i] is None)
             if kv_bank is not None and kv_bank[i] is None and not fold:
                 raise ValueError("this K/V bank was built with the last layer folded (no K|V of that layer): rebuild it with fold_cls_kv = False")
@@ -372,7 +383,7 @@ class NlvrEngine:
                 f, h_n, dv = self.cls_fold, geo.num_attention_heads, tok.shape[2]
                 qp = f["qp"].get(t_n)
                 if qp is None:                                                                            # rows >= 2H stay zero
-                    qp = f["qp"][t_n] = torch.zeros((t_n, 32, dv), dtype=dt, device=cc.device)
+                    qp = f["qp"][t_n] = torch.zeros((t_n, 32, dv), dtype=xdt, device=cc.device)
                 q2 = qc.permute(1, 0, 2, 3).reshape(2, t_n, h_n, 64)                                      # view of the (2, T, D) GEMM result
                 for b in (0, 1):
                     ops.gemm(q2[b].permute(1, 0, 2), f["wkt"][b], None, out=qp[:, b * h_n:(b + 1) * h_n, :].permute(1, 0, 2))
@@ -392,7 +403,7 @@ class NlvrEngine:
                 ops.attention(qc, kv[:, :, 0::2].permute(0, 2, 1, 3), kv[:, :, 1::2].permute(0, 2, 1, 3),
                               ccl.permute(0, 2, 1, 3), scale, emask, kv_index=cand_rows)
             if "wd" in ly:                                                                                # unfolded merge_layer
-                dd = torch.empty((rq, 2, d), dtype=dt, device=cc.device)
+                dd = torch.empty((rq, 2, d), dtype=xdt, device=cc.device)
                 ops.gemm(ccl.view(rq, 2, d).permute(1, 0, 2), ly["wd"], ly["bd"], out=dd.permute(1, 0, 2))
                 m = ops.gemm(dd.view(rq, 2 * d), ly["wm"], ly["bm"], out_dtype=sdt)
             else:

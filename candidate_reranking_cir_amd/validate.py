@@ -27,7 +27,7 @@ def extract_index_features(images: torch.Tensor, model_stage1, batch_size: int =
     toks, pooled = [], []
     for i in range(0, images.shape[0], batch_size):
         t32, p = model_stage1.img_embed(images[i:i + batch_size].to(model_stage1.device), return_pool_and_normalized=True)
-        toks.append(ops.gather_rows(t32, None, model_stage1.compute_dtype))
+        toks.append(ops.gather_rows(t32, None, model_stage1.token_dtype))
         pooled.append(p)
     return torch.cat(toks), torch.cat(pooled)
 

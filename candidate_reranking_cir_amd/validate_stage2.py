@@ -193,7 +193,7 @@ def relative_val_set_from_dataset(relative_val_dataset, index_names: Sequence[st
 
 def _bank16(blip_model, index_features: torch.Tensor) -> torch.Tensor:
     """The reference hands fp32 index features (utils.py:43-55); the scoring path reads the 16-bit bank: one conversion launch."""
-    dt = blip_model.compute_dtype
+    dt = getattr(blip_model, "token_dtype", blip_model.compute_dtype)
     feats = index_features.to(blip_model.device)
     return feats if feats.dtype == dt else ops.gather_rows(feats, None, dt)
 

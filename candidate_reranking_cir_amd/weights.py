@@ -176,5 +176,20 @@ def synth_tensor(key: str, shape, kind: str, seed: int = 0, profile: str = "test
     return _apply_outliers(key, t, kind) if profile == "outlier" else t
 
 
-def synth_state_dict(spec: OrderedDict, seed: int = 0, profile: str = "test") -> "OrderedDict[str, torch.Tensor]":
-    return OrderedDict((k, synth_tensor(k, shape, kind, seed, profile)) for k, (shape, kind) in spec.items())
+def synth_state_dict(spec: OrderedDict, seed: int = 0, profile: str = "test", threads: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """Every tensor has its own generator (seeded by its key), so the tensors can be drawn concurrently and the result does not
+    depend on the thread count (torch.randn releases the GIL; a full-size pair of models is 0.5 G normals: ~25 s on one core)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    items = list(spec.items())
+    n = threads or min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    if n <= 1 or len(items) < 8:
+        return OrderedDict((k, synth_tensor(k, shape, kind, seed, profile)) for k, (shape, kind) in items)
+    saved = torch.get_num_threads()
+    torch.set_num_threads(1)                      # one core per tensor instead of all cores on one tensor at a time
+    try:
+        with ThreadPoolExecutor(n) as pool:
+            vals = list(pool.map(lambda kv: synth_tensor(kv[0], kv[1][0], kv[1][1], seed, profile), items))
+    finally:
+        torch.set_num_threads(saved)
+    return OrderedDict((k, v) for (k, _), v in zip(items, vals))
