@@ -84,11 +84,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
         }
     };
 
+    // Accumulators start at the bias, as in the 256 x 256 kernel: the two kernels then form every output with the SAME sequence
+    // of fp32 operations (bias, then the K-steps in ascending order through the same MFMA shape), so which tile size the
+    // dispatcher picks - it depends on the batch size - never changes a bit of the result.
     f32x4 acc[4][4];
+    {
+        const int nb_ = n0 + wn * 64 + g * 16;
+        float bias_[16];
+        if (a.bias != nullptr && nb_ + 16 <= a.N) {
+            const float4* bp = reinterpret_cast<const float4*>(a.bias + z * a.sBias + nb_);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+            for (int q = 0; q < 4; ++q) {
+                const float4 b4 = bp[q];
+                bias_[q * 4 + 0] = b4.x; bias_[q * 4 + 1] = b4.y; bias_[q * 4 + 2] = b4.z; bias_[q * 4 + 3] = b4.w;
+            }
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < 16; ++q) bias_[q] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{bias_[j * 4 + 0], bias_[j * 4 + 1], bias_[j * 4 + 2], bias_[j * 4 + 3]};
+    }
 
     // fragment read offsets (bytes) inside a tile: row*128 + ((kc ^ (row&7)) << 4)
     const int a_row_off = (wm * 64 + r15) * 128;
@@ -121,18 +139,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
     // ---- epilogue: lane (r15, g) owns, per mi, row m and features nb .. nb+15 ----------------------
     const int nb = n0 + wn * 64 + g * 16;
     if (nb + 16 > a.N) return;
-    float bias[16];
-    if (a.bias != nullptr) {
-        const float4* bp = reinterpret_cast<const float4*>(a.bias + z * a.sBias + nb);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 b4 = bp[q];
-            bias[q * 4 + 0] = b4.x; bias[q * 4 + 1] = b4.y; bias[q * 4 + 2] = b4.z; bias[q * 4 + 3] = b4.w;
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) bias[q] = 0.f;
-    }
     const bool has_res = a.R != nullptr;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
@@ -142,10 +148,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) v[ni * 4 + jj] = acc[mi][ni][jj] + bias[ni * 4 + jj];
+            for (int jj = 0; jj < 4; ++jj) v[ni * 4 + jj] = acc[mi][ni][jj];
         if (a.act == CIR_ACT_GELU) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = gelu_erf(v[q]);
+            for (int q = 0; q < 16; q += 8) {      // the 256 x 256 kernel's packed evaluation: the same operations, the same bits
+                float w8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w8[e] = v[q + e];
+                gelu_erf8(w8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[q + e] = w8[e];
+            }
         } else if (a.act == CIR_ACT_RELU) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) v[q] = fmaxf(v[q], 0.f);
@@ -155,10 +168,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
                 typedef __attribute__((ext_vector_type(8))) _Float16 h8;
                 const h8* rp = reinterpret_cast<const h8*>(reinterpret_cast<const _Float16*>(a.R) + z * a.sR + m * a.ldr + nb);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const h8 r8 = rp[q];
+                for (int q = 0; q < 2; ++q) {       // acc + bias is rounded to the stream type BEFORE the residual joins it (and the
+                    const h8 r8 = rp[q];            // sum is rounded again): what the 256 x 256 epilogue does in its 16-bit row layout
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[q * 8 + e] += (float)r8[e];
+                    for (int e = 0; e < 8; ++e) v[q * 8 + e] = (float)(_Float16)v[q * 8 + e] + (float)r8[e];
                 }
             } else {
                 const float4* rp = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.R) + z * a.sR + m * a.ldr + nb);

@@ -18,8 +18,8 @@
  *   - dtype codes: CIR_BF16 / CIR_F16 for 16-bit activations and weights (fp32 accumulate
  *     everywhere), CIR_F32 for fp32 tensors; the RESIDUAL STREAM (every x + sublayer(x) and the
  *     LayerNorm outputs that feed one) is either fp32 or fp16 ("stream dtype": CIR_F32 / CIR_F16),
- *     independently of the operand type - sums are formed in fp32 and rounded on the store (the large-tile
- *     GEMM rounds its result to the stream type before adding an fp16 residual: two roundings there);
+ *     independently of the operand type - sums are formed in fp32 and rounded on the store (a GEMM with an fp16
+ *     residual rounds its result to the stream type before the residual joins it: two roundings there);
  *   - return 0 on success, a negative CIR_E* code for an argument error detected before launch,
  *     or a positive hipError_t from the launch.  Nothing throws or aborts across the ABI.
  *   - functions are re-entrant and may be called from any host thread.
@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CIR_ABI_VERSION 7
+#define CIR_ABI_VERSION 8
 
 enum { CIR_BF16 = 0, CIR_F16 = 1, CIR_F32 = 2 };
 enum { CIR_ACT_NONE = 0, CIR_ACT_GELU = 1, CIR_ACT_RELU = 2 };
@@ -70,9 +70,10 @@ int cir_set_tuning(int knob, int value);
  *   bf16 operands).  res_dtype: CIR_F32 (with a C in the operand type or fp32) or CIR_F16 (only with an fp16 C; an fp16 C
  *   from bf16 operands takes ONLY an fp16 residual - CIR_EDTYPE otherwise).  C may alias residual.
  *   Requirements: K % 64 == 0, N % 16 == 0, 16-byte aligned rows.
- *   Rounding: one rounding of the fp32 result to the type of C - except an fp16 residual-stream C WITH a residual from the
- *   256 x 256 kernel (large M*N), which rounds A*W^T + bias to fp16 first, adds the residual in fp32 and rounds again: the same
- *   GEMM can differ by one rounding between batch sizes on either side of the tile heuristic (fp32-stream C: bit-identical).
+ *   Rounding: one rounding of the fp32 result to the type of C - except an fp16 residual-stream C WITH a residual, which
+ *   rounds A*W^T + bias to fp16 first, adds the residual in fp32 and rounds again.  Both tile sizes (128 x 128, persistent
+ *   256 x 256; picked from M*N*batch) start their accumulators at the bias, walk K in the same order and share the epilogue
+ *   arithmetic: the result does not depend on the tile choice, i.e. not on the batch size, in any output type (ABI v8).
  * Replaces every nn.Linear on the path: vit.py:35-41,72,84; med.py:158-168,250-251,319-333;
  * nlvr_encoder.py:150-168,250-264,383-396; blip_stage2.py:50-54 (first layer); the erf GELU is
  * ACT2FN['gelu'] (nlvr_encoder.py:376-379) / nn.GELU (vit.py:26).

@@ -314,7 +314,10 @@ def test_full_size_properties(cuda):
     goes through the persistent 256 x 256 GEMM) checked through size-independent properties instead of an oracle run:
       * rows are independent: permuting the candidates permutes the logits BIT FOR BIT (no kernel reduces across rows,
         and a row's reduction order does not depend on where the row sits);
-      * batch invariance: a candidate scored in a small batch (128 x 128 GEMM, other tiling) agrees within the bf16 bound;
+      * batch invariance: a candidate scored in a small batch (every Linear on the 128 x 128 GEMM instead of the persistent
+        256 x 256 one) gets the SAME BITS - tokens and logits - with the fp16 and with the fp32 residual stream (round 4: the two
+        GEMM kernels share their accumulation order and epilogue arithmetic), so a query block may be split over ranks in
+        any sizes without changing a result;
       * the order returned by cir_topk_desc is a permutation that sorts the logits (ties only among equal values)."""
     from candidate_reranking_cir_amd import ops
     g, v = H.geometry(H.FULL_BERT, dict(image_size=224))
@@ -337,11 +340,21 @@ def test_full_size_properties(cuda):
     iperm = torch.randperm(q_n * k, generator=torch.Generator().manual_seed(6)).cuda()
     toks_p = m2.img_embed16(images[q_n:][iperm])
     assert torch.equal(toks_p, toks[q_n:][iperm])
-    # batch invariance against a small batch (other GEMM kernel / tiling)
-    small = m2.score(z[:1], ids[:1], mask[:1], m2.img_embed16(images[q_n:q_n + 6]), torch.zeros(6, dtype=torch.int64, device="cuda"))
-    e = (small - logits[:6]).abs().max().item()
-    print(f"\n[full size] batch-invariance drift {e:.3e}")
-    assert e < LOGIT_TOL["full224"][BF]
+    # batch invariance against a small batch (the other GEMM kernel / tiling): bit for bit, both residual-stream formats
+    for sdt in (None, torch.float32):
+        m2.set_stream_dtype(sdt); m1.set_stream_dtype(sdt)
+        big_t = m2.img_embed16(images[q_n:])
+        big = m2.score(z, ids, mask, big_t, qidx)
+        small_t = m2.img_embed16(images[q_n:q_n + 6])
+        small = m2.score(z[:1], ids[:1], mask[:1], small_t, torch.zeros(6, dtype=torch.int64, device="cuda"))
+        e_t, e = (small_t.float() - big_t[:6].float()).abs().max().item(), (small - big[:6]).abs().max().item()
+        print(f"\n[full size, stream {m2.stream_dtype}] small batch vs large batch: tokens {e_t:.3e} logits {e:.3e}")
+        assert torch.equal(small_t, big_t[:6]) and torch.equal(small, big[:6])
+        # ... and a split of the candidates into two unequal parts (one on each side of the tile heuristic)
+        cut = q_n * k - 37
+        part = torch.cat([m2.score(z, ids, mask, big_t[:cut], qidx[:cut]), m2.score(z, ids, mask, big_t[cut:], qidx[cut:])])
+        assert torch.equal(part, big)
+    m2.set_stream_dtype(None); m1.set_stream_dtype(None)
     # ranking
     lv = logits.view(q_n, k)
     order = ops.argsort_desc(lv)
