@@ -38,7 +38,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2516.6, "f16": 2516.6}  # dense MFMA peak, 256 CU x 2.4 GHz x 4096 flop/clk/CU (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"bf16": 2516.6, "f16": 2516.6, "mixed": 2516.6}  # dense 16-bit MFMA peak, 256 CU x 2.4 GHz x 4096 flop/clk/CU (MI355X_MICROARCH.md)
+_STREAMS = {"f16": ("f16", "f16"), "f32": ("f32", "f32"), "split": ("f32", "f16")}     # name -> (text-side storage, ViT storage)
+
+
+def apply_precision(model, dtype: str, stream: str):
+    """`dtype`: operand precision mode (BLIP_NLVR.set_precision: bf16 / f16 / mixed); `stream`: residual-stream storage -
+    auto (the library's rule), f16, f32, or split (text side fp32, ViT fp16).  Returns the model."""
+    model.set_precision(dtype)
+    if stream == "auto":
+        return model.set_stream_dtype(None, vit=None)
+    t, v = (torch.float16 if x == "f16" else torch.float32 for x in _STREAMS[stream])
+    return model.set_stream_dtype(t, vit=v)
+
+
+def stream_name(model) -> str:
+    """What a run actually used: f16 / f32 / split."""
+    t, v = ("f16" if d == torch.float16 else "f32" for d in (model.stream_dtype, model.vit_stream_dtype))
+    return t if t == v else ("split" if (t, v) == ("f32", "f16") else f"text-{t}+vit-{v}")
+DEFAULT_DTYPE = "f16"
+PRECISION_NOTE = {"f16": "fp16 MFMA operands everywhere, fp32 accumulate (the library's default: holds the reference's rank order - DESIGN.md section 2)",
+                  "bf16": "bf16 MFMA operands everywhere, fp32 accumulate",
+                  "mixed": "bf16 operands for the ViT and the cross-attention block, fp16 for text-side self-attention / FFN / cls_head; fp32 accumulate"}
 D, H, F, LAYERS = 768, 12, 3072, 12
 
 
@@ -490,10 +511,12 @@ def main():
     ap.add_argument("--skip-rate", type=float, default=0.0, help="fraction of queries without a positive in their top-K (skip rule)")
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--tokens", type=int, default=32)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
-    ap.add_argument("--stream-dtype", default="auto", choices=["auto", "f16", "f32"],
-                    help="storage of the residual stream: auto (fp16 with bf16 operands, fp32 with fp16 operands), f16 or f32; "
-                         "sums are formed in fp32 and rounded once per sublayer either way")
+    ap.add_argument("--dtype", default=DEFAULT_DTYPE, choices=["bf16", "f16", "mixed"],
+                    help="MFMA operand precision (fp32 accumulate in all): f16, bf16, or mixed = bf16 for the ViT and the cross-attention "
+                         "block, fp16 for the text-side self-attention / FFN / cls_head (DESIGN.md section 2: rank fidelity per mode)")
+    ap.add_argument("--stream-dtype", default="auto", choices=["auto", "f16", "f32", "split"],
+                    help="storage of the residual stream: auto (the library's rule), f16, f32, or split (text side fp32, ViT fp16); "
+                         "sums are formed in fp32 either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-precision-table", action="store_true", help="skip the short re-runs at the other operand / stream precisions")
     ap.add_argument("--loop-queries", type=int, default=512, help="loop mode: queries of the synthetic split (CIRR val: 4181)")
@@ -541,16 +564,15 @@ def main():
         from candidate_reranking_cir_amd import lib as _lib
         for kv in os.environ["CIR_TUNE"].split(","):
             _lib.set_tuning(*(int(x) for x in kv.split("=")))
-    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     g, v = config.BertGeometry(), config.VitGeometry(image_size=args.image_size)
     m2 = BLIP_NLVR(med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer())
     m2.load_state_dict(weights.synth_state_dict(weights.nlvr_param_spec(g, v), 0, "test"))
     m1 = BLIP_Retrieval(med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer())
     m1.load_state_dict(weights.synth_state_dict(weights.retrieval_param_spec(g, v), 1, "test"))
-    sdt = {"auto": None, "f16": torch.float16, "f32": torch.float32}[args.stream_dtype]
-    m2 = m2.to(dev).eval().set_compute_dtype(dt).set_stream_dtype(sdt)
-    m1 = m1.to(dev).eval().set_compute_dtype(dt).set_stream_dtype(sdt)
-    args.stream_dtype = "f16" if m2.stream_dtype == torch.float16 else "f32"        # what the run actually used
+    m2 = apply_precision(m2.to(dev).eval(), args.dtype, args.stream_dtype)
+    m1 = apply_precision(m1.to(dev).eval(), args.dtype, args.stream_dtype)
+    args.stream_dtype = stream_name(m2)                                              # what the run actually used
+    dt = m2.token_dtype                                                              # 16-bit type of pixels / image tokens in HBM
     m2.engines(); m1.engines()
 
     q_n, k, ns = args.queries, args.k, args.subset
@@ -687,12 +709,11 @@ def main():
     precision = None
     if world == 1 and not args.no_precision_table and not args.no_cpu_baseline:
         precision = {f"{args.dtype}+{args.stream_dtype}_stream": round(total_cand * args.steps / elapsed, 1)}
-        for od, sd_ in (("bf16", "f32"), ("f16", "f32"), ("f16", "f16"), ("bf16", "f16")):
+        for od, sd_ in (("f16", "f16"), ("f16", "split"), ("f16", "f32"), ("mixed", "f16"), ("bf16", "f16"), ("bf16", "f32")):
             if (od, sd_) == (args.dtype, args.stream_dtype):
                 continue
-            odt, sdt_ = (torch.bfloat16 if od == "bf16" else torch.float16), (torch.float32 if sd_ == "f32" else torch.float16)
-            m2.set_compute_dtype(odt).set_stream_dtype(sdt_); m1.set_compute_dtype(odt).set_stream_dtype(sdt_)
-            images_v = images.to(odt)
+            apply_precision(m2, od, sd_); apply_precision(m1, od, sd_)
+            images_v = images.to(m2.token_dtype)
             def vstep():
                 toks = m2.img_embed16(images_v)
                 z = m1.z_t(toks[:q_n], ids, mask)
@@ -704,8 +725,9 @@ def main():
             torch.cuda.synchronize()
             precision[f"{od}+{sd_}_stream"] = round(n_cand * 3 / (time.perf_counter() - tv), 1)
             del images_v
-        precision["note"] = ("triplets/s of the same step at each operand / residual-stream precision (3 steps each; logits drift against the "
-                             "fp32 reference per combination: DESIGN.md section 2, tests/golden/outlier224.npz)")
+        precision["note"] = ("triplets/s of the same step at each operand mode + residual-stream storage (3 steps each; split = text side fp32, "
+                             "ViT fp16).  Rank fidelity of every mode against the reference's fp32 outputs: profiles/r4_precision_modes.json, "
+                             "DESIGN.md section 2")
 
     if rank == 0:
         n_tok = (args.image_size // 16) ** 2 + 1
@@ -743,7 +765,8 @@ def main():
                                    f"{args.tokens}-token captions, {q_n} queries x ({k} candidates + {ns} subset members) per step per GPU, "
                                    f"skip rate {args.skip_rate:g}, random-init weights",
                        "queries_per_step_per_gpu": q_n, "k": k, "subset": ns, "skip_rate": args.skip_rate, "image_size": args.image_size,
-                       "tokens": args.tokens, "triplets_per_step_rank0": n_cand, "residual_stream": args.stream_dtype,
+                       "tokens": args.tokens, "triplets_per_step_rank0": n_cand, "precision_mode": PRECISION_NOTE[args.dtype],
+                       "residual_stream": args.stream_dtype,
                        "parallelism": f"queries sharded over {world} GPU(s) (balanced_order blocks), all-gather of scores+indices"},
             "algorithmic_gflop_per_triplet": round(alg_per_triplet, 2),
             "executed_gflop_per_triplet": round((gemm_flop + attn_flop) / 1e9 / n_cand, 2),

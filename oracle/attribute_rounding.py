@@ -273,13 +273,26 @@ def candidates(go):
     go("C9  fp16 everywhere, fp32 stream", Policy(HF, None))
 
 
+def stream_sites(go):
+    """fp16 operands everywhere; which text-side residual-stream sites need fp32 storage?"""
+    go("S0  fp16 stream everywhere", Policy(HF, HF))
+    txt = lambda ops: (lambda e, l, o, k: k == "s" and e in ("med", "nlvr") and o in ops)
+    for name, ops in (("attention-out sum + LayerNorm (proj)", ("proj",)), ("cross/merge sum + LayerNorm (cproj)", ("cproj",)),
+                      ("FFN-out sum + LayerNorm (fc2)", ("fc2",)), ("z_t / embeddings", ("zt", "emb")),
+                      ("proj + cproj", ("proj", "cproj")), ("cproj + fc2", ("cproj", "fc2")), ("all text-side", ("proj", "cproj", "fc2", "zt", "emb"))):
+        go(f"S   fp32 at: {name}", Policy(HF, HF, [(txt(ops), None)]))
+    nl = lambda e, l, o, k: k == "s" and e == "nlvr"
+    go("S   fp32 at: nlvr only (stage-I stream fp16)", Policy(HF, HF, [(nl, None)]))
+    go("S   fp32 at: nlvr layers 6-11 only", Policy(HF, HF, [(lambda e, l, o, k: k == "s" and e == "nlvr" and l >= 6, None)]))
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "outlier"
     quick = "quick" in sys.argv[2:]
     fx = load_fixture(which)
     max_q = 1 if quick else None
     rows = []
-    if "candidates" in sys.argv[2:]:
+    if "candidates" in sys.argv[2:] or "streams" in sys.argv[2:]:
         def go(name, pol):
             t0 = time.time()
             st = stats(*run(fx, pol, max_q), fx)
@@ -287,8 +300,9 @@ def main():
             rows.append(st)
             print(f"{name:70s} max|d| {st['max_abs']:.2e} centred rms {st['rms_centred']:.2e}  exact {st['exact']:.2f} tau {st['tau']:.3f} "
                   f"top10 {st['top10']:.2f}  ({time.time() - t0:.0f} s)", flush=True)
-        candidates(go)
-        out = os.path.join(ROOT, "profiles", f"r4_precision_candidates_{which}.json")
+        tag = "candidates" if "candidates" in sys.argv[2:] else "streams"
+        (candidates if tag == "candidates" else stream_sites)(go)
+        out = os.path.join(ROOT, "profiles", f"r4_precision_{tag}_{which}.json")
         json.dump(dict(fixture=which, rows=rows), open(out, "w"), indent=1)
         return print("wrote", out)
 

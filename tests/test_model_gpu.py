@@ -25,12 +25,17 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 BF, HF = torch.bfloat16, torch.float16
-TOK_TOL = {BF: 4e-2, HF: 6e-3}
+# Precision modes under test.  BF = bf16 operands + fp16 residual streams (BASELINE's named dtype; round 1-3 headline mode);
+# HF = fp16 operands + fp32 residual streams (the strictest mode: what the fp16 tolerances below were measured on);
+# DEF = the LIBRARY DEFAULT since round 4: fp16 operands + fp16 residual streams (the mode that holds the
+# reference's rank order at >= 16 k triplets/s) - checked on the rank fixtures and the outlier-weight table.
+DEF = "fp16-default"
+TOK_TOL = {BF: 4e-2, HF: 6e-3, DEF: 2.5e-2}
 LOGIT_TOL = {                       # absolute, per fixture (logit sigma over candidates in brackets)
     "full224": {BF: 6e-3, HF: 1.5e-3},          # [0.026]
     "full224_spread": {BF: 4e-2, HF: 4.5e-3},   # [0.345]  (bf16: 1.4e-2 .. 2.7e-2 across the epilogue variants of round 2)
     "full384": {BF: 8e-3, HF: 2e-3},
-    "rank224": {BF: 8e-3, HF: 2e-3},            # [0.14]  (= tol_unit the fixture's label margins were cut with)
+    "rank224": {BF: 8e-3, HF: 2e-3, DEF: 3e-3},  # [0.14]  (BF = tol_unit the fixture's label margins were cut with; DEF measured 1.5e-3)
     "bxb224": {BF: 6e-3, HF: 1.5e-3},           # [0.135]
 }
 REL_TOL = {BF: 0.10, HF: 0.015}     # tiny geometry: |error| <= REL_TOL * sigma(reference logits of that row) [sigma 0.08..0.2; measured 0.039 / 0.006]
@@ -50,8 +55,12 @@ def build_models(g, v, seed, profile, dtype, device, fold_merge=True):
     m2 = BLIP_NLVR(med_config=g, vit_geometry=v, fold_merge=fold_merge, tokenizer=synthetic.HashTokenizer())
     m1 = BLIP_Retrieval(med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer())
     assert m2.load_state_dict(sd2, strict=True) is not None and m1.load_state_dict(sd1, strict=True) is not None
-    m2 = m2.to(device).float().eval().set_compute_dtype(dtype)
-    m1 = m1.to(device).float().eval().set_compute_dtype(dtype)
+    m2, m1 = m2.to(device).float().eval(), m1.to(device).float().eval()
+    for m in (m2, m1):
+        if dtype == DEF:
+            m.set_precision("f16").set_stream_dtype(None, vit=None)          # the library's defaults, spelled out
+        else:
+            m.set_compute_dtype(dtype).set_stream_dtype(torch.float16 if dtype == BF else torch.float32)
     return m2, m1
 
 
@@ -218,6 +227,12 @@ def test_kv_bank_reuse_is_bit_identical(tiny):
     assert len(kvb) == g.num_hidden_layers and kvb[0].shape == (14, v.num_tokens, 4 * g.hidden_size)
     reuse = V.generate_val_predictions(m2, m1, ds, bank, query_batch=3, kv_bank=kvb)
     assert torch.equal(plain[0], reuse[0]) and torch.equal(plain[1], reuse[1])
+    # ... and the bank path itself against the REFERENCE's logits (not only against the other HIP path)
+    ref, gref, skipped = z["cirr_logits"], z["cirr_group_logits"], ~z["labels"].any(1)
+    ours, gours = reuse[0].cpu().numpy(), reuse[1].cpu().numpy()
+    assert np.all(ours[skipped] == np.float32(-99999.99))
+    assert (np.abs(ours[~skipped] - ref[~skipped]) / ref[~skipped].std(axis=1, keepdims=True)).max() < REL_TOL[dt]
+    assert (np.abs(gours - gref) / gref.std(axis=1, keepdims=True)).max() < 2 * REL_TOL[dt]
 
 
 def test_last_layer_cls_trimming_is_equivalent(tiny):
@@ -365,7 +380,7 @@ def test_full_size_properties(cuda):
 
 
 # ------------------------------------------------------------------------------------------------ rank order at K = 100 / 50 / 200
-@pytest.fixture(scope="module", params=[BF, HF], ids=["bf16", "fp16"])
+@pytest.fixture(scope="module", params=[BF, HF, DEF], ids=["bf16", "fp16", "default"])
 def rank(request, cuda):
     from candidate_reranking_cir_amd import validate_stage2 as V
     z = H.load("rank224.npz")
@@ -418,7 +433,7 @@ def test_rank_order_cirr_k100_k200(rank, tag):
     print(f"\n[rank224 {tag} {dt}]")
     n_fix = _rank_asserts(tag, logits[~skipped], ref[~skipped], tol)
     _rank_asserts(tag + " subset", glogits, gref, tol, min_decided_frac=0.5)
-    assert n_fix >= {"c100": {BF: 2, HF: 20}, "c200": {BF: 0, HF: 8}}[tag][dt]      # (measured 4 / 31 and 0 / 12)
+    assert n_fix >= {"c100": {BF: 2, HF: 20, DEF: 8}, "c200": {BF: 0, HF: 8, DEF: 2}}[tag][dt]      # (measured 4 / 31 and 0 / 12)
     # the target scored as a top-K candidate and as a subset member is the same image through the same z_t
     for q in np.where(~skipped)[0]:
         ci, gi = int(z[f"{tag}_labels"][q].argmax()), int(np.where(z[f"{tag}_groups"][q] == z[f"{tag}_targets"][q])[0][0])
@@ -427,6 +442,27 @@ def test_rank_order_cirr_k100_k200(rank, tag):
     ours = V.compute_cirr_val_metrics(logits_t, glogits_t, ds)
     print("   recall ours", np.round(ours, 2), "reference", np.round(z[f"{tag}_metrics"], 2))
     np.testing.assert_allclose(ours, z[f"{tag}_metrics"], atol=1e-4)
+
+
+def test_rank_kv_bank_path_against_reference(rank):
+    """SURVEY 8(f)-1 at the benchmark geometry: K = 100 (+5) scored straight out of the per-image K/V bank of the 256-image
+    index (224 px, 197 tokens) - against the reference's own logits, and bit for bit against the per-candidate path."""
+    from candidate_reranking_cir_amd import validate_stage2 as V
+    z, m2, m1, bank, dt = rank
+    ds = V.RelativeValSet(ref_index=z["c100_refs"], cand_index=z["c100_cand"], labels=z["c100_labels"],
+                          captions=[str(c) for c in z["c100_caps"]], group_index=z["c100_groups"], target_index=z["c100_targets"])
+    kvb = m2.build_kv_bank(bank)
+    lt, gt = V.generate_cirr_val_predictions(m2, m1, ds, bank, query_batch=4, kv_bank=kvb)
+    plain = V.generate_cirr_val_predictions(m2, m1, ds, bank, query_batch=4)
+    assert torch.equal(lt, plain[0]) and torch.equal(gt, plain[1])
+    del kvb
+    ref, gref, skipped = z["c100_logits"], z["c100_group_logits"], ~z["c100_labels"].any(1)
+    logits = lt.cpu().numpy()
+    assert np.array_equal(logits[skipped], ref[skipped])
+    e = max(np.abs(logits[~skipped] - ref[~skipped]).max(), np.abs(gt.cpu().numpy() - gref).max())
+    print(f"\n[rank224 c100 K/V bank {dt}] max|dlogit| vs reference {e:.3e}")
+    assert e < LOGIT_TOL["rank224"][dt]
+    np.testing.assert_allclose(V.compute_cirr_val_metrics(lt, gt, ds), z["c100_metrics"], atol=1e-4)
 
 
 def test_rank_order_fiq_k50(rank):
@@ -454,9 +490,11 @@ def order_stats(ours: np.ndarray, ref: np.ndarray):
 RANK_FLOORS = {          # (exact-position fraction, Kendall tau, top-10 overlap) floors = measured on MI355X minus ~10 %:
     # measured       bf16: c100 0.752 / 0.9933 / 0.97   c200 0.510 / 0.9915 / 0.95   f50 0.827 / 0.9924 / 1.00
     #                fp16: c100 0.945 / 0.9989 / 1.00   c200 0.927 / 0.9992 / 1.00   f50 0.987 / 0.9995 / 1.00
-    "c100": {BF: (0.67, 0.989, 0.87), HF: (0.85, 0.997, 0.9)},
-    "c200": {BF: (0.45, 0.987, 0.85), HF: (0.83, 0.997, 0.9)},
-    "f50": {BF: (0.74, 0.988, 0.9), HF: (0.88, 0.997, 0.9)},
+    #             default (fp16 operands + fp16 streams, round 4): c100 0.932 / 0.9985 / 0.97 - the floor there is the acceptance bar of
+    #             the round-3 review: >= 0.90 of the sorted positions hold exactly the reference's candidate at K = 100
+    "c100": {BF: (0.67, 0.989, 0.87), HF: (0.85, 0.997, 0.9), DEF: (0.90, 0.997, 0.9)},
+    "c200": {BF: (0.45, 0.987, 0.85), HF: (0.83, 0.997, 0.9), DEF: (0.78, 0.996, 0.9)},
+    "f50": {BF: (0.74, 0.988, 0.9), HF: (0.88, 0.997, 0.9), DEF: (0.88, 0.997, 0.9)},
 }
 
 
@@ -518,7 +556,7 @@ def test_vit_large_width(cuda, dtype):
     spec = {k: sh for k, sh in weights.nlvr_param_spec(config.BertGeometry(encoder_width=1024), v).items() if k.startswith("visual_encoder.")}
     sd = weights.synth_state_dict(spec, 5, "test")
     imgs = synthetic.scene_images(range(3), 224)
-    eng = VitEngine({k: t.cuda() for k, t in sd.items()}, v, dtype, cuda)
+    eng = VitEngine({k: t.cuda() for k, t in sd.items()}, v, dtype, cuda, stream_dtype=torch.float16 if dtype == torch.bfloat16 else torch.float32)
     y32, y16 = eng.forward(imgs.cuda(), want32=True)
     with torch.no_grad():
         ref = O.vit_forward(sd, imgs, n_heads=16)
