@@ -75,6 +75,25 @@ def ln(w, key, x, eps):
     return F.layer_norm(x, (x.shape[-1],), w[key + ".weight"], w[key + ".bias"], eps)
 
 
+FOLD_LN = [False]     # emulate the LayerNorm fold of the ViT: the consuming GEMM runs on the RAW fp16 stream with weights W o gamma
+
+
+def ln_lin_fold(w, ln_key, lin_key, x, eps, site_op):
+    """LN(x) W^T + b as rstd * (x W'^T - mu s) + b', W' = round16(W o gamma), s = row sums of W', b' = b + W beta (fp32):
+    what a GEMM on the raw residual stream computes when the statistics arrive separately (LayerNorm fold)."""
+    eng, layer, op = site_op
+    dt = POL[0](eng, layer, op, "w")
+    g, be = w[ln_key + ".weight"], w[ln_key + ".bias"]
+    W = w[lin_key + ".weight"]
+    Wp = W * g[None, :]
+    Wp = Wp if dt is None else Wp.to(dt).float()
+    s = Wp.sum(1)
+    bp = w[lin_key + ".bias"] + W @ be
+    mu = x.mean(-1, keepdim=True)
+    rstd = torch.rsqrt(x.var(-1, unbiased=False, keepdim=True) + eps)
+    return rstd * (x @ Wp.t() - mu * s) + bp
+
+
 def vit(w, image, prefix="visual_encoder.", eps=1e-6):
     E = "vit"
     pw = w[prefix + "patch_embed.proj.weight"]
@@ -88,16 +107,22 @@ def vit(w, image, prefix="visual_encoder.", eps=1e-6):
     x = rq(x, (E, -1, "patch", "s"))
     for i in range(12):
         p = f"{prefix}blocks.{i}."
-        y = rq(ln(w, p + "norm1", x, eps), (E, i, "qkv", "a"))
-        qkv = rq(lin(w, p + "attn.qkv", y, (E, i, "qkv")), (E, i, "qkv", "o"))
+        if FOLD_LN[0]:
+            qkv = rq(ln_lin_fold(w, p + "norm1", p + "attn.qkv", x, eps, (E, i, "qkv")), (E, i, "qkv", "o"))
+        else:
+            y = rq(ln(w, p + "norm1", x, eps), (E, i, "qkv", "a"))
+            qkv = rq(lin(w, p + "attn.qkv", y, (E, i, "qkv")), (E, i, "qkv", "o"))
         n = qkv.shape[1]
         qkv = qkv.reshape(b, n, 3, nh, 64).permute(2, 0, 3, 1, 4)
         a = (qkv[0] @ qkv[1].transpose(-2, -1)) * 0.125
         a = rq(a.softmax(dim=-1), (E, i, "attn", "p"))
         y = rq((a @ qkv[2]).transpose(1, 2).reshape(b, n, d), (E, i, "attn", "o"))
         x = rq(x + lin(w, p + "attn.proj", y, (E, i, "proj")), (E, i, "proj", "s"))
-        y = rq(ln(w, p + "norm2", x, eps), (E, i, "fc1", "a"))
-        f = rq(F.gelu(lin(w, p + "mlp.fc1", y, (E, i, "fc1"))), (E, i, "fc1", "o"))
+        if FOLD_LN[0]:
+            f = rq(F.gelu(ln_lin_fold(w, p + "norm2", p + "mlp.fc1", x, eps, (E, i, "fc1"))), (E, i, "fc1", "o"))
+        else:
+            y = rq(ln(w, p + "norm2", x, eps), (E, i, "fc1", "a"))
+            f = rq(F.gelu(lin(w, p + "mlp.fc1", y, (E, i, "fc1"))), (E, i, "fc1", "o"))
         x = rq(x + lin(w, p + "mlp.fc2", f, (E, i, "fc2")), (E, i, "fc2", "s"))
     return ln(w, prefix + "norm", x, eps)            # fp32 tokens; their 16-bit copy is rounded where it is consumed ("tokens")
 
@@ -205,7 +230,7 @@ def run(fx, pol, max_q=None):
     with torch.no_grad():
         used = sorted(set(fx["refs"].tolist()) | set(fx["cand"].ravel().tolist()) | set(fx["groups"].ravel().tolist()))
         row = {j: i for i, j in enumerate(used)}
-        sig = tuple(str(pol("vit", l, o, k)) for l in (-1, 0, 5, 11) for o in ("patch", "qkv", "attn", "proj", "fc1", "fc2") for k in "awops")
+        sig = (FOLD_LN[0],) + tuple(str(pol("vit", l, o, k)) for l in (-1, 0, 5, 11) for o in ("patch", "qkv", "attn", "proj", "fc1", "fc2") for k in "awops")
         if sig not in fx.setdefault("_banks", {}):       # most runs differ only in the fusion part: one ViT pass per distinct ViT policy
             fx["_banks"][sig] = torch.cat([vit(fx["sd2"], fx["imgs"][used[i:i + 32]]) for i in range(0, len(used), 32)])
         bank = fx["_banks"][sig]
@@ -292,6 +317,13 @@ def main():
     fx = load_fixture(which)
     max_q = 1 if quick else None
     rows = []
+    if "fold" in sys.argv[2:]:
+        for fold in (False, True):
+            FOLD_LN[0] = fold
+            st = stats(*run(fx, Policy(HF, HF), max_q), fx)
+            print(f"fp16 operands + fp16 streams, ViT LayerNorm fold {fold}: max|d| {st['max_abs']:.2e} centred rms {st['rms_centred']:.2e} exact {st['exact']:.3f} "
+                  f"tau {st['tau']:.4f} top10 {st['top10']:.2f}", flush=True)
+        return
     if "candidates" in sys.argv[2:] or "streams" in sys.argv[2:]:
         def go(name, pol):
             t0 = time.time()

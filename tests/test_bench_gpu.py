@@ -29,7 +29,8 @@ def test_single_rank_contract_line():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in d
-    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["value"] > 0 and d["unit"] == "triplets/s" and d["dtype"] == "bf16"
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["value"] > 0 and d["unit"] == "triplets/s" and d["dtype"] == "f16"
+    assert d["config"]["precision_mode"].startswith("fp16 MFMA operands") and d["config"]["residual_stream"] == "f16"     # the library default
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert rf["kernel"].startswith("cir::gemm") and "traffic" in rf and rf["all_gemm_kernels"]["launches_per_step"] > 100
