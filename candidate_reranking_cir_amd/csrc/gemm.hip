@@ -116,7 +116,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
     const int nk = a.K / BK;
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();  // (vmcnt(0) + barrier) tile kt landed everywhere; buffer (kt+1)&1 is free again
+        // The LDS-DMA pieces of tile kt must have landed before any wave reads them.  The wait is EXPLICIT: hipcc's wait-count
+        // pass dropped the vmcnt(0) it used to put in front of this barrier once a VGPR-destination load (the bias) preceded
+        // the loop (round 4: every K >= 128 result wrong, K = 64 right) - do not rely on it for DMA-written LDS.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // tile kt landed everywhere; buffer (kt+1)&1 is free again
         if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
         const char* As = smem + (kt & 1) * 2 * kTileBytes;
         const char* Ws = As + kTileBytes;
