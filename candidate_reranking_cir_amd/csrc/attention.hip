@@ -34,6 +34,17 @@
 //     max(r.x, r.y) of the builtin's two results into one of them when both inputs are the same register: wrong values).
 //   * two key tiles per update (one running-max / rescale / exchange step per 64 keys, two independent score chains, +24
 //     registers = exactly the 128 that keep 4 waves per SIMD, 2 spilled): 689 us - slower.
+// Measured and dropped in round 4 (same shape; tools/attn_layout_probe.py, profiles/r4_secondary/attn_layout_probe.txt):
+//   * a TWO-PASS kernel without the online softmax: 16 queries per wave on mfma_f32_16x16x32, the scores of all <= 224 keys in 56
+//     registers, one row maximum / sum (two cross-lane steps each), 28 + 28 independent MFMAs, P^T fed to the second product straight
+//     from the accumulators by defining the B operand's k-slots as [tile 2b keys 4g.. | tile 2b+1 keys 4g..] and reading V^T with the
+//     same map through two ds_read_b64_tr_b16 (V rows XOR-swizzled on row bits 1 and 2: conflict-free); 90 registers, no spills,
+//     correct to the online kernel's error on the first run.  Alone: 608 us against 679 us (fp16; 603 / 659 bf16); in the benchmark
+//     step: 60.1 ms of attention kernels against 60.6 ms - nothing.  With the fused QKV tensor stored HEAD-MAJOR ((36, M, 64): a
+//     head's K of one image = 25 KB contiguous instead of 128-byte pieces 4608 bytes apart) both kernels take 598 us.  Three
+//     structures (staged online, streamed ring, two-pass) and two layouts all end at 590-680 us = 3.0-3.5 TB/s for the 2.05 GB the
+//     kernel must move: neither the softmax chain nor the DRAM access pattern is the bound; a workgroup's life is load 82 KB ->
+//     compute -> store with two or three workgroups per CU to overlap, and the time is their sum, not their maximum.
 
 #include "common.hpp"
 
@@ -296,175 +307,6 @@ __global__ __launch_bounds__(1024) void attn_shared_kernel(const AttnArgs a, int
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// attn_two_pass_kernel (round 4): unmasked attention over at most 224 keys (the 197-token ViT of the benchmark) WITHOUT the
-// online softmax.  One wave owns 16 queries and keeps the scores of ALL keys in registers (14 tiles of 16 keys x 16 queries from
-// mfma_f32_16x16x32: 56 registers), so a row's maximum and sum are taken ONCE: 28 independent score MFMAs, one max tree + two
-// cross-lane steps, 56 independent exponentials, one sum, then 28 independent P.V MFMAs - no running maximum, no rescale of O,
-// no serial tile-to-tile chain (the staged online kernel spends ~1.4 k cycles of latency per 520 cycles of issue in that chain
-// and its 3.5 waves per SIMD hide half of it: VALU busy 48 %, matrix pipe 19 %).
-//   S^T tile t:  A = K rows t*16 + i (lane i = lane & 15, d-chunk g = lane >> 4: ds_read_b128, conflict-free with the staged
-//                K image's swizzle), B = Q^T (lane = query, d-chunk g) -> lane (query, g) holds keys t*16 + 4g .. 4g+3.
-//   O^T += V^T P^T over 32-key blocks (tiles 2b, 2b+1): the B operand's k-slots 8g .. 8g+7 of lane (query, g) are DEFINED as
-//                [tile 2b keys 4g..4g+3 | tile 2b+1 keys 4g..4g+3] = the lane's own packed probabilities (no data movement),
-//                and the A operand V^T takes the same k <-> key map from two ds_read_b64_tr_b16 (4 keys x 16 dh blocks at
-//                rows 4g.. of each tile).  V rows are 128 B with the byte column XORed by ((row>>1)&1)<<6 | ((row>>2)&1)<<5:
-//                the eight 4-key blocks a 32-lane half reads then sit on 64 distinct banks.
-// Keys >= Lk: their K / V rows are clamped copies of the last row (finite), their scores are set to -inf (p = 0).
-// QSPLIT = 2: the queries of one (item, head) are dealt to TWO workgroups of half the waves (blocks i and i + 8: the same XCD, so the
-// second staging of the head's K / V is an L2 hit) - two to three workgroups then share a CU and one's staging loads overlap
-// another's arithmetic; with all 13 waves in one workgroup a CU holds a single workgroup (20 wave slots at 90 registers).
-template <typename T, int QSPLIT>
-__global__ __launch_bounds__(896) void attn_two_pass_kernel(const AttnArgs a) {
-    using X8 = typename Elem<T>::x8;
-    constexpr int NT = 14, LKP = NT * 16;                       // 16-key tiles, padded key count
-    __shared__ __attribute__((aligned(16))) char smem[2 * LKP * 128];
-    char* const Ks = smem;
-    char* const Vs = smem + LKP * 128;
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int64_t t = blockIdx.x;
-    int part = 0;
-    if constexpr (QSPLIT == 2) {                               // blocks i and i + 8 of a group of 16 = the two halves of one unit
-        const int64_t grp = t >> 4;
-        const int r16 = (int)(t & 15);
-        part = r16 >> 3;
-        t = grp * 8 + (r16 & 7);
-        if (t >= a.total) return;                               // (a.total = number of (item, head) units here; whole block leaves)
-    }
-    const int h = (int)(t % a.H);
-    t /= a.H;
-    const int b0 = (int)(t % a.B0);
-    const int64_t b1 = t / a.B0;
-    const int64_t kb1 = a.kv_index ? a.kv_index[b1] : b1;
-    const T* kb = reinterpret_cast<const T*>(a.k) + kb1 * a.k_s1 + b0 * a.k_s0 + h * 64;
-    const T* vb = reinterpret_cast<const T*>(a.v) + kb1 * a.v_s1 + b0 * a.v_s0 + h * 64;
-
-    const int n = lane & 15, g = lane >> 4;
-    const int q0 = (part * (int)(blockDim.x >> 6) + wave) * 16;
-    // Q^T fragments (B operand: lane = query n, d = 8g + 32 ks), requested before the staging so that their latency hides under it
-    X8 qf[2];
-    {
-        const int qrow = min(q0 + n, a.Lq - 1);
-        const T* qp = reinterpret_cast<const T*>(a.q) + b1 * a.q_s1 + b0 * a.q_s0 + (int64_t)qrow * a.q_rs + h * 64 + 8 * g;
-        qf[0] = *reinterpret_cast<const X8*>(qp);
-        qf[1] = *reinterpret_cast<const X8*>(qp + 32);
-    }
-    // ---- stage K (slot = chunk ^ ((row>>1)&7)) and V (byte column ^ bit1<<6 ^ bit2<<5): all loads of a thread in flight first ----
-    {
-        constexpr int SB = 5;                                   // 224 rows x 8 chunks = 1792 chunks over >= 704 threads: <= 3 per thread
-        const int stride = blockDim.x;
-        X8 kv[SB], vv[SB];
-#pragma unroll
-        for (int i = 0; i < SB; ++i) {
-            const int c = threadIdx.x + i * stride;
-            const int row = min(c >> 3, a.Lk - 1), ch = c & 7;  // rows >= Lk: copies of the last key (finite; masked below)
-            if (c < LKP * 8) {
-                kv[i] = *reinterpret_cast<const X8*>(kb + (int64_t)row * a.k_rs + ch * 8);
-                vv[i] = *reinterpret_cast<const X8*>(vb + (int64_t)row * a.v_rs + ch * 8);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < SB; ++i) {
-            const int c = threadIdx.x + i * stride;
-            const int row = c >> 3, ch = c & 7;
-            if (c < LKP * 8) {
-                *reinterpret_cast<X8*>(Ks + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = kv[i];
-                *reinterpret_cast<X8*>(Vs + row * 128 + ((ch * 16) ^ (((row >> 1) & 1) << 6) ^ (((row >> 2) & 1) << 5))) = vv[i];
-            }
-        }
-    }
-    __syncthreads();
-    if (q0 >= a.Lq) return;                                     // a whole wave without queries (wave-uniform: EXEC stays all ones for the others)
-
-    // ---- pass 1: all scores -----------------------------------------------------------------------------------------------
-    const int nt = (a.Lk + 15) >> 4;                            // tiles that hold at least one real key (wave-uniform)
-    const char* const kr = Ks + n * 128;
-    const int kc0 = ((g ^ ((n >> 1) & 7)) << 4), kc1 = (((4 + g) ^ ((n >> 1) & 7)) << 4);   // tile bases are multiples of 16 rows: swizzle is lane-constant
-    f32x4 sc[NT];
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt) {
-        sc[tt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        if (tt < nt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const X8 k0 = *reinterpret_cast<const X8*>(kr + tt * 2048 + kc0);
-            const X8 k1 = *reinterpret_cast<const X8*>(kr + tt * 2048 + kc1);
-            acc = Elem<T>::mfma16(k0, qf[0], acc);
-            acc = Elem<T>::mfma16(k1, qf[1], acc);
-            if (tt * 16 + 16 > a.Lk) {                          // the ragged tile (wave-uniform)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = (tt * 16 + 4 * g + j) < a.Lk ? acc[j] : -INFINITY;
-            }
-            sc[tt] = acc;
-        }
-    }
-    // ---- row maximum (raw scores; the scale is positive and rides in the exponent's FMA) -------------------------------------
-    float mx = -INFINITY;
-#pragma unroll
-    for (int tt = 0; tt < NT; ++tt) mx = fmaxf(fmaxf(mx, fmaxf(sc[tt][0], sc[tt][1])), fmaxf(sc[tt][2], sc[tt][3]));
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float sl = a.scale * kLog2e;
-    const f32x2 sl2 = {sl, sl}, m2 = {-mx * sl, -mx * sl};
-    // ---- pass 2: probabilities, row sum, O^T += V^T P^T per 32-key block --------------------------------------------------------
-    int voff[4];
-    {
-        const int qq = n >> 2, p = n & 3;
-        const int x = (((qq >> 1) & 1) << 6) ^ ((g & 1) << 5);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) voff[dt] = (4 * g + qq) * 128 + ((dt * 32) ^ x) + 8 * p;
-    }
-    f32x4 o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x2 lsum = {0.f, 0.f};
-#pragma unroll
-    for (int b = 0; b < NT / 2; ++b) {
-        if (2 * b < nt) {                                       // wave-uniform: blocks without a real key contribute nothing
-            X8 pf;
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const f32x4 sv = sc[2 * b + half];
-                f32x2 a0 = __builtin_elementwise_fma(f32x2{sv[0], sv[1]}, sl2, m2);
-                f32x2 a1 = __builtin_elementwise_fma(f32x2{sv[2], sv[3]}, sl2, m2);
-                f32x2 p0, p1;
-                p0.x = __builtin_amdgcn_exp2f(a0.x); p0.y = __builtin_amdgcn_exp2f(a0.y);
-                p1.x = __builtin_amdgcn_exp2f(a1.x); p1.y = __builtin_amdgcn_exp2f(a1.y);
-                lsum += p0;
-                lsum += p1;
-                pf[4 * half + 0] = static_cast<T>(p0.x); pf[4 * half + 1] = static_cast<T>(p0.y);
-                pf[4 * half + 2] = static_cast<T>(p1.x); pf[4 * half + 3] = static_cast<T>(p1.y);
-            }
-            const char* const vt = Vs + b * 4096;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vt + voff[dt]));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vt + 2048 + voff[dt]));
-                s16x8 both;
-                both.s0 = lo.x; both.s1 = lo.y; both.s2 = lo.z; both.s3 = lo.w;
-                both.s4 = hi.x; both.s5 = hi.y; both.s6 = hi.z; both.s7 = hi.w;
-                o[dt] = Elem<T>::mfma16(__builtin_bit_cast(X8, both), pf, o[dt]);
-            }
-        }
-    }
-    float l = lsum.x + lsum.y;
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    // ---- O^T[d = 16 dt + 4g + j][query n] / l  ->  out[query][h*64 + d] ---------------------------------------------------
-    if (q0 + n < a.Lq) {
-        const float inv = 1.0f / l;
-        T* op = reinterpret_cast<T*>(a.out) + b1 * a.o_s1 + b0 * a.o_s0 + (int64_t)(q0 + n) * a.o_rs + h * 64 + 4 * g;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            u32x2 pk;
-            pk.x = pack2<T>(o[dt][0] * inv, o[dt][1] * inv);
-            pk.y = pack2<T>(o[dt][2] * inv, o[dt][3] * inv);
-            *reinterpret_cast<u32x2*>(op + dt * 16) = pk;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 template <typename T, bool MASKED>
 __global__ __launch_bounds__(256) void attn_stream_kernel(const AttnArgs a) {
     using X8 = typename Elem<T>::x8;
@@ -720,23 +562,6 @@ extern "C" int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t 
     // (up to 608 keys = 152 KiB of LDS: the 577-token ViT of the reference's 384-px scripts still fits one CU)
     const int shared_max = g_tune[CIR_TUNE_ATTN_SHARED_MAX] == 0 ? 608 : g_tune[CIR_TUNE_ATTN_SHARED_MAX];   // (-1: never)
     const bool shared = a.nqt >= 2 && lk_pad <= shared_max;
-    // unmasked, <= 224 keys and <= 224 queries (the 197-token ViT): the two-pass kernel - 16 queries per wave, all scores in registers
-    if (shared && mask == nullptr && Lk <= 224 && Lq <= 224 && Lq > 32 && g_tune[CIR_TUNE_ATTN_TWO_PASS] != -1) {
-        const int64_t units = (int64_t)B1 * B0 * H;
-        if (units > 0x3fffffff) return CIR_ESHAPE;
-        const int nq16 = (Lq + 15) / 16;
-        a.total = units;
-        if (g_tune[CIR_TUNE_ATTN_TWO_PASS] == 1) {             // one workgroup per unit
-            dim3 grid((unsigned)units), block((unsigned)(nq16 * 64));
-            if (dtype == CIR_BF16) hipLaunchKernelGGL((attn_two_pass_kernel<__bf16, 1>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((attn_two_pass_kernel<_Float16, 1>), grid, block, 0, s, a);
-        } else {                                                // two workgroups per unit (groups of 16 blocks = 8 units)
-            dim3 grid((unsigned)(((units + 7) / 8) * 16)), block((unsigned)(((nq16 + 1) / 2) * 64));
-            if (dtype == CIR_BF16) hipLaunchKernelGGL((attn_two_pass_kernel<__bf16, 2>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((attn_two_pass_kernel<_Float16, 2>), grid, block, 0, s, a);
-        }
-        CIR_LAUNCH_RESULT();
-    }
     if (shared) {
         const int64_t nblk = (int64_t)B1 * B0 * H;
         if (nblk > 0x7fffffff) return CIR_ESHAPE;

@@ -176,7 +176,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // ---- host side ----------------------------------------------------------------------------------
 namespace cir {
 // kernel-selection overrides (cir_set_tuning; misc.hip owns the storage): 0 = automatic
-extern int g_tune[4];
+extern int g_tune[3];
 }  // namespace cir
 #define CIR_CHECK_PTR(p) do { if ((p) == nullptr) return CIR_EINVAL; } while (0)
 #define CIR_LAUNCH_RESULT() do { hipError_t e_ = hipGetLastError(); return e_ == hipSuccess ? CIR_OK : (int)e_; } while (0)

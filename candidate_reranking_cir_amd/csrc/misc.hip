@@ -237,14 +237,13 @@ __global__ __launch_bounds__(256) void topk_desc_kernel(const float* logits, int
 
 extern "C" int cir_version(void) { return CIR_ABI_VERSION; }
 
-namespace cir { int g_tune[4] = {0, 0, 0, 0}; }
+namespace cir { int g_tune[3] = {0, 0, 0}; }
 
 extern "C" int cir_set_tuning(int knob, int value) {
     switch (knob) {
         case CIR_TUNE_GEMM_TILE: if (value != 0 && value != 128 && value != 256) return CIR_EINVAL; break;
         case CIR_TUNE_GEMM_GROUP_W: if (value < 0 || value > 64) return CIR_EINVAL; break;
         case CIR_TUNE_ATTN_SHARED_MAX: if (value != 0 && value != -1 && (value < 32 || value > 608)) return CIR_EINVAL; break;
-        case CIR_TUNE_ATTN_TWO_PASS: if (value != 0 && value != -1 && value != 1) return CIR_EINVAL; break;
         default: return CIR_EINVAL;
     }
     cir::g_tune[knob] = value;

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CIR_LIB", os.path.join(_HERE, "libcirrank.so"))   # CIR_LIB: A/B a second build
 
 CIR_BF16, CIR_F16, CIR_F32 = 0, 1, 2
-TUNE_GEMM_TILE, TUNE_GEMM_GROUP_W, TUNE_ATTN_SHARED_MAX, TUNE_ATTN_TWO_PASS = 0, 1, 2, 3   # cir_set_tuning knobs (tests / A-B only)
+TUNE_GEMM_TILE, TUNE_GEMM_GROUP_W, TUNE_ATTN_SHARED_MAX = 0, 1, 2   # cir_set_tuning knobs (tests / A-B only)
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 # name -> argtypes; mirrors include/cirrank.h declaration by declaration

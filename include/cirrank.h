@@ -58,10 +58,8 @@ const char* cir_strerror(int code);
  *   CIR_TUNE_GEMM_GROUP_W     0 auto | 1..64    : n-panels per raster group of the 256x256 kernel
  *   CIR_TUNE_ATTN_SHARED_MAX  0 auto (608) | -1 never | 32..608 : largest padded key count for which
  *                             cir_attention stages a head's K/V once per workgroup in LDS
- *   CIR_TUNE_ATTN_TWO_PASS    0 auto (on, two workgroups per head) | 1 one workgroup per head | -1 off : the two-pass kernel
- *                             for unmasked attention over <= 224 keys (ViT at 224 px); off = the staged online-softmax kernel
  */
-enum { CIR_TUNE_GEMM_TILE = 0, CIR_TUNE_GEMM_GROUP_W = 1, CIR_TUNE_ATTN_SHARED_MAX = 2, CIR_TUNE_ATTN_TWO_PASS = 3 };
+enum { CIR_TUNE_GEMM_TILE = 0, CIR_TUNE_GEMM_GROUP_W = 1, CIR_TUNE_ATTN_SHARED_MAX = 2 };
 int cir_set_tuning(int knob, int value);
 
 /*

@@ -490,11 +490,12 @@ def order_stats(ours: np.ndarray, ref: np.ndarray):
 RANK_FLOORS = {          # (exact-position fraction, Kendall tau, top-10 overlap) floors = measured on MI355X minus ~10 %:
     # measured       bf16: c100 0.752 / 0.9933 / 0.97   c200 0.510 / 0.9915 / 0.95   f50 0.827 / 0.9924 / 1.00
     #                fp16: c100 0.945 / 0.9989 / 1.00   c200 0.927 / 0.9992 / 1.00   f50 0.987 / 0.9995 / 1.00
-    #             default (fp16 operands + fp16 streams, round 4): c100 0.932 / 0.9985 / 0.97 - the floor there is the acceptance bar of
-    #             the round-3 review: >= 0.90 of the sorted positions hold exactly the reference's candidate at K = 100
+    #             default (fp16 operands + fp16 streams, round 4): c100 0.922-0.932 / 0.9984 / 1.00   c200 0.775 / 0.9974 / 1.00
+    #             f50 0.940 / 0.9962 / 1.00 - the c100 floor is the acceptance bar of the round-3 review: >= 0.90 of the sorted positions
+    #             hold exactly the reference's candidate at K = 100
     "c100": {BF: (0.67, 0.989, 0.87), HF: (0.85, 0.997, 0.9), DEF: (0.90, 0.997, 0.9)},
-    "c200": {BF: (0.45, 0.987, 0.85), HF: (0.83, 0.997, 0.9), DEF: (0.78, 0.996, 0.9)},
-    "f50": {BF: (0.74, 0.988, 0.9), HF: (0.88, 0.997, 0.9), DEF: (0.88, 0.997, 0.9)},
+    "c200": {BF: (0.45, 0.987, 0.85), HF: (0.83, 0.997, 0.9), DEF: (0.72, 0.996, 0.9)},
+    "f50": {BF: (0.74, 0.988, 0.9), HF: (0.88, 0.997, 0.9), DEF: (0.88, 0.995, 0.9)},
 }
 
 

@@ -456,34 +456,3 @@ def test_gemm_tile_choice_is_bit_invariant(ops, dtype, case):
         ref = mid + kw["residual"].float()
         ulp_of = lambda t: torch.maximum(t.abs(), torch.tensor(2.0 ** -14, device="cuda")).log2().floor().exp2() * 2.0 ** -10
         assert bool(((outs[128].float() - ref).abs() <= ulp_of(mid) * 0.51 + ulp_of(ref) * 0.51 + 1e-5).all())
-
-
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
-@pytest.mark.parametrize("lq,lk", [(197, 197), (224, 224), (33, 40), (100, 17), (209, 208), (64, 193)])
-def test_attention_two_pass_kernel(ops, dtype, lq, lk):
-    """Unmasked attention over <= 224 keys (the 197-token ViT) runs on the two-pass kernel - 16 queries per wave, every score of a
-    row in registers, ONE max / sum per row, no online rescale - in its two launch shapes (one or two workgroups per head);
-    against fp32 torch and against the staged online-softmax kernel (the same arithmetic up to the order of the row sums)."""
-    from candidate_reranking_cir_amd import lib
-    b, h = 3, 4
-    gen = torch.Generator(device="cpu").manual_seed(lq * 1000 + lk)
-    q = (torch.randn((b, lq, h * 64), generator=gen) * 1.5).to(dtype).cuda()
-    kv = (torch.randn((b, lk, 2, h * 64), generator=gen) * 1.5).to(dtype).cuda()
-    k, v = kv[:, :, 0], kv[:, :, 1]                                  # strided rows, like the fused QKV tensor of the ViT
-    outs = {}
-    try:
-        for mode in (-1, 0, 1):
-            lib.set_tuning(lib.TUNE_ATTN_TWO_PASS, mode)
-            ctx = torch.full((b, 1, lq, h * 64), float("nan"), dtype=dtype, device="cuda")
-            ops.attention(q.unsqueeze(1), k.unsqueeze(1), v.unsqueeze(1), ctx, 0.125)
-            outs[mode] = ctx[:, 0].float()
-    finally:
-        lib.set_tuning(lib.TUNE_ATTN_TWO_PASS, 0)
-    qh, kh, vh = (t.float().reshape(b, -1, h, 64).transpose(1, 2) for t in (q, k, v))
-    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, -1) @ vh).transpose(1, 2).reshape(b, lq, h * 64)
-    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
-    for mode in (0, 1):
-        assert torch.isfinite(outs[mode]).all()
-        assert (outs[mode] - ref).abs().max().item() < tol
-        assert (outs[mode] - outs[-1]).abs().max().item() < tol / 2
-    assert torch.equal(outs[0], outs[1])                                 # the split only changes which workgroup owns a query tile
