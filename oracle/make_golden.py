@@ -550,6 +550,44 @@ def train_goldens(R, full_bert):
           "norm range", min(norms), max(norms))
 
 
+def train_goldens_197(R, full_bert):
+    """tests/golden/train197.npz: the same one-step fixture at the benchmark's token geometry - B = 8 ragged captions (64 triplets),
+    197 image tokens per target (224 px) - so that the backward products run at extents where the 128-tile / split-row / candidate-
+    major paths of cir_bmm are the ones taken.  The step's inputs (z_t, target tokens) are INPUTS of img_txt_fusion, not model
+    outputs, so they are seeded normal tensors the test regenerates (nothing large is stored); dropout 0, fp32 CPU reference."""
+    cfg = dict(full_bert, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    vit = dict(image_size=224, width=768, depth=1, num_heads=12)                  # the ViT is not run: geometry only
+    m2, m1, g, v = build_reference_models(R, cfg, vit, seed=13, profile="test")
+    b, n_tok = 8, 197
+    caps = [synthetic.caption_text(170 + i, n) for i, n in enumerate((5, 12, 3, 7, 9, 4, 11, 6))]
+    tok = m2.tokenizer(caps, padding="longest", return_tensors="pt")
+    ids = tok.input_ids.clone(); ids[:, 0] = m2.tokenizer.enc_token_id
+    gen = torch.Generator().manual_seed(197)
+    z_t = torch.randn((b, ids.shape[1], 768), generator=gen)
+    feats = torch.randn((b, n_tok, 768), generator=gen)
+
+    class Z:
+        last_hidden_state = z_t
+    m2.train()
+    for p in m2.visual_encoder.parameters():
+        p.requires_grad_(False)
+    logits = m2.img_txt_fusion(Z(), feats, caps, train=True)
+    loss = torch.nn.functional.cross_entropy(logits, torch.arange(b))
+    loss.backward()
+    names, norms, samples = [], [], []
+    for name, p in m2.named_parameters():
+        if p.grad is None:
+            continue
+        gq = p.grad.detach().flatten()
+        names.append(name); norms.append(gq.double().norm().item())
+        samples.append(gq[torch.from_numpy(grad_sample_index(gq.numel()))].numpy())
+    np.savez_compressed(os.path.join(OUT, "train197.npz"), bert_cfg=json.dumps(cfg), vit_cfg=json.dumps(vit), seed=13, profile="test",
+                        caps=np.array(caps), input_ids=ids.numpy(), attention_mask=tok.attention_mask.numpy(), input_seed=197, n_tok=n_tok,
+                        z_t_slice=z_t[:, :2, :8].numpy(), feats_slice=feats[:, :2, :8].numpy(),
+                        logits=logits.detach().numpy(), loss=loss.item(), names=np.array(names), norms=np.array(norms), samples=np.stack(samples))
+    print("train197: loss", loss.item(), "logits sigma", logits.std().item(), "params with grad", len(names), "norm range", min(norms), max(norms))
+
+
 def tiny_goldens(R, ref_val):
     """tests/golden/tiny_loop.npz + masks.npz: reduced geometry through the reference's own loops.  Weights use the
     "spread" profile and the index images are structured (synthetic.scene_image), so that the candidates of a query get
@@ -627,6 +665,8 @@ def main():
         R = ref_shim.load_reference_modules()
         _install_torchvision_stub()
         full_bert = json.load(open(os.path.join(ref_shim.REFERENCE_ROOT, "configs", "med_config.json")))
+        if len(sys.argv) > 2 and sys.argv[2] == "197":
+            return train_goldens_197(R, full_bert)
         return train_goldens(R, full_bert)
     if len(sys.argv) > 1 and sys.argv[1] == "ckpt":     # only the checkpoint-loader fixture
         torch.manual_seed(0)

@@ -173,23 +173,32 @@ def test_vit_large_tiny():
     assert abs(y.double().sum().item() - float(z["tokens_sum"])) < 1e-1
 
 
-def test_training_step_gradients():
-    """The gradient oracle (torch autograd through O.img_txt_fusion_train) against ONE training step of the
+@pytest.mark.parametrize("fixture", ["train768", "train197"])
+def test_training_step_gradients(fixture):
+    """(train197, round 4: the same step at B = 8 x 197 image tokens; its inputs are regenerated from the stored seed.)
+    The gradient oracle (torch autograd through O.img_txt_fusion_train) against ONE training step of the
     real reference (tests/golden/train768.npz: BLIP_NLVR.train() with dropout 0, img_txt_fusion, cross-entropy, backward):
     logits, loss, the set of parameters that receive a gradient, every gradient's norm, sum and 64 sampled entries."""
     import json
     import torch.nn.functional as F
-    z = H.load("train768.npz")
+    z = H.load(fixture + ".npz")
     g, v = H.geometry(json.loads(str(z["bert_cfg"])), json.loads(str(z["vit_cfg"])))
     sd2, _ = H.state_dicts(g, v, int(z["seed"]), str(z["profile"]))
     torch.set_num_threads(8)
+    if "z_t" in z.files:
+        z_t_in, feats_in = torch.from_numpy(z["z_t"]), torch.from_numpy(z["feats"])
+    else:
+        gen = torch.Generator().manual_seed(int(z["input_seed"]))
+        z_t_in = torch.randn((z["input_ids"].shape[0], z["input_ids"].shape[1], 768), generator=gen)
+        feats_in = torch.randn((z["input_ids"].shape[0], int(z["n_tok"]), 768), generator=gen)
+        np.testing.assert_array_equal(z_t_in[:, :2, :8].numpy(), z["z_t_slice"])
+    bsz = z["input_ids"].shape[0]
     w = {k: t.clone().float() for k, t in sd2.items()}
     keys = [k for k in w if k.startswith(("text_encoder.", "cls_head.")) and w[k].is_floating_point()]
     for k in keys:
         w[k].requires_grad_(True)
-    logits = O.img_txt_fusion_train(w, torch.from_numpy(z["z_t"]), torch.from_numpy(z["feats"]), torch.from_numpy(z["input_ids"]),
-                                    torch.from_numpy(z["attention_mask"]))
-    loss = F.cross_entropy(logits, torch.arange(4))
+    logits = O.img_txt_fusion_train(w, z_t_in, feats_in, torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]))
+    loss = F.cross_entropy(logits, torch.arange(bsz))
     loss.backward()
     np.testing.assert_allclose(logits.detach().numpy(), z["logits"], atol=2e-4)
     assert abs(loss.item() - float(z["loss"])) < 1e-4
