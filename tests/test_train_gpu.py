@@ -31,8 +31,8 @@ GRAD_REL_MEAN = {BF: 0.03, HF: 0.004}
 # change of the forward's rounding (round 4's GEMM epilogue unification moved the worst tensor 0.135 -> 0.254 / 0.036 -> 0.128
 # with the same-ReLU-piece errors below unchanged), so this row gets a per-tensor cap plus a norm-weighted mean; the backward
 # ARITHMETIC is pinned by GRAD_REL / GRAD_REL_MEAN on the ReLU piece the forward took.
-GOLDEN_REL = {BF: 0.40, HF: 0.25}             # measured 0.257 / 0.154 on train768 (deterministic run to run and across GEMM tile choices)
-GOLDEN_REL_MEAN = {BF: 0.25, HF: 0.13}        # measured 0.161 / 0.084
+GOLDEN_REL = {BF: 0.60, HF: 0.25}             # measured 0.257 / 0.154 on train768, 0.478 (cls_head.0.weight itself) / 0.050 on train197
+GOLDEN_REL_MEAN = {BF: 0.35, HF: 0.13}        # measured 0.161 / 0.084 and 0.248 / 0.026 (deterministic run to run and across GEMM tiles)
 LOGIT_ABS = {BF: 6e-3, HF: 1.5e-3}      # logit sigma of the fixture: 0.12
 
 
