@@ -574,9 +574,6 @@ def main():
     args.stream_dtype = stream_name(m2)                                              # what the run actually used
     dt = m2.token_dtype                                                              # 16-bit type of pixels / image tokens in HBM
     m2.engines(); m1.engines()
-    if os.environ.get("CIR_BENCH_HEAD_MAJOR") == "0":                  # A/B runs only: the fused projections row-major, as before round 4
-        for eng in m2.engines():
-            eng.head_major = False
 
     q_n, k, ns = args.queries, args.k, args.subset
     if args.mode == "bank":

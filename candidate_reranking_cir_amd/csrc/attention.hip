@@ -57,7 +57,6 @@ struct AttnArgs {
     const float* mask; int64_t m_s1, m_s0;
     const int64_t* kv_index;   // optional: item b1 reads K/V of bank row kv_index[b1] (cross-query K/V cache)
     void* out; int64_t o_s1, o_s0, o_rs;
-    int64_t q_hs, k_hs, v_hs, o_hs;   // element stride between heads (64 = heads side by side in a row; head-major tensors: the slab stride)
     int B0, H, Lq, Lk, nqt;
     int64_t total;
     float scale;
@@ -220,13 +219,13 @@ __global__ __launch_bounds__(1024) void attn_shared_kernel(const AttnArgs a, int
     const int b0 = (int)(t % a.B0);
     const int64_t b1 = t / a.B0;
     const int64_t kb1 = a.kv_index ? a.kv_index[b1] : b1;
-    const T* kb = reinterpret_cast<const T*>(a.k) + kb1 * a.k_s1 + b0 * a.k_s0 + h * a.k_hs;
-    const T* vb = reinterpret_cast<const T*>(a.v) + kb1 * a.v_s1 + b0 * a.v_s0 + h * a.v_hs;
+    const T* kb = reinterpret_cast<const T*>(a.k) + kb1 * a.k_s1 + b0 * a.k_s0 + h * 64;
+    const T* vb = reinterpret_cast<const T*>(a.v) + kb1 * a.v_s1 + b0 * a.v_s0 + h * 64;
     const float* mp = MASKED ? a.mask + b1 * a.m_s1 + b0 * a.m_s0 : nullptr;
 
     const int r = lane & 31, hh = lane >> 5;
     // Q fragments of this wave's first query tile: requested BEFORE the K/V staging so that their latency overlaps it
-    const T* const qbase = reinterpret_cast<const T*>(a.q) + b1 * a.q_s1 + b0 * a.q_s0 + h * a.q_hs + 8 * hh;
+    const T* const qbase = reinterpret_cast<const T*>(a.q) + b1 * a.q_s1 + b0 * a.q_s0 + h * 64 + 8 * hh;
     X8 qf[4];
     {
         const int qrow = min(min(wave, a.nqt - 1) * 32 + r, a.Lq - 1);
@@ -301,7 +300,7 @@ __global__ __launch_bounds__(1024) void attn_shared_kernel(const AttnArgs a, int
             pv_tile<T>(st, vt_base, voff, pf);
         }
         if (q0 + r < a.Lq) {
-            T* op = reinterpret_cast<T*>(a.out) + b1 * a.o_s1 + b0 * a.o_s0 + (int64_t)(q0 + r) * a.o_rs + h * a.o_hs + 4 * hh;
+            T* op = reinterpret_cast<T*>(a.out) + b1 * a.o_s1 + b0 * a.o_s0 + (int64_t)(q0 + r) * a.o_rs + h * 64 + 4 * hh;
             store_out<T>(st, op);
         }
     }
@@ -328,10 +327,10 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const AttnArgs a) {
     const int r = lane & 31, hh = lane >> 5;
     const int q0 = qt * 32;
     const int qrow = min(q0 + r, a.Lq - 1);
-    const T* qp = reinterpret_cast<const T*>(a.q) + b1 * a.q_s1 + b0 * a.q_s0 + (int64_t)qrow * a.q_rs + h * a.q_hs + 8 * hh;
+    const T* qp = reinterpret_cast<const T*>(a.q) + b1 * a.q_s1 + b0 * a.q_s0 + (int64_t)qrow * a.q_rs + h * 64 + 8 * hh;
     const int64_t kb1 = a.kv_index ? a.kv_index[b1] : b1;
-    const T* kb = reinterpret_cast<const T*>(a.k) + kb1 * a.k_s1 + b0 * a.k_s0 + h * a.k_hs + 8 * hh;
-    const T* vb = reinterpret_cast<const T*>(a.v) + kb1 * a.v_s1 + b0 * a.v_s0 + h * a.v_hs;
+    const T* kb = reinterpret_cast<const T*>(a.k) + kb1 * a.k_s1 + b0 * a.k_s0 + h * 64 + 8 * hh;
+    const T* vb = reinterpret_cast<const T*>(a.v) + kb1 * a.v_s1 + b0 * a.v_s0 + h * 64;
     const float* mp = MASKED ? a.mask + b1 * a.m_s1 + b0 * a.m_s0 : nullptr;
 
     X8 qf[4];
@@ -384,7 +383,7 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const AttnArgs a) {
         __builtin_amdgcn_wave_barrier();  // keep the next tile's LDS writes behind these reads
     }
     if (q0 + r < a.Lq) {
-        T* op = reinterpret_cast<T*>(a.out) + b1 * a.o_s1 + b0 * a.o_s0 + (int64_t)(q0 + r) * a.o_rs + h * a.o_hs + 4 * hh;
+        T* op = reinterpret_cast<T*>(a.out) + b1 * a.o_s1 + b0 * a.o_s0 + (int64_t)(q0 + r) * a.o_rs + h * 64 + 4 * hh;
         store_out<T>(st, op);
     }
 }
@@ -534,18 +533,18 @@ __global__ __launch_bounds__(256, 2) void cls_xattn_kernel(const T* __restrict__
 
 }  // namespace cir
 
-static int attention_impl(const void* q, int64_t q_s1, int64_t q_s0, int64_t q_rs, int64_t q_hs, const void* k, int64_t k_s1,
-                          int64_t k_s0, int64_t k_rs, int64_t k_hs, const void* v, int64_t v_s1, int64_t v_s0, int64_t v_rs, int64_t v_hs,
-                          const float* mask, int64_t m_s1, int64_t m_s0, const int64_t* kv_index, void* out, int64_t o_s1,
-                          int64_t o_s0, int64_t o_rs, int64_t o_hs, int B1, int B0, int H, int Lq, int Lk, float scale, int dtype, void* stream) {
+extern "C" int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t q_rs, const void* k, int64_t k_s1,
+                             int64_t k_s0, int64_t k_rs, const void* v, int64_t v_s1, int64_t v_s0, int64_t v_rs,
+                             const float* mask, int64_t m_s1, int64_t m_s0, const int64_t* kv_index, void* out, int64_t o_s1,
+                             int64_t o_s0, int64_t o_rs, int B1, int B0, int H, int Lq, int Lk, float scale, int dtype, void* stream) {
     using namespace cir;
     CIR_CHECK_PTR(q); CIR_CHECK_PTR(k); CIR_CHECK_PTR(v); CIR_CHECK_PTR(out);
     if (B1 <= 0 || B0 <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return CIR_EINVAL;
     if (dtype != CIR_BF16 && dtype != CIR_F16) return CIR_EDTYPE;
-    const int64_t strides[] = {q_s1, q_s0, q_rs, q_hs, k_s1, k_s0, k_rs, k_hs, v_s1, v_s0, v_rs, v_hs};
+    const int64_t strides[] = {q_s1, q_s0, q_rs, k_s1, k_s0, k_rs, v_s1, v_s0, v_rs};
     for (int64_t s : strides)
         if (s % 8) return CIR_EALIGN;
-    if (o_s1 % 4 || o_s0 % 4 || o_rs % 4 || o_hs % 4) return CIR_EALIGN;
+    if (o_s1 % 4 || o_s0 % 4 || o_rs % 4) return CIR_EALIGN;
     if (!cir_aligned16(q) || !cir_aligned16(k) || !cir_aligned16(v) || (reinterpret_cast<uintptr_t>(out) & 7)) return CIR_EALIGN;
     AttnArgs a;
     a.q = q; a.q_s1 = q_s1; a.q_s0 = q_s0; a.q_rs = q_rs;
@@ -554,7 +553,6 @@ static int attention_impl(const void* q, int64_t q_s1, int64_t q_s0, int64_t q_r
     a.mask = mask; a.m_s1 = m_s1; a.m_s0 = m_s0;
     a.kv_index = kv_index;
     a.out = out; a.o_s1 = o_s1; a.o_s0 = o_s0; a.o_rs = o_rs;
-    a.q_hs = q_hs; a.k_hs = k_hs; a.v_hs = v_hs; a.o_hs = o_hs;
     a.B0 = B0; a.H = H; a.Lq = Lq; a.Lk = Lk; a.nqt = (Lq + 31) / 32;
     a.total = (int64_t)B1 * B0 * H * a.nqt;
     a.scale = scale;
@@ -590,23 +588,6 @@ static int attention_impl(const void* q, int64_t q_s1, int64_t q_s0, int64_t q_r
     if (dtype == CIR_BF16) { if (mk) hipLaunchKernelGGL((attn_stream_kernel<__bf16, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((attn_stream_kernel<__bf16, false>), grid, block, 0, s, a); }
     else { if (mk) hipLaunchKernelGGL((attn_stream_kernel<_Float16, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((attn_stream_kernel<_Float16, false>), grid, block, 0, s, a); }
     CIR_LAUNCH_RESULT();
-}
-
-extern "C" int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t q_rs, const void* k, int64_t k_s1,
-                             int64_t k_s0, int64_t k_rs, const void* v, int64_t v_s1, int64_t v_s0, int64_t v_rs,
-                             const float* mask, int64_t m_s1, int64_t m_s0, const int64_t* kv_index, void* out, int64_t o_s1,
-                             int64_t o_s0, int64_t o_rs, int B1, int B0, int H, int Lq, int Lk, float scale, int dtype, void* stream) {
-    return attention_impl(q, q_s1, q_s0, q_rs, 64, k, k_s1, k_s0, k_rs, 64, v, v_s1, v_s0, v_rs, 64, mask, m_s1, m_s0, kv_index,
-                          out, o_s1, o_s0, o_rs, 64, B1, B0, H, Lq, Lk, scale, dtype, stream);
-}
-
-extern "C" int cir_attention_hs(const void* q, int64_t q_s1, int64_t q_s0, int64_t q_rs, int64_t q_hs, const void* k, int64_t k_s1,
-                                int64_t k_s0, int64_t k_rs, int64_t k_hs, const void* v, int64_t v_s1, int64_t v_s0, int64_t v_rs,
-                                int64_t v_hs, const float* mask, int64_t m_s1, int64_t m_s0, const int64_t* kv_index, void* out,
-                                int64_t o_s1, int64_t o_s0, int64_t o_rs, int64_t o_hs, int B1, int B0, int H, int Lq, int Lk, float scale,
-                                int dtype, void* stream) {
-    return attention_impl(q, q_s1, q_s0, q_rs, q_hs, k, k_s1, k_s0, k_rs, k_hs, v, v_s1, v_s0, v_rs, v_hs, mask, m_s1, m_s0, kv_index,
-                          out, o_s1, o_s0, o_rs, o_hs, B1, B0, H, Lq, Lk, scale, dtype, stream);
 }
 
 extern "C" int cir_cls_cross_attention(const void* x, int64_t x_s1, const int64_t* x_index, const void* qp, void* out, int T, int Lk, int D,

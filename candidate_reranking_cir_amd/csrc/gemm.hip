@@ -192,9 +192,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
             for (int q = 0; q < 4; ++q) cp[q] = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
         } else {
             using CT = typename std::conditional<OUT == 2, _Float16, T>::type;
-            // (head-major C: the lane's 16 features lie inside one 64-column block = one slab)
-            const int64_t coff = a.slab ? (int64_t)(nb >> 6) * a.slab + m * a.ldc + (nb & 63) : m * a.ldc + nb;
-            u32x4* cp = reinterpret_cast<u32x4*>(reinterpret_cast<CT*>(a.C) + z * a.sC + coff);
+            u32x4* cp = reinterpret_cast<u32x4*>(reinterpret_cast<CT*>(a.C) + z * a.sC + m * a.ldc + nb);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 u32x4 o;
@@ -210,10 +208,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
 
 }  // namespace cir
 
-static int gemm_impl(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW,
-                     const float* bias, int64_t strideBias, const void* residual, int res_dtype, int64_t ldr,
-                     int64_t strideR, void* C, int64_t ldc, int64_t strideC, int64_t M, int N, int K, int batch,
-                     int act, int in_dtype, int out_dtype, int64_t slab, void* stream) {
+extern "C" int cir_gemm_bias_act(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW,
+                                 const float* bias, int64_t strideBias, const void* residual, int res_dtype, int64_t ldr,
+                                 int64_t strideR, void* C, int64_t ldc, int64_t strideC, int64_t M, int N, int K, int batch,
+                                 int act, int in_dtype, int out_dtype, void* stream) {
     using namespace cir;
     CIR_CHECK_PTR(A); CIR_CHECK_PTR(W); CIR_CHECK_PTR(C);
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return CIR_EINVAL;
@@ -233,19 +231,13 @@ static int gemm_impl(const void* A, int64_t lda, int64_t strideA, const void* W,
     if (bias && (!cir_aligned16(bias) || strideBias % 4)) return CIR_EALIGN;
     const int64_t res_elems_per16 = res_dtype == CIR_F32 ? 4 : 8;
     if (residual && (!cir_aligned16(residual) || ldr % res_elems_per16 || strideR % res_elems_per16)) return CIR_EALIGN;
-    if (slab < 0) return CIR_EINVAL;
-    if (slab > 0) {   // head-major C: 16-bit, no residual, whole 64-column blocks
-        if (residual || out_dtype == CIR_F32) return CIR_EDTYPE;
-        if (N % 64 != 0 || ldc < 64) return CIR_ESHAPE;
-        if (slab % 8) return CIR_EALIGN;
-    }
 
     GemmArgs a;
     a.A = A; a.lda = lda; a.sA = strideA;
     a.W = W; a.ldw = ldw; a.sW = strideW;
     a.bias = bias; a.sBias = strideBias;
     a.R = residual; a.ldr = ldr; a.sR = strideR;
-    a.C = C; a.ldc = ldc; a.sC = strideC; a.slab = slab;
+    a.C = C; a.ldc = ldc; a.sC = strideC;
     a.M = M; a.N = N; a.K = K; a.batch = batch; a.act = act; a.group_w = 1;
     a.tiles_m = (int)((M + BM - 1) / BM);
     a.tiles_n = (N + BN - 1) / BN;
@@ -277,20 +269,4 @@ static int gemm_impl(const void* A, int64_t lda, int64_t strideA, const void* W,
     else CIR_LAUNCH128(_Float16);
 #undef CIR_LAUNCH128
     CIR_LAUNCH_RESULT();
-}
-
-extern "C" int cir_gemm_bias_act(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW,
-                                 const float* bias, int64_t strideBias, const void* residual, int res_dtype, int64_t ldr,
-                                 int64_t strideR, void* C, int64_t ldc, int64_t strideC, int64_t M, int N, int K, int batch,
-                                 int act, int in_dtype, int out_dtype, void* stream) {
-    return gemm_impl(A, lda, strideA, W, ldw, strideW, bias, strideBias, residual, res_dtype, ldr, strideR, C, ldc, strideC, M, N, K, batch,
-                     act, in_dtype, out_dtype, 0, stream);
-}
-
-extern "C" int cir_gemm_bias_act_slab(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW,
-                                      const float* bias, int64_t strideBias, void* C, int64_t ldc, int64_t slab_stride, int64_t strideC,
-                                      int64_t M, int N, int K, int batch, int act, int in_dtype, int out_dtype, void* stream) {
-    if (slab_stride <= 0) return CIR_EINVAL;
-    return gemm_impl(A, lda, strideA, W, ldw, strideW, bias, strideBias, nullptr, CIR_F32, 0, 0, C, ldc, strideC, M, N, K, batch,
-                     act, in_dtype, out_dtype, slab_stride, stream);
 }

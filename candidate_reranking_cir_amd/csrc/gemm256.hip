@@ -437,11 +437,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
             [[maybe_unused]] const unsigned st_w0 = stg_addr + r15 * 128 + (((0 + g) ^ (r15 & 7)) << 4);
             [[maybe_unused]] const unsigned st_w1 = stg_addr + r15 * 128 + (((4 + g) ^ (r15 & 7)) << 4);
             [[maybe_unused]] const unsigned st_rd = stg_addr + rr * 128 + ((sl ^ (rr & 7)) << 4);
-            // (head-major C, a.slab > 0: this wave's 64 features are one column block = one slab of (M, 64) rows - the block index
-            //  moves into the wave-uniform base, the lane offset loses its column-block term)
-            [[maybe_unused]] const unsigned st_voff = (unsigned)((rr * a.ldc + (a.slab ? 0 : wc * 64) + sl * 8) * (int64_t)sizeof(OT));
-            [[maybe_unused]] const char* const c_tile = reinterpret_cast<const char*>(a.C) +
-                (cz * a.sC + (cm0 + wr * 64) * a.ldc + (a.slab ? (int64_t)((cn0 >> 6) + wc) * a.slab : (int64_t)cn0)) * (int64_t)sizeof(OT);
+            [[maybe_unused]] const unsigned st_voff = (unsigned)((rr * a.ldc + wc * 64 + sl * 8) * (int64_t)sizeof(OT));
+            [[maybe_unused]] const char* const c_tile = reinterpret_cast<const char*>(a.C) + (cz * a.sC + (cm0 + wr * 64) * a.ldc + cn0) * (int64_t)sizeof(OT);
             [[maybe_unused]] const int64_t c_row8 = a.ldc * 8 * (int64_t)sizeof(OT);
             u32x4 wd[4];                                            // one pass of packed outputs: [sub][nh] (16-bit) / [nh][half] (fp32)
             // activation + pack of pass `ps` into wd (pure VALU: overlaps the LDS round trip of the previous pass)
@@ -549,8 +546,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                     if (full || (m < a.M && ncol + (OUT_F32 ? 4 : 8) <= a.N)) {
                         u32x4* cp;
                         if constexpr (OUT_F32) cp = reinterpret_cast<u32x4*>(reinterpret_cast<float*>(a.C) + cz * a.sC + m * a.ldc + ncol);
-                        else cp = reinterpret_cast<u32x4*>(reinterpret_cast<OT*>(a.C) + cz * a.sC +
-                                                           (a.slab ? (int64_t)(ncol >> 6) * a.slab + m * a.ldc + (ncol & 63) : m * a.ldc + ncol));
+                        else cp = reinterpret_cast<u32x4*>(reinterpret_cast<OT*>(a.C) + cz * a.sC + m * a.ldc + ncol);
                         STORE_C(cp, dd[j])
                     }
                 }

@@ -10,8 +10,6 @@ struct GemmArgs {
     const float* bias; int64_t sBias;
     const void* R; int64_t ldr, sR;    // residual: fp32 or fp16 (the element type of C in the fp32-layout epilogues)
     void* C; int64_t ldc, sC;
-    int64_t slab;  // 0: C row-major (M, N).  > 0: HEAD-MAJOR C - column block j = n / 64 is its own (M, 64) matrix at C + j * slab
-                   // (row stride ldc): the 64 columns of one attention head of every row are contiguous (cir_gemm_bias_act_slab)
     int64_t M; int N, K, batch, act, tiles_m, tiles_n;
     int dbg;       // diagnostic (stamped) build only: experiment switches from the environment; 0 in the shipped library
     int group_w;   // gemm256: tiles are walked in column groups of this many n-panels (weights stay L2-resident)

@@ -86,7 +86,6 @@ class VitEngine:
                 w1=_w16(sd[b + "mlp.fc1.weight"], dtype, device), c1=_f32(sd[b + "mlp.fc1.bias"], device),
                 w2=_w16(sd[b + "mlp.fc2.weight"], dtype, device), c2=_f32(sd[b + "mlp.fc2.bias"], device)))
         self.gf, self.bf = _f32(sd[p + "norm.weight"], device), _f32(sd[p + "norm.bias"], device)
-        self.head_major = d % 64 == 0            # fused QKV in head-major layout (attribute: A/B runs and the bit-identity test)
 
     def forward(self, image: torch.Tensor, want32: bool = False, chunk: int = 2048, out32: Optional[torch.Tensor] = None,
                 out16: Optional[torch.Tensor] = None):
@@ -115,15 +114,9 @@ class VitEngine:
         ctx = torch.empty((bsz, n, d), dtype=dt, device=x.device)
         for blk in self.blocks:
             _, xb = _ln(x, blk["g1"], blk["b1"], geo.layer_norm_eps, dt, sdt, need_stream=False)
-            if self.head_major:
-                # fused q|k|v written HEAD-MAJOR ((3H, B*N, 64): a head's rows of one image = 25 KB contiguous instead of 128-byte
-                # pieces a 4.6-KB fused row apart) and read by the attention through its strides: same arithmetic, same bits
-                hm = ops.gemm(xb, blk["wqkv"], blk["bqkv"], head_major=True).view(3, d // 64, bsz, n, 64)   # vit.py:72
-                q5, k5, v5 = (hm[j].permute(1, 2, 0, 3).unsqueeze(1) for j in range(3))                      # (B, 1, N, H, 64) views
-                ops.attention(q5, k5, v5, ctx.unsqueeze(1), scale)                                           # vit.py:73-83
-            else:
-                qkv = ops.gemm(xb, blk["wqkv"], blk["bqkv"]).view(bsz, n, 3, d)
-                ops.attention(qkv[:, :, 0].unsqueeze(1), qkv[:, :, 1].unsqueeze(1), qkv[:, :, 2].unsqueeze(1), ctx.unsqueeze(1), scale)
+            qkv = ops.gemm(xb, blk["wqkv"], blk["bqkv"]).view(bsz, n, 3, d)    # vit.py:72
+            ops.attention(qkv[:, :, 0].unsqueeze(1), qkv[:, :, 1].unsqueeze(1), qkv[:, :, 2].unsqueeze(1),
+                          ctx.unsqueeze(1), scale)                             # vit.py:73-83
             ops.gemm(ctx.view(bsz * n, d), blk["wo"], blk["bo"], residual=x, out_dtype=sdt, out=x)  # :84,:108
             _, xb = _ln(x, blk["g2"], blk["b2"], geo.layer_norm_eps, dt, sdt, need_stream=False)
             f = ops.gemm(xb, blk["w1"], blk["c1"], act=ops.ACT_GELU)           # vit.py:36-37
@@ -214,7 +207,7 @@ class NlvrEngine:
     Layout: hidden states are (branch, row, D) with row = candidate * L + token.  Per layer:
     batched(2) QKV GEMM -> self-attention -> batched out-proj(+residual) -> LayerNormA/B ->
     batched cross-Q GEMM; ONE K|V GEMM over the candidate tokens for both branches
-    ([K0;K1;V0;V1] stacked, N = 4D); cross-attention writes [c0|c1] rows; the merge is a single
+    ([K0;V0;K1;V1] stacked, N = 4D); cross-attention writes [c0|c1] rows; the merge is a single
     K = 2D GEMM ([.5 W0 | .5 W1] for the averaging layers, [Wm_a W0 | Wm_b W1] folded for the
     merge_layer ones - `fold_merge=False` keeps dense0/dense1 and merge_layer as separate GEMMs);
     twin LayerNorm with the shared merged tensor; FFN on both branches as one M = 2R GEMM pair.
@@ -229,7 +222,6 @@ class NlvrEngine:
         self.trim_last = True   # last layer: per-token work on the CLS rows only (results identical for the rows that are used)
         self.kv_chunk = 0       # candidates per K|V + cross-attention chunk (0 = all at once; attribute, for A/B runs)
         self.fold_cls_kv = True  # last layer: fold the cross K / V projections out of the token side (False: K|V GEMM + attention)
-        self.head_major = geo.hidden_size % 64 == 0   # per-candidate K|V written head-major (see VitEngine; the K/V BANK stays row-major)
         e = prefix + "embeddings."
         self.word, self.posemb = _f32(sd[e + "word_embeddings.weight"], device), _f32(sd[e + "position_embeddings.weight"], device)
         self.ge, self.be = _f32(sd[e + "LayerNorm.weight"], device), _f32(sd[e + "LayerNorm.bias"], device)
@@ -248,7 +240,7 @@ class NlvrEngine:
             ly["b1"] = _f32(torch.stack([sd[p + f"attention.output.LayerNorm{c}.bias"] for c in "AB"]), device)
             ly["wq"] = _w16(torch.stack([sd[c + "query.weight"].float() for c in ca]), xdt, device)
             ly["bq"] = _f32(torch.stack([sd[c + "query.bias"].float() for c in ca]), device)
-            kv_keys = [ca[0] + "key", ca[1] + "key", ca[0] + "value", ca[1] + "value"]   # [K0 K1 V0 V1]: keys (and values) of both branches adjacent
+            kv_keys = [ca[0] + "key", ca[0] + "value", ca[1] + "key", ca[1] + "value"]
             ly["wkv"] = _w16(_cat(sd, kv_keys, ".weight"), xdt, device)           # (4D, Dv)
             ly["bkv"] = _f32(_cat(sd, kv_keys, ".bias"), device)
             # one-time weight preparation in fp64 on the host (keeps library GEMMs out of the device timeline)
@@ -310,7 +302,7 @@ class NlvrEngine:
     @torch.no_grad()
     def build_kv_bank(self, bank16: torch.Tensor, chunk: int = 512) -> list:
         """Cross-attention K|V of every index image for every layer and both branches:
-        bank16 (n_index, N, Dv) 16-bit -> 12 tensors (n_index, N, 4D) = [K0 K1 V0 V1].  These projections are
+        bank16 (n_index, N, Dv) 16-bit -> 12 tensors (n_index, N, 4D) = [K0 V0 K1 V1].  These projections are
         query-independent (45 % of the fusion flops at 224 px); a real dataset re-uses a few thousand index images
         across 1e5-1e6 candidate slots, and 288 GB of HBM holds the whole bank (CIRR val at 384 px: 98 GB)."""
         n_idx, n, dv = bank16.shape
@@ -401,17 +393,12 @@ class NlvrEngine:
                 step_c = self.kv_chunk if self.kv_chunk > 0 else t_n
                 for c0 in range(0, t_n, step_c):
                     c1 = min(c0 + step_c, t_n)
-                    cm = None if emask is None else emask[c0:c1]
-                    if self.head_major:     # (2 [K, V], 2 branches, H, candidates, N, 64) -> (candidates, 2, N, H, 64) views
-                        hm = ops.gemm(cand2[c0 * n:c1 * n], ly["wkv"], ly["bkv"], head_major=True).view(2, 2, d // 64, c1 - c0, n, 64)
-                        ops.attention(qc[c0:c1], hm[0].permute(2, 0, 3, 1, 4), hm[1].permute(2, 0, 3, 1, 4), ccl[c0:c1].permute(0, 2, 1, 3), scale, cm)
-                    else:
-                        kv = ops.gemm(cand2[c0 * n:c1 * n], ly["wkv"], ly["bkv"]).view(c1 - c0, n, 4, d)  # [K0 K1 V0 V1]
-                        ops.attention(qc[c0:c1], kv[:, :, 0:2].permute(0, 2, 1, 3), kv[:, :, 2:4].permute(0, 2, 1, 3),
-                                      ccl[c0:c1].permute(0, 2, 1, 3), scale, cm)                            # nlvr_encoder.py:321-344
+                    kv = ops.gemm(cand2[c0 * n:c1 * n], ly["wkv"], ly["bkv"]).view(c1 - c0, n, 4, d)     # [K0 V0 K1 V1]
+                    ops.attention(qc[c0:c1], kv[:, :, 0::2].permute(0, 2, 1, 3), kv[:, :, 1::2].permute(0, 2, 1, 3),
+                                  ccl[c0:c1].permute(0, 2, 1, 3), scale, None if emask is None else emask[c0:c1])   # nlvr_encoder.py:321-344
             else:
-                kv = kv_bank[i].view(-1, n, 4, d)                                                         # (n_index, N, 4, D) bank, [K0 K1 V0 V1]
-                ops.attention(qc, kv[:, :, 0:2].permute(0, 2, 1, 3), kv[:, :, 2:4].permute(0, 2, 1, 3),
+                kv = kv_bank[i].view(-1, n, 4, d)                                                         # (n_index, N, 4, D) bank
+                ops.attention(qc, kv[:, :, 0::2].permute(0, 2, 1, 3), kv[:, :, 1::2].permute(0, 2, 1, 3),
                               ccl.permute(0, 2, 1, 3), scale, emask, kv_index=cand_rows)
             if "wd" in ly:                                                                                # unfolded merge_layer
                 dd = torch.empty((rq, 2, d), dtype=xdt, device=cc.device)

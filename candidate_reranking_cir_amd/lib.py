@@ -24,19 +24,12 @@ SIGNATURES = {
     "cir_gemm_bias_act": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                                   c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                   c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "cir_gemm_bias_act_slab": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
-                                       c_void_p, c_int64, c_int64, c_int64,
-                                       c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "cir_layernorm": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
                               c_int64, c_int64, c_int, c_int, c_float, c_int, c_void_p]),
     "cir_attention": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
                               c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                               c_void_p, c_int64, c_int64, c_int64,
                               c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
-    "cir_attention_hs": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64,
-                                 c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
-                                 c_void_p, c_int64, c_int64, c_int64, c_int64,
-                                 c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "cir_cls_cross_attention": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "cir_embed_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                     c_int64, c_int, c_int, c_int, c_float, c_int, c_void_p]),

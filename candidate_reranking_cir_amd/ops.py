@@ -61,10 +61,8 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-         act: int = ACT_NONE, out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None, head_major: bool = False) -> torch.Tensor:
-    """out = act(a @ w.T + bias) (+ residual).  `head_major`: the result as (N / 64, M, 64) [batched: (B, N / 64, M, 64)] - every
-    64-column block (one attention head of a fused projection) a contiguous matrix of its own (cir_gemm_bias_act_slab; 16-bit,
-    no residual); `attention` reads such tensors through their strides.  a (M,K) or (B,M,K) 16-bit with contiguous rows (any
+         act: int = ACT_NONE, out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act(a @ w.T + bias) (+ residual).  a (M,K) or (B,M,K) 16-bit with contiguous rows (any
     row stride); w (N,K) / (B,N,K); bias fp32 (N) / (B,N); out in a.dtype (operand copy), fp32 or fp16 (residual
     stream, also from bf16 operands); residual shaped like out: fp32 (out in a.dtype or fp32) or fp16 (with an fp16 out; the only
     residual an fp16 out from bf16 operands takes)."""
@@ -78,28 +76,6 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     n = w3.shape[1]
     assert w3.shape[0] == nb and w3.shape[2] == k and a3.stride(2) == 1 and w3.stride(2) == 1
     out_dtype = out_dtype or a.dtype
-    if head_major:
-        assert residual is None and n % 64 == 0 and out_dtype != torch.float32, "head-major output: 16-bit, no residual, N % 64 == 0"
-        if out is None:
-            out = torch.empty((nb, n // 64, m, 64) if batched else (n // 64, m, 64), dtype=out_dtype, device=a.device)
-        o4 = out if out.dim() == 4 else out.unsqueeze(0)
-        assert o4.shape == (nb, n // 64, m, 64) and o4.stride(3) == 1 and o4.dtype == out_dtype
-        sb = 0
-        if bias is not None:
-            assert bias.dtype == torch.float32 and bias.stride(-1) == 1
-            sb = bias.stride(0) if bias.dim() == 2 else 0
-        if PROFILE_GEMM is not None:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
-        code = _lib.load().cir_gemm_bias_act_slab(
-            a3.data_ptr(), a3.stride(1), a3.stride(0), w3.data_ptr(), w3.stride(1), w3.stride(0), _ptr(bias), sb,
-            o4.data_ptr(), o4.stride(2), o4.stride(1), o4.stride(0), m, n, k, nb, act, _DT[a.dtype], _DT[out_dtype], _stream())
-        if PROFILE_GEMM is not None:
-            ev1.record()
-            alg_bytes = nb * ((m * k + n * k) * a.element_size() + m * n * o4.element_size() + (n * 4 if bias is not None else 0))
-            PROFILE_GEMM.append((2.0 * nb * m * n * k, ev0, ev1, float(alg_bytes), gemm_kernel_name(m, n, k, nb, False, act, out_dtype, a.dtype)))
-        _lib.check(code, "cir_gemm_bias_act_slab")
-        return out
     if out is None:
         out = torch.empty((nb, m, n) if batched else (m, n), dtype=out_dtype, device=a.device)
     o3 = out if out.dim() == 3 else out.unsqueeze(0)
@@ -173,30 +149,17 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
               mask: Optional[torch.Tensor] = None, kv_index: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q/out: (B1, B0, Lq, H*64) views, k/v: (B1, B0, Lk, H*64) views (any strides, unit last stride);
     mask: additive fp32 (B1, B0, Lk) view or None.  With `kv_index` (B1,) int64, k/v are banks
-    (rows, B0, Lk, H*64) and item b1 attends to bank row kv_index[b1].  Writes `out` and returns it.
-    Any of q / k / v / out may instead be a 5-D view (B1, B0, L, H, 64) with its own head stride - how the head-major
-    tensors of `gemm(..., head_major=True)` are passed (cir_attention_hs)."""
+    (rows, B0, Lk, H*64) and item b1 attends to bank row kv_index[b1].  Writes `out` and returns it."""
     _need_cuda(q, k, v, out, mask, kv_index)
-    hs = []
-    flat = []
-    for t in (q, k, v, out):
-        if t.dim() == 5:
-            assert t.shape[4] == 64 and t.stride(4) == 1
-            hs.append(t.stride(3))
-            flat.append(t.as_strided((t.shape[0], t.shape[1], t.shape[2], t.shape[3] * 64), (t.stride(0), t.stride(1), t.stride(2), 1), t.storage_offset()))
-        else:
-            hs.append(64)
-            flat.append(t)
-    q, k, v, out_v = flat
     b1, b0, lq, d = q.shape
     lk = k.shape[2]
     if kv_index is None:
         assert k.shape == (b1, b0, lk, d)
     else:
         assert kv_index.dtype == torch.int64 and kv_index.shape == (b1,) and kv_index.is_contiguous() and k.shape[1:] == (b0, lk, d)
-    assert d % 64 == 0 and v.shape == k.shape and out_v.shape == q.shape
-    assert q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1 and out_v.stride(3) == 1
-    assert q.dtype == k.dtype == v.dtype == out_v.dtype
+    assert d % 64 == 0 and v.shape == k.shape and out.shape == q.shape
+    assert q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1 and out.stride(3) == 1
+    assert q.dtype == k.dtype == v.dtype == out.dtype
     ms1 = ms0 = 0
     if mask is not None:
         assert mask.dtype == torch.float32 and mask.shape == (b1, b0, lk) and mask.stride(2) == 1
@@ -204,10 +167,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     if PROFILE_ATTN is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    code = _lib.load().cir_attention_hs(
-        q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), hs[0], k.data_ptr(), k.stride(0), k.stride(1), k.stride(2), hs[1],
-        v.data_ptr(), v.stride(0), v.stride(1), v.stride(2), hs[2], _ptr(mask), ms1, ms0, _ptr(kv_index),
-        out_v.data_ptr(), out_v.stride(0), out_v.stride(1), out_v.stride(2), hs[3], b1, b0, d // 64, lq, lk, float(scale), _DT[q.dtype], _stream())
+    code = _lib.load().cir_attention(
+        q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), k.data_ptr(), k.stride(0), k.stride(1), k.stride(2),
+        v.data_ptr(), v.stride(0), v.stride(1), v.stride(2), _ptr(mask), ms1, ms0, _ptr(kv_index),
+        out.data_ptr(), out.stride(0), out.stride(1), out.stride(2), b1, b0, d // 64, lq, lk, float(scale), _DT[q.dtype], _stream())
     if PROFILE_ATTN is not None:
         ev1.record()
         PROFILE_ATTN.append((4.0 * b1 * b0 * lq * lk * d, ev0, ev1, (lq, lk)))

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CIR_ABI_VERSION 9
+#define CIR_ABI_VERSION 8
 
 enum { CIR_BF16 = 0, CIR_F16 = 1, CIR_F32 = 2 };
 enum { CIR_ACT_NONE = 0, CIR_ACT_GELU = 1, CIR_ACT_RELU = 2 };
@@ -87,22 +87,6 @@ int cir_gemm_bias_act(const void* A, int64_t lda, int64_t strideA,
                       int act, int in_dtype, int out_dtype, void* stream);
 
 /*
- * The same product with a HEAD-MAJOR 16-bit C and no residual: column block j = n / 64 (one attention head of a fused
- * q|k|v or k|v projection) is its own (M, 64) matrix at C + j * slab_stride with row stride ldc (>= 64), i.e. element
- * (m, n) lives at C + b * strideC + (n / 64) * slab_stride + m * ldc + n % 64.  A head's rows are then contiguous
- * (64 elements = one 128-byte line per row, a 197-token image = 25 KB in one piece) instead of 128-byte pieces a whole
- * fused row apart - what cir_attention_hs reads.  N % 64 == 0; out_dtype = in_dtype or CIR_F16; same arithmetic, same bits
- * as cir_gemm_bias_act.  Serves the fused projections of vit.py:72 and nlvr_encoder.py:150-168 (keys / values of the
- * cross-attention).
- */
-int cir_gemm_bias_act_slab(const void* A, int64_t lda, int64_t strideA,
-                           const void* W, int64_t ldw, int64_t strideW,
-                           const float* bias, int64_t strideBias,
-                           void* C, int64_t ldc, int64_t slab_stride, int64_t strideC,
-                           int64_t M, int N, int K, int batch,
-                           int act, int in_dtype, int out_dtype, void* stream);
-
-/*
  * y[b] = LayerNorm(x[b] (+ residual[b]); gamma[b], beta[b], eps) over the last dimension.
  *   x, residual (rows, cols) in x_dtype (CIR_F32 or CIR_F16: the residual stream); gamma/beta fp32 (cols);
  *   outputs: y_stream in y_stream_dtype (CIR_F32 / CIR_F16: the copy that feeds the next residual) and/or
@@ -132,18 +116,6 @@ int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t q_rs,
                   const float* mask, int64_t m_s1, int64_t m_s0, const int64_t* kv_index,
                   void* out, int64_t o_s1, int64_t o_s0, int64_t o_rs,
                   int B1, int B0, int H, int Lq, int Lk, float scale, int dtype, void* stream);
-
-/*
- * cir_attention with an explicit element stride between heads per tensor (q_hs, k_hs, v_hs, o_hs; cir_attention = 64 everywhere):
- * element (b1, b0, row, h, d) of k lives at k + b1*k_s1 + b0*k_s0 + row*k_rs + h*k_hs + d.  Reads the head-major tensors
- * cir_gemm_bias_act_slab writes (k_rs = 64, k_hs = slab stride) and writes a row-major context (o_hs = 64).  Same kernels, same bits.
- */
-int cir_attention_hs(const void* q, int64_t q_s1, int64_t q_s0, int64_t q_rs, int64_t q_hs,
-                     const void* k, int64_t k_s1, int64_t k_s0, int64_t k_rs, int64_t k_hs,
-                     const void* v, int64_t v_s1, int64_t v_s0, int64_t v_rs, int64_t v_hs,
-                     const float* mask, int64_t m_s1, int64_t m_s0, const int64_t* kv_index,
-                     void* out, int64_t o_s1, int64_t o_s0, int64_t o_rs, int64_t o_hs,
-                     int B1, int B0, int H, int Lq, int Lk, float scale, int dtype, void* stream);
 
 /*
  * Cross-attention of ONE query row per (branch, head) over the tokens of each candidate, K / V projections folded out of

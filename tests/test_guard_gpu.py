@@ -305,32 +305,3 @@ def test_attention_kv_bank_many_workgroups(ops):
     ops.attention(q, gth[:, :, 0::2].permute(0, 2, 1, 3), gth[:, :, 1::2].permute(0, 2, 1, 3), out_b, 0.125)
     torch.cuda.synchronize()
     assert torch.equal(out_a, out_b)
-
-
-# ------------------------------------------------------------------------------------------------ head-major GEMM output
-@pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "fp16"])
-@pytest.mark.parametrize("tile", [128, 256])
-@pytest.mark.parametrize("m,n,k", [(79588, 2304, 768), (70001, 3072, 256), (1000, 192, 128), (333, 64, 64)])
-def test_head_major_gemm_exact_with_guard_bands(ops, dtype, tile, m, n, k):
-    """cir_gemm_bias_act_slab: every 64-column block of the result a (M, 64) matrix of its own.  Exact integers against torch,
-    every slab inside canaries (slack rows before / after each slab: a store that runs past a slab's last row, or a column-block
-    index off by one, lands on a canary), both tile sizes, > 256 persistent tiles with a ragged M edge for the large shapes."""
-    from candidate_reranking_cir_amd import lib
-    a = _ints((m, k), -3, 3, dtype, seed=m + k)
-    w = _ints((n, k), -3, 3, dtype, seed=n + k + 1)
-    bias = _ints((n,), -5, 5, torch.float32, seed=3)
-    pr = 24
-    big = torch.empty((n // 64, m + 2 * pr, 64), dtype=dtype, device="cuda")
-    big.view(_INT[dtype]).fill_(CANARY[dtype])
-    view = big[:, pr:pr + m, :]
-    lib.set_tuning(lib.TUNE_GEMM_TILE, tile)
-    try:
-        out = ops.gemm(a, w, bias, head_major=True, out=view)
-    finally:
-        lib.set_tuning(lib.TUNE_GEMM_TILE, 0)
-    torch.cuda.synchronize()
-    ref = (a.float() @ w.float().T + bias).to(dtype)
-    assert torch.equal(out.permute(1, 0, 2).reshape(m, n), ref)
-    bits = big.view(_INT[dtype]).clone()
-    bits[:, pr:pr + m, :] = CANARY[dtype]
-    assert bool((bits == CANARY[dtype]).all()), "a store left its slab"

@@ -235,27 +235,6 @@ def test_kv_bank_reuse_is_bit_identical(tiny):
     assert (np.abs(gours - gref) / gref.std(axis=1, keepdims=True)).max() < 2 * REL_TOL[dt]
 
 
-def test_head_major_projections_are_bit_neutral(tiny):
-    """The ViT's fused q|k|v and the per-candidate cross K|V are written head-major (cir_gemm_bias_act_slab) and read through
-    strides (cir_attention_hs): a change of layout only - tokens and logits equal the row-major schedule bit for bit."""
-    from candidate_reranking_cir_amd import validate_stage2 as V
-    z, g, v, m2, m1, dt = tiny
-    imgs = H.fixture_images(z, range(14), v.image_size)
-    ds = V.RelativeValSet(ref_index=z["refs"], cand_index=z["cand_idx"], labels=z["labels"], captions=[str(c) for c in z["cirr_caps"]],
-                          group_index=z["groups"], target_index=z["targets"])
-    vit, nlvr = m2.engines()
-    assert vit.head_major and nlvr.head_major
-    bank = V.extract_index_features(imgs, m2)
-    out = V.generate_val_predictions(m2, m1, ds, bank, query_batch=3)
-    try:
-        vit.head_major = nlvr.head_major = False
-        bank_rm = V.extract_index_features(imgs, m2)
-        out_rm = V.generate_val_predictions(m2, m1, ds, bank_rm, query_batch=3)
-    finally:
-        vit.head_major = nlvr.head_major = True
-    assert torch.equal(bank, bank_rm) and torch.equal(out[0], out_rm[0]) and torch.equal(out[1], out_rm[1])
-
-
 def test_last_layer_cls_trimming_is_equivalent(tiny):
     """The last layer's per-token work on CLS rows only gives the logits of the untrimmed schedule (same rows, same
     kernels up to the tile variant; bias enters the accumulator first or last)."""

@@ -456,45 +456,3 @@ def test_gemm_tile_choice_is_bit_invariant(ops, dtype, case):
         ref = mid + kw["residual"].float()
         ulp_of = lambda t: torch.maximum(t.abs(), torch.tensor(2.0 ** -14, device="cuda")).log2().floor().exp2() * 2.0 ** -10
         assert bool(((outs[128].float() - ref).abs() <= ulp_of(mid) * 0.51 + ulp_of(ref) * 0.51 + 1e-5).all())
-
-
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
-@pytest.mark.parametrize("act", ["none", "gelu"])
-def test_gemm_head_major_has_the_row_major_bits(ops, gemm_tile, dtype, act):
-    """The head-major output mode changes WHERE an element is stored, nothing else: (N / 64, M, 64) slabs == the row-major result
-    viewed the same way, bit for bit - plain and batched, ragged M."""
-    m, n, k = 1024 + 40, 512, 256
-    a, w = _rand((m, k), dtype, seed=31), _rand((n, k), dtype, 0.1, seed=32)
-    bias = _rand((n,), torch.float32, seed=33)
-    kw = {} if act == "none" else dict(act=ops.ACT_GELU)
-    rm = ops.gemm(a, w, bias, **kw)
-    hm = ops.gemm(a, w, bias, head_major=True, **kw)
-    assert hm.shape == (n // 64, m, 64) and torch.equal(hm.permute(1, 0, 2).reshape(m, n), rm)
-    a3, w3, b3 = torch.stack([a, a.flip(0)]), torch.stack([w, w.flip(0)]), torch.stack([bias, bias.flip(0)])
-    rm3 = ops.gemm(a3, w3, b3, **kw)
-    hm3 = ops.gemm(a3, w3, b3, head_major=True, **kw)
-    assert hm3.shape == (2, n // 64, m, 64) and torch.equal(hm3.permute(0, 2, 1, 3).reshape(2, m, n), rm3)
-
-
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
-@pytest.mark.parametrize("lq,lk,masked", [(197, 197, False), (32, 197, False), (32, 50, True), (500, 200, False)])
-def test_attention_reads_head_major_tensors(ops, dtype, lq, lk, masked):
-    """cir_attention_hs: q / k / v handed over as (B1, B0, L, H, 64) views of head-major tensors (head stride = slab stride) give
-    the bits of the row-major call - staged and streamed kernels, with and without a key mask, row-major context either way."""
-    b1, b0, h = 5, 2, 12
-    gen = torch.Generator(device="cpu").manual_seed(lq + 7 * lk)
-    q = torch.randn((b1, b0, lq, h * 64), generator=gen).to(dtype).cuda()
-    k = torch.randn((b1, b0, lk, h * 64), generator=gen).to(dtype).cuda()
-    v = torch.randn((b1, b0, lk, h * 64), generator=gen).to(dtype).cuda()
-    mask = None
-    if masked:
-        valid = torch.randint(1, lk + 1, (b1, b0), generator=gen)
-        mask = ((torch.arange(lk)[None, None] >= valid[..., None]).float() * -10000.0).cuda()
-    ref = ops.attention(q, k, v, torch.empty_like(q), 0.125, mask)
-    to_hm = lambda t: t.view(b1, b0, -1, h, 64).permute(3, 0, 1, 2, 4).contiguous().permute(1, 2, 3, 0, 4)   # storage (H, B1, B0, L, 64)
-    out = torch.empty_like(q)
-    ops.attention(to_hm(q), to_hm(k), to_hm(v), out, 0.125, mask)
-    assert torch.equal(out, ref)
-    out_hm = torch.empty((h, b1, b0, lq, 64), dtype=dtype, device="cuda").permute(1, 2, 3, 0, 4)                # head-major context too
-    ops.attention(q, to_hm(k), v, out_hm, 0.125, mask)
-    assert torch.equal(out_hm.reshape(b1, b0, lq, h * 64), ref)
