@@ -746,7 +746,7 @@ def main():
         # HBM bytes per launch of the dominant kernel: offline PMC passes of this same command (tools/collect_profiles.sh); the
         # summary names the workload and the hash of the kernel sources it was measured on - any other build reports null
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r3_pmc_summary.json")
+        tpath = os.path.join(ROOT, "profiles", "r4_pmc_summary.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             same = (tj.get("csrc_sha16") == csrc_sha16() and tj.get("queries") == q_n and tj.get("k") == k and tj.get("subset") == ns
@@ -755,7 +755,7 @@ def main():
             ent = tj.get("by_kernel", {}).get(dom_name) if same else None
             if ent:
                 traffic = round(ent["hbm_bytes_per_launch"])
-                traffic_src = ("profiles/r3_pmc_summary.json: offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these "
+                traffic_src = ("profiles/r4_pmc_summary.json: offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these "
                                "kernel sources (csrc_sha16 matches; not this run)")
         line = {
             "metric": "query-candidate triplets scored/sec at K=100", "value": round(value, 2), "unit": "triplets/s",

@@ -327,6 +327,17 @@ def main():
         row["added_rms_centred"] = float(np.sqrt(max(st["rms_centred"] ** 2 - base["rms_centred"] ** 2, 0.0)))
         json.dump(doc, open(path, "w"), indent=1)
         return print(which, "vit layers 6-8:", st)
+    if "tail" in sys.argv[2:]:       # what would a more precise TAIL (cls_head, last layer) buy in the default mode?
+        def go(name, pol):
+            st = stats(*run(fx, pol, max_q), fx)
+            print(f"{name:64s} max|d| {st['max_abs']:.2e} centred rms {st['rms_centred']:.2e} exact {st['exact']:.3f} tau {st['tau']:.4f} top10 {st['top10']:.2f}", flush=True)
+        go("default: fp16 operands + fp16 streams", Policy(HF, HF))
+        go("  + cls_head exact (fp32 operands)", Policy(HF, HF, [(lambda e, l, o, k: o == "cls", None)]))
+        go("  + cls_head exact + nlvr layer 11 exact (operands and stream)", Policy(HF, HF, [(lambda e, l, o, k: e == "nlvr" and (o == "cls" or l == 11), None)]))
+        go("  + cls_head exact + nlvr layers 10-11 stream fp32 only", Policy(HF, HF, [(lambda e, l, o, k: o == "cls" or (e == "nlvr" and l >= 10 and k == "s"), None)]))
+        for l0 in (11, 10, 9, 8, 6):
+            go(f"  + nlvr stream fp32 from layer {l0} on (operands fp16 everywhere)", Policy(HF, HF, [(lambda e, l, o, k, l0=l0: e == "nlvr" and l >= l0 and k == "s", None)]))
+        return
     if "fold" in sys.argv[2:]:
         for fold in (False, True):
             FOLD_LN[0] = fold

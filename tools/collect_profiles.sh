@@ -7,7 +7,7 @@
 # The profiled program is `python3 bench.py ...` directly after `--` (no env / bash -c hop: the profiler's preloaded
 # library has initialised the GPU before the program starts).
 set -euo pipefail
-TAG=${1:-r3}
+TAG=${1:-r4}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"

@@ -2,7 +2,7 @@
 # Secondary-configuration bench lines, per-shape GEMM table, stand-alone kernel timings (GPU box; run through gpurun from
 # the repo root):   bash tools/collect_secondary.sh r3   -> gpurun_out/<tag>_sec/*.json|txt   (copy what is judged into profiles/)
 set -uo pipefail
-TAG=${1:-r3}
+TAG=${1:-r4}
 O=gpurun_out/${TAG}_sec
 mkdir -p $O
 python bench.py --steps 20 --warmup 5 > $O/bench_default_20steps.json 2> $O/err.txt                                   # the driver's command
@@ -10,12 +10,15 @@ python bench.py --steps 80 --warmup 5 --no-cpu-baseline --no-precision-table > $
 python bench.py --queries 16 --steps 20 --warmup 5 --no-cpu-baseline --no-precision-table > $O/bench_q16.json 2>> $O/err.txt   # round 2's step size
 python bench.py --steps 10 --warmup 3 --skip-rate 0.25 --no-cpu-baseline --no-precision-table > $O/bench_skip025.json 2>> $O/err.txt
 python bench.py --k 50 --subset 0 --steps 10 --warmup 3 --no-cpu-baseline --no-precision-table > $O/bench_k50_fiq.json 2>> $O/err.txt
-python bench.py --k 200 --dtype f16 --queries 32 --steps 10 --warmup 3 --no-cpu-baseline --no-precision-table > $O/bench_k200_f16.json 2>> $O/err.txt
+python bench.py --k 200 --queries 32 --steps 10 --warmup 3 --no-cpu-baseline --no-precision-table > $O/bench_k200_f16.json 2>> $O/err.txt
+python bench.py --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-precision-table > $O/bench_bf16.json 2>> $O/err.txt                 # rounds 1-3 headline mode
+python bench.py --dtype mixed --steps 20 --warmup 5 --no-cpu-baseline --no-precision-table > $O/bench_mixed.json 2>> $O/err.txt
+python bench.py --stream-dtype split --steps 20 --warmup 5 --no-cpu-baseline --no-precision-table > $O/bench_f16_split.json 2>> $O/err.txt   # text stream fp32, ViT fp16
 python bench.py --image-size 384 --queries 16 --steps 6 --warmup 2 --no-cpu-baseline --no-precision-table > $O/bench_384px.json 2>> $O/err.txt
 python bench.py --mode bank --steps 10 --warmup 3 > $O/bench_bank_mode.json 2>> $O/err.txt
 python bench.py --mode loop > $O/bench_loop_mode.json 2>> $O/err.txt
 python bench.py --mode train --image-size 384 --steps 10 --warmup 3 > $O/bench_train_mode.json 2>> $O/err.txt                    # stage2_train.py step, B = 16
-python bench.py --mode train --image-size 384 --dtype f16 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_train_mode_f16.json 2>> $O/err.txt
+python bench.py --mode train --image-size 384 --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_train_mode_bf16.json 2>> $O/err.txt
 python bench.py --mode train --image-size 224 --train-batch 32 --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_train_mode_b32_224.json 2>> $O/err.txt
 Q=64 python tools/gemm_shapes.py $O/gemm_shapes.json > $O/gemm_shapes.txt 2>> $O/err.txt
 python tools/gemm_ab.py > $O/gemm_ab.txt 2>> $O/err.txt
