@@ -451,6 +451,9 @@ class NlvrTrainer:
         slab = self.slab
         if self.grad_scale != 1.0:
             slab.gflat = T.eltwise(slab.gflat, T.MODE_SCALE, p_drop=1.0 / self.grad_scale)
+        # fp16 operands: an intermediate gradient above 65504 turns into inf -> NaN in the weight gradients.  What GradScaler's
+        # found_inf does for the reference (stage2_train.py:215-218): one reduction, read by AdamW.step (which skips the update)
+        self.grads_finite = torch.isfinite(slab.gflat).all() if self.dtype == torch.float16 else None
         return {n: slab.grad(n) for n in slab.names}
 
 
@@ -533,6 +536,11 @@ class AdamW:
         if not ps:
             return
         if self.model is not None:
+            tr = getattr(self.model, "_trainer", None)
+            if tr is not None and getattr(tr, "grads_finite", None) is not None and not bool(tr.grads_finite):
+                self.t -= 1                                   # non-finite fp16 gradients: skip this update like GradScaler.step would
+                self.skipped_steps = getattr(self, "skipped_steps", 0) + 1
+                return
             self.model._text_stale = True                     # the weights change HERE: the next eval / score call repacks
         fp, fg = self._flat_range([p.data for p in ps]), self._flat_range([p.grad for p in ps])
         if fp is not None and fg is not None and fp[1] == fg[1] and all(p.data_ptr() - fp[0] == p.grad.data_ptr() - fg[0] for p in ps):

@@ -360,3 +360,17 @@ def test_backward_guards_and_engine_staleness(cuda):
     opt.step()
     after = m.img_txt_fusion(z_t, feats, caps)
     assert (after - before).abs().max().item() > 1e-3, "the inference engine still holds the pre-step weights"
+    # fp16 operands: non-finite gradients (an overflowed intermediate) skip the update, as GradScaler.step would
+    m2 = build(g, v, int(zf["seed"]), str(zf["profile"]), HF)[0]
+    freeze_vit(m2)
+    m2.train()
+    opt2 = AdamW([p for p in m2.parameters() if p.requires_grad], lr=1e-2, weight_decay=0.0, model=m2)
+    F.cross_entropy(m2.img_txt_fusion(z_t, feats, caps), gt).backward()
+    assert bool(m2._trainer.grads_finite)
+    w0 = m2.cls_head[0].weight.detach().clone() if hasattr(m2.cls_head, "__getitem__") else dict(m2.named_parameters())["cls_head.0.weight"].detach().clone()
+    m2._trainer.grads_finite = torch.tensor(False, device=cuda)                  # what an inf in the gradient buffer sets
+    opt2.step()
+    assert opt2.skipped_steps == 1 and opt2.t == 0 and torch.equal(dict(m2.named_parameters())["cls_head.0.weight"].detach(), w0)
+    m2._trainer.grads_finite = torch.tensor(True, device=cuda)
+    opt2.step()
+    assert opt2.t == 1 and not torch.equal(dict(m2.named_parameters())["cls_head.0.weight"].detach(), w0)
