@@ -345,18 +345,21 @@ class NlvrTrainer:
                 s["cat16"] = cat16
                 m = ly["merge"].fwd(cat16, torch.float32)
             m = self._drop(m, self._site(i, 2, 4))
-            h32n, h16n = [], []
+            # FFN: the SAME weights serve both branches (nlvr_encoder.py:469-476) - one pass over the 2R stacked rows (one GEMM pair,
+            # one GELU / dropout / LayerNorm launch, and in the backward one dgrad / wgrad product each instead of two half-sized ones)
+            pre2 = [T.eltwise(m, T.MODE_ADD, a32[b]) for b in (0, 1)]
+            x32 = torch.empty((2 * r, d), dtype=torch.float32, device=dev)
+            x16 = torch.empty((2 * r, d), dtype=dt, device=dev)
             for b in (0, 1):
-                pre2 = T.eltwise(m, T.MODE_ADD, a32[b])
-                x32, x16 = ly[f"ln2{b}"].fwd(pre2, dt)
-                z = ly["w1"].fwd(x16, torch.float32)
-                f16 = T.eltwise(z, T.MODE_GELU, out_dtype=dt)
-                o = self._drop(ly["w2"].fwd(f16, torch.float32), self._site(i, b, 5))
-                pre3 = T.eltwise(o, T.MODE_ADD, x32)
-                hn, hn16 = ly["ln3"].fwd(pre3, dt)
-                h32n.append(hn); h16n.append(hn16)
-                for key, val in (("pre2", pre2), ("x16", x16), ("z", z), ("f16", f16), ("pre3", pre3)):
-                    s[key].append(val)
+                ops.layernorm(pre2[b], ly[f"ln2{b}"].g, ly[f"ln2{b}"].b, g.layer_norm_eps, want32=True, dtype16=dt, stream_dtype=torch.float32,
+                              out32=x32[b * r:(b + 1) * r], out16=x16[b * r:(b + 1) * r])
+            z = ly["w1"].fwd(x16, torch.float32)
+            f16 = T.eltwise(z, T.MODE_GELU, out_dtype=dt)
+            o = self._drop(ly["w2"].fwd(f16, torch.float32), self._site(i, 0, 5))
+            pre3 = T.eltwise(o, T.MODE_ADD, x32)
+            hn, hn16 = ly["ln3"].fwd(pre3, dt)
+            h32n, h16n = [hn[:r], hn[r:]], [hn16[:r], hn16[r:]]
+            s.update(pre2=pre2, x16=x16, z=z, f16=f16, pre3=pre3)
             sv["layers"].append(s)
             h32, h16 = h32n, h16n
         # cat(CLS_0, CLS_1) -> cls_head (nlvr_encoder.py:906-908, blip_stage2.py:50-54, 94-99)
@@ -404,14 +407,12 @@ class NlvrTrainer:
         undrop = lambda x, site: x if self.p_hidden <= 0 else T.eltwise(x, T.MODE_DROPOUT, p_drop=self.p_hidden, seed=site)
         for i in reversed(range(len(self.layers))):
             ly, s = self.layers[i], sv["layers"][i]
-            dpre2 = []
-            for b in (0, 1):
-                dpre3 = ly["ln3"].bwd(s["pre3"][b], dh[b])
-                do = undrop(dpre3, self._site(i, b, 5))
-                df = ly["w2"].bwd(s["f16"][b], do)
-                dz = T.eltwise(s["z"][b], T.MODE_GELU_BWD, df)
-                dx = add(ly["w1"].bwd(s["x16"][b], dz), dpre3)
-                dpre2.append(ly[f"ln2{b}"].bwd(s["pre2"][b], dx))
+            dpre3 = ly["ln3"].bwd(s["pre3"], torch.cat([dh[0], dh[1]]))             # both branches: 2R stacked rows, shared FFN weights
+            do = undrop(dpre3, self._site(i, 0, 5))
+            df = ly["w2"].bwd(s["f16"], do)
+            dz = T.eltwise(s["z"], T.MODE_GELU_BWD, df)
+            dx = add(ly["w1"].bwd(s["x16"], dz), dpre3)
+            dpre2 = [ly[f"ln2{b}"].bwd(s["pre2"][b], dx[b * r:(b + 1) * r].contiguous()) for b in (0, 1)]
             dm = undrop(add(dpre2[0], dpre2[1]), self._site(i, 2, 4))
             if ly["merge"] is None:
                 half = T.eltwise(dm, T.MODE_SCALE, p_drop=0.5)
