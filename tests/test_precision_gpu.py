@@ -42,11 +42,11 @@ def order_stats(ours: np.ndarray, ref: np.ndarray):
 # mode -> (text operands, image operands or None, text stream, ViT stream), bound on max|dlogit| (the fixture's logit sigma is only
 # 0.027: the outlier channels dominate every LayerNorm's statistics and compress the informative signal), floor on Kendall tau,
 # floor on the top-10 overlap.  Measured on MI355X (round 4, tools/precision_modes.py -> profiles/r4_precision_modes.json):
-#   bf16, fp16 streams (round 1-3 headline)            3.6e-2 / tau 0.636 / top-10 0.50     16.7 k triplets/s
-#   mixed (ViT + cross block bf16, text fp16), fp16     1.2e-2 / tau 0.916 / top-10 0.85     16.8 k
-#   fp16, fp16 streams  (LIBRARY DEFAULT)               9.5e-3 / tau 0.910 / top-10 0.90     16.4 k
-#   fp16, text stream fp32, ViT stream fp16 ("split")   5.9e-3 / tau 0.944 / top-10 0.85     15.8 k
-#   fp16, fp32 streams                                  5.1e-3 / tau 0.939 / top-10 0.90     15.0 k
+#   bf16, fp16 streams (round 1-3 headline)            4.2e-2 / tau 0.647 / top-10 0.50     16.8 k triplets/s
+#   mixed (ViT + cross block bf16, text fp16), fp16     8.9e-3 / tau 0.909 / top-10 0.90     16.9 k
+#   fp16, fp16 streams  (LIBRARY DEFAULT)               1.1e-2 / tau 0.906 / top-10 0.85     16.6 k
+#   fp16, text stream fp32, ViT stream fp16 ("split")   3.5e-3 / tau 0.942 / top-10 0.95     15.9 k
+#   fp16, fp32 streams                                  3.4e-3 / tau 0.942 / top-10 0.95     15.0 k
 # The per-site attribution (oracle/attribute_rounding.py, profiles/r4_precision_attribution_outlier.json) says where the bf16
 # error enters on THIS fixture: the text-side self-attention / FFN / cls_head activations (ViT and cross block in bf16: tau
 # unchanged) - which is what "mixed" keeps in fp16; on well-conditioned weights (rank224) the bf16 WEIGHT rounding of the ViT

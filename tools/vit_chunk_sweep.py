@@ -15,7 +15,7 @@ eng = m2.engines(text=False)[0]
 n = 6784
 images = torch.randn((n, 3, 224, 224), generator=torch.Generator(device=dev).manual_seed(1), device=dev).to(m2.token_dtype)
 out = torch.empty((n, 197, 768), dtype=m2.token_dtype, device=dev)
-for chunk in (2048, 1132, 848, 680, 424, 340, 212):
+for chunk in ([int(c) for c in sys.argv[2].split(",")] if len(sys.argv) > 2 else (2048, 1132, 848, 680, 424, 340, 212)):
     for rep in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         eng.forward(images, chunk=chunk, out16=out)
