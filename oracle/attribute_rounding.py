@@ -42,7 +42,7 @@ class Policy:
         for pred, dt in self.rules:
             if pred(eng, layer, op, kind):
                 return dt
-        return self.stream if kind == "s" else self.base
+        return self.stream if kind in ("s", "t") else self.base
 
 
 POL = [None]
@@ -150,18 +150,18 @@ def med(w, ids, mask, enc32, prefix="text_encoder.", eps=1e-12):
         h = rq(hs, (E, i, "qkv", "a"))
         q, k, v = (rq(lin(w, a + n, h, (E, i, "qkv")), (E, i, "qkv", "o")) for n in ("query", "key", "value"))
         ctx = sdpa(q, k, v, sm, 12, (E, i, "attn"))
-        t = rq(lin(w, p + "attention.output.dense", ctx, (E, i, "proj")) + hs, (E, i, "proj", "s"))
+        t = rq(lin(w, p + "attention.output.dense", ctx, (E, i, "proj")) + hs, (E, i, "proj", "t"))
         hs = rq(ln(w, p + "attention.output.LayerNorm", t, eps), (E, i, "proj", "s"))
         c = p + "crossattention.self."
         h = rq(hs, (E, i, "cq", "a"))
         q = rq(lin(w, c + "query", h, (E, i, "cq")), (E, i, "cq", "o"))
         k, v = (rq(lin(w, c + n, enc, (E, i, "ckv")), (E, i, "ckv", "o")) for n in ("key", "value"))
         ctx = sdpa(q, k, v, None, 12, (E, i, "cattn"))
-        t = rq(lin(w, p + "crossattention.output.dense", ctx, (E, i, "cproj")) + hs, (E, i, "cproj", "s"))
+        t = rq(lin(w, p + "crossattention.output.dense", ctx, (E, i, "cproj")) + hs, (E, i, "cproj", "t"))
         hs = rq(ln(w, p + "crossattention.output.LayerNorm", t, eps), (E, i, "cproj", "s"))
         h = rq(hs, (E, i, "fc1", "a"))
         f = rq(F.gelu(lin(w, p + "intermediate.dense", h, (E, i, "fc1"))), (E, i, "fc1", "o"))
-        t = rq(lin(w, p + "output.dense", f, (E, i, "fc2")) + hs, (E, i, "fc2", "s"))
+        t = rq(lin(w, p + "output.dense", f, (E, i, "fc2")) + hs, (E, i, "fc2", "t"))
         hs = rq(ln(w, p + "output.LayerNorm", t, eps), (E, i, "fc2", "s"))
     return hs                                          # z_t: the API hands fp32 of the stream copy on
 
@@ -180,7 +180,7 @@ def nlvr(w, ids, mask, z_t, cand32, prefix="text_encoder.", eps=1e-12):
             h = rq(hs[b], (E, i, "qkv", "a"))
             q, k, v = (rq(lin(w, s + n, h, (E, i, "qkv")), (E, i, "qkv", "o")) for n in ("query", "key", "value"))
             ctx = sdpa(q, k, v, sm, 12, (E, i, "attn"))
-            t = rq(lin(w, f"{p}attention.output.dense{b}", ctx, (E, i, "proj")) + hs[b], (E, i, "proj", "s"))
+            t = rq(lin(w, f"{p}attention.output.dense{b}", ctx, (E, i, "proj")) + hs[b], (E, i, "proj", "t"))
             att.append(rq(ln(w, p + "attention.output.LayerNorm" + "AB"[b], t, eps), (E, i, "proj", "s")))
         dd = []
         for b in (0, 1):
@@ -192,12 +192,12 @@ def nlvr(w, ids, mask, z_t, cand32, prefix="text_encoder.", eps=1e-12):
             dd.append(lin(w, f"{p}crossattention.output.dense{b}", ctx, (E, i, "cproj")))     # folded with the merge: no store between
         mk = p + "crossattention.output.merge_layer"
         m = lin(w, mk, torch.cat(dd, -1), (E, i, "cproj")) if mk + ".weight" in w else (dd[0] + dd[1]) / 2
-        m = rq(m, (E, i, "cproj", "s"))
+        m = rq(m, (E, i, "cproj", "t"))
         x = [rq(ln(w, p + "crossattention.output.LayerNorm" + "AB"[b], m + att[b], eps), (E, i, "cproj", "s")) for b in (0, 1)]
         for b in (0, 1):
             h = rq(x[b], (E, i, "fc1", "a"))
             f = rq(F.gelu(lin(w, p + "intermediate.dense", h, (E, i, "fc1"))), (E, i, "fc1", "o"))
-            t = rq(lin(w, p + "output.dense", f, (E, i, "fc2")) + x[b], (E, i, "fc2", "s"))
+            t = rq(lin(w, p + "output.dense", f, (E, i, "fc2")) + x[b], (E, i, "fc2", "t"))
             hs[b] = rq(ln(w, p + "output.LayerNorm", t, eps), (E, i, "fc2", "s"))
     hid = rq(torch.cat([hs[0][:, 0], hs[1][:, 0]], -1), (E, 12, "cls", "a"))
     y = rq(F.relu(lin(w, "cls_head.0", hid, (E, 12, "cls"))), (E, 12, "cls", "o"))
@@ -327,6 +327,16 @@ def main():
         row["added_rms_centred"] = float(np.sqrt(max(st["rms_centred"] ** 2 - base["rms_centred"] ** 2, 0.0)))
         json.dump(doc, open(path, "w"), indent=1)
         return print(which, "vit layers 6-8:", st)
+    if "sums" in sys.argv[2:]:       # text-side stream: is it the pre-LayerNorm SUMS (GEMM outputs) or the LayerNorm OUTPUTS that need fp32?
+        def go(name, pol):
+            st = stats(*run(fx, pol, max_q), fx)
+            print(f"{name:64s} max|d| {st['max_abs']:.2e} centred rms {st['rms_centred']:.2e} exact {st['exact']:.3f} tau {st['tau']:.4f} top10 {st['top10']:.2f}", flush=True)
+        txt = lambda e: e in ("med", "nlvr")
+        go("fp16 operands, fp16 streams (default)", Policy(HF, HF))
+        go("  text-side pre-LN sums fp32, LN outputs fp16", Policy(HF, HF, [(lambda e, l, o, k: txt(e) and k == "t", None)]))
+        go("  text-side LN outputs fp32, pre-LN sums fp16", Policy(HF, HF, [(lambda e, l, o, k: txt(e) and k == "s", None)]))
+        go("  both fp32 (split)", Policy(HF, HF, [(lambda e, l, o, k: txt(e) and k in ("s", "t"), None)]))
+        return
     if "tail" in sys.argv[2:]:       # what would a more precise TAIL (cls_head, last layer) buy in the default mode?
         def go(name, pol):
             st = stats(*run(fx, pol, max_q), fx)
