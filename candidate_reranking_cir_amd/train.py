@@ -486,10 +486,22 @@ class _FusionTrainFn(torch.autograd.Function):
                                "reverse pass keeps one gradient buffer per forward; run the forward again")
         tr.consumed = True
         grads = tr.backward(dlogits.contiguous().float())
-        for name, p in tr.model.named_parameters():
-            if name in grads and p.requires_grad:
-                gq = grads[name]
+        slab = tr.slab
+        live = [(n, p) for n, p in tr.model.named_parameters() if n in grads and p.requires_grad]
+        # Gradient accumulation over micro-batches (stage2_train.py's grad_accumulation_step): when every .grad is still a slice of the
+        # flat buffer a previous backward installed, ONE flat add folds it into the new buffer and .grad is re-pointed to the new
+        # slices - so the optimizer keeps its one-launch flat path (per-tensor adds: ~570 launches, and AdamW falls back to 570 more)
+        prev = getattr(tr, "acc_gflat", None)
+        if (prev is not None and prev is not slab.gflat and prev.numel() == slab.gflat.numel()
+                and all(p.grad is not None and p.grad.data_ptr() == prev.data_ptr() + 4 * slab.off[n] and p.grad.is_contiguous() for n, p in live)):
+            slab.gflat = T.eltwise(slab.gflat, T.MODE_ADD, prev)
+            for n, p in live:
+                p.grad = slab.grad(n)
+        else:
+            for n, p in live:
+                gq = grads[n]
                 p.grad = gq if p.grad is None else T.eltwise(p.grad.contiguous(), T.MODE_ADD, gq.contiguous())
+        tr.acc_gflat = slab.gflat
         return None, None, None, None, None, None
 
 

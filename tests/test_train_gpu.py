@@ -374,3 +374,39 @@ def test_backward_guards_and_engine_staleness(cuda):
     m2._trainer.grads_finite = torch.tensor(True, device=cuda)
     opt2.step()
     assert opt2.t == 1 and not torch.equal(dict(m2.named_parameters())["cls_head.0.weight"].detach(), w0)
+
+
+def test_gradient_accumulation_keeps_the_flat_path(cuda):
+    """Two micro-batches before one optimizer step (stage2_train.py's grad_accumulation_step): .grad after the second backward is
+    the sum of both passes' gradients, still laid out as slices of ONE flat buffer, and train.AdamW takes its one-launch path."""
+    from candidate_reranking_cir_amd.train import AdamW
+    zf, g, v, _, _ = H.tiny_setup()
+    m = build(g, v, int(zf["seed"]), str(zf["profile"]), BF)[0]
+    freeze_vit(m)
+    m.train()
+    caps = [synthetic.caption_text(90 + i, n) for i, n in enumerate((4, 8, 6))]
+    rng = torch.Generator().manual_seed(7)
+    l = H.tokenize(caps)[0].shape[1]
+    z_t = torch.randn((3, l, g.hidden_size), generator=rng).cuda()
+    feats = torch.randn((3, 17, g.encoder_width), generator=rng).cuda()
+    gt = torch.arange(3, device=cuda)
+    g_tr = m.bert_geometry
+    g_tr.hidden_dropout_prob = g_tr.attention_probs_dropout_prob = 0.0          # deterministic passes: the sum is checkable
+    ps = [p for p in m.parameters() if p.requires_grad]
+    (F.cross_entropy(m.img_txt_fusion(z_t, feats, caps), gt) / 2).backward()
+    g1 = [p.grad.detach().clone() for p in ps if p.grad is not None]
+    (F.cross_entropy(m.img_txt_fusion(z_t.flip(0), feats, caps), gt) / 2).backward()
+    live = [p for p in ps if p.grad is not None]
+    m2 = build(g, v, int(zf["seed"]), str(zf["profile"]), BF)[0]
+    freeze_vit(m2); m2.train()
+    m2.bert_geometry.hidden_dropout_prob = m2.bert_geometry.attention_probs_dropout_prob = 0.0
+    (F.cross_entropy(m2.img_txt_fusion(z_t.flip(0), feats, caps), gt) / 2).backward()
+    g2 = [p.grad.detach().clone() for p in m2.parameters() if p.requires_grad and p.grad is not None]
+    assert len(g1) == len(g2) == len(live) > 300
+    worst = max(((p.grad - (a + b)).abs().max() / ((a + b).abs().max() + 1e-12)).item() for p, a, b in zip(live, g1, g2))
+    print(f"\\n[grad accumulation] max relative deviation from the sum of the two passes {worst:.2e}")
+    assert worst < 1e-5
+    opt = AdamW(ps, lr=1e-3)
+    assert AdamW._flat_range([p.grad for p in live]) is not None                 # still slices of one flat buffer
+    opt.step()
+    assert opt._flat is not None                                                 # ... and the optimizer took the flat path
