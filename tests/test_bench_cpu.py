@@ -50,3 +50,22 @@ def test_launcher_starts_one_child_per_rank_and_relays_failure(tmp_path, monkeyp
     assert len({g[4] for g in got}) == 1 and int(got[0][4]) > 0
     monkeypatch.setenv("FAIL_RANK", "1")
     assert b.launch_ranks(3) == 7
+
+
+def test_precision_flags_map_to_model_settings():
+    """--dtype / --stream-dtype -> BLIP_NLVR settings (no GPU: the engines are only packed on first use) and the names the JSON line prints."""
+    import torch
+    from candidate_reranking_cir_amd import config
+    from candidate_reranking_cir_amd.blip_stage2 import BLIP_NLVR
+    b = _bench()
+    m = BLIP_NLVR(med_config=config.BertGeometry(hidden_size=128, num_attention_heads=2, num_hidden_layers=2, intermediate_size=256, encoder_width=128),
+                  vit_geometry=config.VitGeometry(image_size=64, width=128, depth=2, num_heads=2), tokenizer=None)
+    assert (m.precision, m.stream_dtype, m.vit_stream_dtype) == ("f16", torch.float16, torch.float16) and b.DEFAULT_DTYPE == "f16"   # library defaults
+    want = {("f16", "auto"): ("f16", torch.float16, None, "f16"), ("bf16", "auto"): ("bf16", torch.bfloat16, None, "f16"),
+            ("mixed", "auto"): ("mixed", torch.float16, torch.bfloat16, "f16"), ("f16", "split"): ("f16", torch.float16, None, "split"),
+            ("f16", "f32"): ("f16", torch.float16, None, "f32"), ("bf16", "f32"): ("bf16", torch.bfloat16, None, "f32")}
+    for (dtype, stream), (prec, cdt, idt, sname) in want.items():
+        b.apply_precision(m, dtype, stream)
+        assert (m.precision, m.compute_dtype, m.image_dtype, b.stream_name(m)) == (prec, cdt, idt, sname)
+        assert m.token_dtype == (idt or cdt)
+    assert set(b.PRECISION_NOTE) == {"f16", "bf16", "mixed"} == set(b.PEAK_TFLOPS)
