@@ -178,6 +178,7 @@ class NlvrTrainer:
         self.step_no = 0
         self._hd = self.geo.hidden_size // self.geo.num_attention_heads
         self._scale = self._hd ** -0.5
+        self.fused_attention = True       # cir_attention_train_fwd / _bwd (head dimension 64); False: the un-fused bmm / softmax chain
 
     # ------------------------------------------------------------------------------------------------ parameters
     _EMB = "text_encoder.embeddings."
@@ -265,6 +266,12 @@ class NlvrTrainer:
         values exist once."""
         nb1, h_n, mq, _ = q4.shape
         mk, d = k4.shape[2], self.geo.hidden_size
+        if self.fused_attention and self._hd == 64:
+            # round 4: ONE kernel - scores, mask, softmax, dropout, P.V tile by tile in registers - and a log-sum-exp per row for the
+            # recomputing backward; no score / probability tensor is materialised (cir_attention_train_fwd)
+            ctx = torch.empty((nb1 * mq, d), dtype=q4.dtype, device=q4.device)
+            lse = T.attention_train_fwd(q4, k4, v4, mask, self._heads(ctx, nb1, mq), self._scale, self.p_attn, site)
+            return ctx, (lse, mask, site, ctx)
         ld = (mk + 7) // 8 * 8                                                       # padded score rows: 16-byte loads in cir_bmm
         s = torch.empty((nb1, h_n, mq, ld), dtype=torch.float32, device=q4.device)
         T.bmm(q4, k4, False, True, out=s[..., :mk])
@@ -276,8 +283,13 @@ class NlvrTrainer:
     def _attn_bwd(self, dctx, q4, k4, v4, saved, dq4, dk4, dv4):
         """dctx fp32 (G*mq, D) -> dq4 / dk4 / dv4: fp32 head views the gradients are written into (slices of the buffer the fused
         projection's backward reads)."""
-        p, pd, site = saved
         nb1, h_n, mq, _ = q4.shape
+        if len(saved) == 4:                                                          # fused pair (see _attn_fwd)
+            lse, mask, site, ctx = saved
+            T.attention_train_bwd(q4, k4, v4, mask, self._heads(ctx, nb1, mq), self._heads(_cast(dctx, q4.dtype), nb1, mq), lse, dq4, dk4, dv4,
+                                  self._scale, self.p_attn, site)
+            return
+        p, pd, site = saved
         mk, ld = k4.shape[2], p.shape[1]
         dc = self._heads(_cast(dctx, q4.dtype), nb1, mq)
         pd4 = pd.view(nb1, h_n, mq, ld)[..., :mk]

@@ -87,6 +87,43 @@ def softmax_dropout_bwd(p: torch.Tensor, dpd: torch.Tensor, scale: float, p_drop
     return ds
 
 
+def _hv(t: torch.Tensor):
+    """(G, H, rows, 64) head view -> (pointer, group / head / row strides); unit last stride."""
+    assert t.dim() == 4 and t.shape[3] == 64 and t.stride(3) == 1
+    return t.data_ptr(), t.stride(0), t.stride(1), t.stride(2)
+
+
+def attention_train_fwd(q4: torch.Tensor, k4: torch.Tensor, v4: torch.Tensor, mask: Optional[torch.Tensor], out4: torch.Tensor, scale: float,
+                        p_drop: float, seed: int) -> torch.Tensor:
+    """Fused training attention (cir_attention_train_fwd): q4 / out4 (G, H, Lq, 64), k4 / v4 (G, H, Lk, 64) 16-bit head views, mask fp32
+    (G, Lk) additive or None; writes out4, returns the log2-domain log-sum-exp (G, H, Lq) fp32 the backward needs."""
+    _need_cuda(q4, k4, v4, mask, out4)
+    g, h, lq, _ = q4.shape
+    lk = k4.shape[2]
+    assert k4.shape == v4.shape == (g, h, lk, 64) and out4.shape == q4.shape and q4.dtype == k4.dtype == v4.dtype == out4.dtype
+    if mask is not None:
+        assert mask.dtype == torch.float32 and mask.shape == (g, lk) and mask.is_contiguous()
+    lse = torch.empty((g, h, lq), dtype=torch.float32, device=q4.device)
+    _lib.check(_lib.load().cir_attention_train_fwd(*_hv(q4), *_hv(k4), *_hv(v4), _ptr(mask), *_hv(out4), lse.data_ptr(), g, h, lq, lk, float(scale),
+                                                   float(p_drop), int(seed) & (2 ** 63 - 1), _DT[q4.dtype], _stream()), "cir_attention_train_fwd")
+    return lse
+
+
+def attention_train_bwd(q4, k4, v4, mask, out4, dout4, lse, dq4, dk4, dv4, scale: float, p_drop: float, seed: int):
+    """Recomputing backward of `attention_train_fwd`: dout4 16-bit in out4's layout; dq4 / dk4 / dv4 fp32 head views (written)."""
+    _need_cuda(q4, k4, v4, mask, out4, dout4, lse, dq4, dk4, dv4)
+    g, h, lq, _ = q4.shape
+    lk = k4.shape[2]
+    assert dout4.shape == out4.shape and dout4.stride() == out4.stride() and dout4.dtype == out4.dtype == q4.dtype
+    assert lse.shape == (g, h, lq) and lse.is_contiguous() and lse.dtype == torch.float32
+    assert dq4.shape == q4.shape and dk4.shape == k4.shape and dv4.shape == v4.shape and dq4.dtype == dk4.dtype == dv4.dtype == torch.float32
+    dsum = torch.empty((g, h, lq), dtype=torch.float32, device=q4.device)
+    qo = _hv(out4)
+    _lib.check(_lib.load().cir_attention_train_bwd(*_hv(q4), *_hv(k4), *_hv(v4), _ptr(mask), qo[0], dout4.data_ptr(), qo[1], qo[2], qo[3], lse.data_ptr(),
+                                                   dsum.data_ptr(), *_hv(dq4), *_hv(dk4), *_hv(dv4), g, h, lq, lk, float(scale), float(p_drop),
+                                                   int(seed) & (2 ** 63 - 1), _DT[q4.dtype], _stream()), "cir_attention_train_bwd")
+
+
 def layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor, eps: float) -> torch.Tensor:
     """x, dy fp32 (rows, cols) contiguous; dgamma / dbeta fp32 (cols) are ACCUMULATED into -> dx fp32."""
     _need_cuda(x, gamma, dy, dgamma, dbeta)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CIR_ABI_VERSION 8
+#define CIR_ABI_VERSION 9
 
 enum { CIR_BF16 = 0, CIR_F16 = 1, CIR_F32 = 2 };
 enum { CIR_ACT_NONE = 0, CIR_ACT_GELU = 1, CIR_ACT_RELU = 2 };
@@ -220,6 +220,23 @@ int cir_softmax_dropout(const float* S, int64_t ld_s, const float* mask, int64_t
 /* dS = scale * P * (dP - sum_cols(dP * P)), dP = dropout-backward(dPd) with the forward's (p_drop, seed); dPd fp32, dS 16-bit. */
 int cir_softmax_dropout_bwd(const void* P, int64_t ld_p, const float* dPd, int64_t ld_d, void* dS, int64_t ld_ds, int64_t rows, int cols,
                             float scale, float p_drop, uint64_t seed, int dtype, void* stream);
+/* FUSED attention of the training pass (round 4): out = dropout(softmax(q k^T * scale + mask)) v per (group, head), head dimension 64, with
+ * the log2-domain log-sum-exp of every row written to lse (G, H, Lq) - and its recomputing backward: dq / dk / dv (fp32) from q, k, v,
+ * out, d_out and lse; the probabilities are recomputed tile by tile and the dropout mask regenerated from its counter (element index
+ * ((g * H + h) * Lq + query) * Lk + key), so no score / probability tensor exists in memory.  Tensors are head views: element
+ * (g, h, row, d) at base + g * x_sg + h * x_sh + row * x_sr + d; out and d_out share one layout; mask fp32 (G, Lk) additive or NULL;
+ * dsum_scratch fp32 (G * H * Lq) receives rowsum(d_out * out).  Replaces, for BertSelfAttention.forward in train() mode
+ * (nlvr_encoder.py:140-222, dropout :207) and its adjoint, the cir_bmm / cir_softmax_dropout[_bwd] chain. */
+int cir_attention_train_fwd(const void* q, int64_t q_sg, int64_t q_sh, int64_t q_sr, const void* k, int64_t k_sg, int64_t k_sh, int64_t k_sr,
+                            const void* v, int64_t v_sg, int64_t v_sh, int64_t v_sr, const float* mask, void* out, int64_t o_sg, int64_t o_sh,
+                            int64_t o_sr, float* lse, int G, int H, int Lq, int Lk, float scale, float p_drop, uint64_t seed, int dtype,
+                            void* stream);
+int cir_attention_train_bwd(const void* q, int64_t q_sg, int64_t q_sh, int64_t q_sr, const void* k, int64_t k_sg, int64_t k_sh, int64_t k_sr,
+                            const void* v, int64_t v_sg, int64_t v_sh, int64_t v_sr, const float* mask, const void* out, const void* d_out,
+                            int64_t o_sg, int64_t o_sh, int64_t o_sr, const float* lse, float* dsum_scratch, float* dq, int64_t dq_sg,
+                            int64_t dq_sh, int64_t dq_sr, float* dk, int64_t dk_sg, int64_t dk_sh, int64_t dk_sr, float* dv, int64_t dv_sg,
+                            int64_t dv_sh, int64_t dv_sr, int G, int H, int Lq, int Lk, float scale, float p_drop, uint64_t seed, int dtype,
+                            void* stream);
 /* LayerNorm backward from the saved fp32 input x of the forward: dx (written), dgamma / dbeta (fp32, ACCUMULATED atomically). */
 int cir_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int64_t rows, int cols,
                       float eps, void* stream);

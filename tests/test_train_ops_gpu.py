@@ -1,4 +1,5 @@
 """Training-mode operators (include/cirrank.h) against plain fp32 PyTorch on the MI355X."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -171,3 +172,64 @@ def test_colsum_embed_adamw(T):
         opt.step()
         T.adamw_step(p, g, m, v, 1e-3, (0.9, 0.98), 1e-7, 0.05, step)
     torch.testing.assert_close(p, pt.data, atol=1e-6, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ fused training attention (round 4)
+def _keep_mask(seed: int, g: int, h: int, lq: int, lk: int, p: float) -> torch.Tensor:
+    """The dropout mask of cir_attention_train_fwd / _bwd regenerated on the host: splitmix64 of (seed, ((g*H+h)*Lq+q)*Lk+key) >= p."""
+    idx = np.arange(g * h * lq * lk, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (idx + np.uint64(1))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return torch.from_numpy((u >= np.float32(p)).reshape(g, h, lq, lk))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("g,h,lq,lk,masked,p", [(5, 2, 9, 9, True, 0.0), (3, 12, 32, 32, True, 0.1), (2, 3, 70, 45, False, 0.1),
+                                                  (2, 12, 512, 577, False, 0.1), (4, 2, 33, 100, True, 0.25)])
+def test_fused_training_attention_matches_torch_autograd(T, dtype, g, h, lq, lk, masked, p):
+    """cir_attention_train_fwd / _bwd against torch autograd of dropout(softmax(q k^T * scale + mask)) v with the SAME dropout mask
+    (regenerated on the host from the kernel's counter): context, log-sum-exp, dQ, dK, dV - self-attention shapes (ragged 9 x 9 with a
+    key mask), the stacked cross-attention shape of the training step (512 queries x 577 keys), strided head views (fused q|k|v rows)."""
+    dev = torch.device("cuda")
+    gen = torch.Generator().manual_seed(g * 1000 + lq * 10 + lk)
+    qkv = torch.randn((g * lq, 3, h * 64), generator=gen).to(dtype).to(dev)                       # fused projection rows: strided head views
+    kvx = torch.randn((g * lk, 2, h * 64), generator=gen).to(dtype).to(dev)
+    heads = lambda x, rows, part, parts: x.view(g, rows, parts, h, 64)[:, :, part].permute(0, 2, 1, 3)
+    q4 = heads(qkv, lq, 0, 3)
+    k4, v4 = (heads(kvx, lk, 0, 2), heads(kvx, lk, 1, 2))
+    mask = None
+    if masked:
+        valid = torch.randint(1, lk + 1, (g,), generator=gen)
+        mask = ((torch.arange(lk)[None] >= valid[:, None]).float() * -10000.0).to(dev).contiguous()
+    scale, seed = 0.125, 123456789 + lq
+    ctx = torch.empty((g * lq, h * 64), dtype=dtype, device=dev)
+    out4 = ctx.view(g, lq, h, 64).permute(0, 2, 1, 3)
+    lse = T.attention_train_fwd(q4, k4, v4, mask, out4, scale, p, seed)
+    dout = (torch.randn((g * lq, h * 64), generator=gen) * 0.5).to(dtype).to(dev)
+    dq = torch.full((g * lq, 3, h * 64), float("nan"), dtype=torch.float32, device=dev)
+    dkv = torch.full((g * lk, 2, h * 64), float("nan"), dtype=torch.float32, device=dev)
+    T.attention_train_bwd(q4, k4, v4, mask, out4, dout.view(g, lq, h, 64).permute(0, 2, 1, 3), lse, heads(dq, lq, 0, 3), heads(dkv, lk, 0, 2),
+                          heads(dkv, lk, 1, 2), scale, p, seed)
+    torch.cuda.synchronize()
+    # ---- torch reference (fp32, same operands, same mask)
+    qf, kf, vf = (t.float().detach().clone().requires_grad_(True) for t in (q4, k4, v4))
+    s = qf @ kf.transpose(-1, -2) * scale
+    if mask is not None:
+        s = s + mask[:, None, None, :]
+    pr = torch.softmax(s, -1)
+    keep = _keep_mask(seed, g, h, lq, lk, p).to(dev) if p > 0 else torch.ones_like(pr, dtype=torch.bool)
+    o_ref = (pr * keep / (1.0 - p)) @ vf
+    o_ref.backward(dout.float().view(g, lq, h, 64).permute(0, 2, 1, 3))
+    lse_ref = torch.logsumexp(s, -1) * 1.4426950408889634
+    tol = 3e-2 if dtype == torch.bfloat16 else 4e-3
+    e_o = (out4.float() - o_ref).abs().max().item()
+    e_l = (lse - lse_ref).abs().max().item()
+    rel = lambda a, b: ((a - b).norm() / (b.norm() + 1e-12)).item()
+    e_q, e_k, e_v = rel(heads(dq, lq, 0, 3), qf.grad), rel(heads(dkv, lk, 0, 2), kf.grad), rel(heads(dkv, lk, 1, 2), vf.grad)
+    print(f"\\n[fused train attention {dtype} {g}x{h} {lq}x{lk} mask={masked} p={p}] ctx {e_o:.2e}  lse {e_l:.2e}  dq {e_q:.2e}  dk {e_k:.2e}  dv {e_v:.2e}")
+    assert e_o < tol and e_l < 2e-3 and max(e_q, e_k, e_v) < (2e-2 if dtype == torch.bfloat16 else 3e-3)
+    assert torch.isfinite(dq[:, 0]).all() and torch.isfinite(dkv).all() and torch.isnan(dq[:, 1:]).all()      # only the q slice of the fused buffer is written
