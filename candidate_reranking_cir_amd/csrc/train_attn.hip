@@ -33,6 +33,8 @@ struct TAttnArgs {
     const void* k; int64_t k_sg, k_sh, k_sr;
     const void* v; int64_t v_sg, v_sh, v_sr;
     const void* o; const void* d_o; int64_t o_sg, o_sh, o_sr;     // O (forward: written) and dO share one layout
+    float* o32; const float* do32;                                // optional fp32 twins of O / dO in the same layout: D = rowsum(dO * O) is then
+                                                                  // formed from them (rounding O to 16 bits first costs the bias gradients 2-3x)
     const float* mask;                                            // additive key mask (G, Lk) contiguous, or null
     float* lse;                                                   // (G, H, Lq) log2-domain log-sum-exp (forward: written)
     float* dsum;                                                  // (G, H, Lq) D = rowsum(dO * O) (dQ kernel: written; dK/dV kernel: read)
@@ -206,6 +208,7 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const TAttnArgs a) {
                 pk.y = pack2<T>(o[dt][qd * 4 + 2] * inv, o[dt][qd * 4 + 3] * inv);
                 *reinterpret_cast<u32x2*>(op + dt * 32 + 8 * qd) = pk;
             }
+        if (a.o32 != nullptr) store_f32(o, a.o32 + g * a.o_sg + h * a.o_sh + (int64_t)(q0 + r) * a.o_sr + 4 * hh, inv);
         if (hh == 0) a.lse[gh * a.Lq + q0 + r] = m_run + log2f(l_run);
     }
 }
@@ -248,12 +251,23 @@ __global__ __launch_bounds__(256) void tattn_bwd_dq_kernel(const TAttnArgs a) {
     // D = rowsum(dO * O): this lane holds 32 of the row's 64 dh of both
     float dsum = 0.f;
     {
-        X8 of[4];
-        frag_load<T>(reinterpret_cast<const T*>(a.o) + orow, of);
+        if (a.o32 != nullptr && a.do32 != nullptr) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dsum = fmaf(static_cast<float>(dof[s][j]), static_cast<float>(of[s][j]), dsum);
+                for (int half = 0; half < 2; ++half) {
+                    const float4 x = *reinterpret_cast<const float4*>(a.o32 + orow + 16 * s + 4 * half);
+                    const float4 y = *reinterpret_cast<const float4*>(a.do32 + orow + 16 * s + 4 * half);
+                    dsum = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, fmaf(x.w, y.w, dsum))));
+                }
+        } else {
+            X8 of[4];
+            frag_load<T>(reinterpret_cast<const T*>(a.o) + orow, of);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dsum = fmaf(static_cast<float>(dof[s][j]), static_cast<float>(of[s][j]), dsum);
+        }
         dsum += __shfl_xor(dsum, 32, 64);
         if (hh == 0 && q0 + r < a.Lq) a.dsum[gh * a.Lq + q0 + r] = dsum;
     }
@@ -404,15 +418,16 @@ static int tattn_check(const TAttnArgs& a, int dtype) {
 
 extern "C" int cir_attention_train_fwd(const void* q, int64_t q_sg, int64_t q_sh, int64_t q_sr, const void* k, int64_t k_sg, int64_t k_sh,
                                        int64_t k_sr, const void* v, int64_t v_sg, int64_t v_sh, int64_t v_sr, const float* mask, void* out,
-                                       int64_t o_sg, int64_t o_sh, int64_t o_sr, float* lse, int G, int H, int Lq, int Lk, float scale,
+                                       int64_t o_sg, int64_t o_sh, int64_t o_sr, float* out32, float* lse, int G, int H, int Lq, int Lk, float scale,
                                        float p_drop, uint64_t seed, int dtype, void* stream) {
     using namespace cir;
     CIR_CHECK_PTR(q); CIR_CHECK_PTR(k); CIR_CHECK_PTR(v); CIR_CHECK_PTR(out); CIR_CHECK_PTR(lse);
+    if (out32 != nullptr && !cir_aligned16(out32)) return CIR_EALIGN;
     TAttnArgs a = {};
     a.q = q; a.q_sg = q_sg; a.q_sh = q_sh; a.q_sr = q_sr;
     a.k = k; a.k_sg = k_sg; a.k_sh = k_sh; a.k_sr = k_sr;
     a.v = v; a.v_sg = v_sg; a.v_sh = v_sh; a.v_sr = v_sr;
-    a.o = out; a.d_o = nullptr; a.o_sg = o_sg; a.o_sh = o_sh; a.o_sr = o_sr;
+    a.o = out; a.d_o = nullptr; a.o_sg = o_sg; a.o_sh = o_sh; a.o_sr = o_sr; a.o32 = out32;
     a.mask = mask; a.lse = lse;
     a.G = G; a.H = H; a.Lq = Lq; a.Lk = Lk; a.nqt = (Lq + 31) / 32; a.nkt = (Lk + 31) / 32;
     a.scale = scale; a.p_drop = p_drop; a.seed = seed;
@@ -428,7 +443,8 @@ extern "C" int cir_attention_train_fwd(const void* q, int64_t q_sg, int64_t q_sh
 
 extern "C" int cir_attention_train_bwd(const void* q, int64_t q_sg, int64_t q_sh, int64_t q_sr, const void* k, int64_t k_sg, int64_t k_sh,
                                        int64_t k_sr, const void* v, int64_t v_sg, int64_t v_sh, int64_t v_sr, const float* mask, const void* out,
-                                       const void* d_out, int64_t o_sg, int64_t o_sh, int64_t o_sr, const float* lse, float* dsum_scratch,
+                                       const void* d_out, int64_t o_sg, int64_t o_sh, int64_t o_sr, const float* out32, const float* d_out32, const float* lse,
+                                       float* dsum_scratch,
                                        float* dq, int64_t dq_sg, int64_t dq_sh, int64_t dq_sr, float* dk, int64_t dk_sg, int64_t dk_sh,
                                        int64_t dk_sr, float* dv, int64_t dv_sg, int64_t dv_sh, int64_t dv_sr, int G, int H, int Lq, int Lk,
                                        float scale, float p_drop, uint64_t seed, int dtype, void* stream) {
@@ -440,6 +456,9 @@ extern "C" int cir_attention_train_bwd(const void* q, int64_t q_sg, int64_t q_sh
     a.k = k; a.k_sg = k_sg; a.k_sh = k_sh; a.k_sr = k_sr;
     a.v = v; a.v_sg = v_sg; a.v_sh = v_sh; a.v_sr = v_sr;
     a.o = out; a.d_o = d_out; a.o_sg = o_sg; a.o_sh = o_sh; a.o_sr = o_sr;
+    a.o32 = const_cast<float*>(out32); a.do32 = d_out32;
+    if ((out32 == nullptr) != (d_out32 == nullptr)) return CIR_EINVAL;
+    if (out32 != nullptr && (!cir_aligned16(out32) || !cir_aligned16(d_out32))) return CIR_EALIGN;
     a.mask = mask; a.lse = const_cast<float*>(lse); a.dsum = dsum_scratch;
     a.dq = dq; a.dq_sg = dq_sg; a.dq_sh = dq_sh; a.dq_sr = dq_sr;
     a.dk = dk; a.dk_sg = dk_sg; a.dk_sh = dk_sh; a.dk_sr = dk_sr;
