@@ -213,15 +213,20 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const TAttnArgs a) {
     }
 }
 
-// probability / adjoint of one score element (shared by both backward kernels)
+// probability / adjoint of one score element (shared by both backward kernels).  The probability that multiplies (dP - D) is the one
+// the FORWARD used: a kept element's is its 16-bit dropout(P) value scaled back - D = rowsum(dO * O) = sum_j Pd16_ij dPd_ij was formed
+// with exactly those, so sum_j dS_ij = D (1 - sum_j P_ij) vanishes as the softmax Jacobian demands; with the unrounded fp32 p the row
+// sums of dS are off by the rounding of P and the (column-summed) query-bias gradients lose a factor 2-3 of accuracy.
 struct Adj { float pd, ds; };
+template <typename T>
 __device__ __forceinline__ Adj adjoint(float s, float dp, float sl, float maskv, float lse, float dsum, bool valid, float scale, float p_drop,
                                         float keep, uint64_t seed, uint64_t idx) {
     const float p = valid ? __builtin_amdgcn_exp2f(fmaf(s, sl, maskv) - lse) : 0.f;
     const bool kept = p_drop <= 0.f || uniform01_t(seed, idx) >= p_drop;
     Adj r;
-    r.pd = kept ? p * keep : 0.f;
-    r.ds = p * ((kept ? dp * keep : 0.f) - dsum) * scale;
+    r.pd = kept ? static_cast<float>(static_cast<T>(p * keep)) : 0.f;
+    const float pf = kept ? r.pd * (1.0f / keep) : p;
+    r.ds = pf * ((kept ? dp * keep : 0.f) - dsum) * scale;
     return r;
 }
 
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(256) void tattn_bwd_dq_kernel(const TAttnArgs a) {
             const int key = key0 + acc_row(i, hh);
             float maskv = 0.f;
             if constexpr (MASKED) maskv = fmaxf(mp[min(key, a.Lk - 1)], -2.0e38f) * kLog2eT;
-            const Adj ad = adjoint(s[i], dp[i], sl, maskv, lse, dsum, qvalid && key < a.Lk, a.scale, a.p_drop, keep, a.seed, rowbase + (uint64_t)key);
+            const Adj ad = adjoint<T>(s[i], dp[i], sl, maskv, lse, dsum, qvalid && key < a.Lk, a.scale, a.p_drop, keep, a.seed, rowbase + (uint64_t)key);
             dsf[i >> 3][i & 7] = static_cast<T>(ad.ds);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(256) void tattn_bwd_dkv_kernel(const TAttnArgs a) {
         for (int i = 0; i < 16; ++i) {
             const int qi = q0 + acc_row(i, hh);
             const uint64_t idx = (uint64_t)(gh * a.Lq + min(qi, a.Lq - 1)) * (uint64_t)a.Lk + (uint64_t)krow;
-            const Adj ad = adjoint(s[i], dp[i], sl, maskv, lse_i[i], ds_i[i], kvalid && qi < a.Lq, a.scale, a.p_drop, keep, a.seed, idx);
+            const Adj ad = adjoint<T>(s[i], dp[i], sl, maskv, lse_i[i], ds_i[i], kvalid && qi < a.Lq, a.scale, a.p_drop, keep, a.seed, idx);
             pdf[i >> 3][i & 7] = static_cast<T>(ad.pd);
             dsf[i >> 3][i & 7] = static_cast<T>(ad.ds);
         }
