@@ -33,8 +33,7 @@ struct TAttnArgs {
     const void* k; int64_t k_sg, k_sh, k_sr;
     const void* v; int64_t v_sg, v_sh, v_sr;
     const void* o; const void* d_o; int64_t o_sg, o_sh, o_sr;     // O (forward: written) and dO share one layout
-    float* o32; const float* do32;                                // optional fp32 twins of O / dO in the same layout: D = rowsum(dO * O) is then
-                                                                  // formed from them (rounding O to 16 bits first costs the bias gradients 2-3x)
+    float* o32;                                                   // optional fp32 twin of O in the same layout: D = rowsum(dO * O) is then formed from it
     const float* mask;                                            // additive key mask (G, Lk) contiguous, or null
     float* lse;                                                   // (G, H, Lq) log2-domain log-sum-exp (forward: written)
     float* dsum;                                                  // (G, H, Lq) D = rowsum(dO * O) (dQ kernel: written; dK/dV kernel: read)
@@ -256,14 +255,17 @@ __global__ __launch_bounds__(256) void tattn_bwd_dq_kernel(const TAttnArgs a) {
     // D = rowsum(dO * O): this lane holds 32 of the row's 64 dh of both
     float dsum = 0.f;
     {
-        if (a.o32 != nullptr && a.do32 != nullptr) {
+        if (a.o32 != nullptr) {
+            // O from its fp32 twin (the exact fp32 accumulation of the ROUNDED Pd and V the forward multiplied), dO as the 16-bit
+            // operand the dPd product below consumes: D then equals sum_j Pd16_ij dPd_ij term for term - the rounding of O (no twin)
+            // or an unrounded fp32 dO (a twin of dO) each break that identity and with it the zero row sums of dS
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const float4 x = *reinterpret_cast<const float4*>(a.o32 + orow + 16 * s + 4 * half);
-                    const float4 y = *reinterpret_cast<const float4*>(a.do32 + orow + 16 * s + 4 * half);
-                    dsum = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, fmaf(x.w, y.w, dsum))));
+                    dsum = fmaf(x.x, static_cast<float>(dof[s][4 * half + 0]), fmaf(x.y, static_cast<float>(dof[s][4 * half + 1]),
+                           fmaf(x.z, static_cast<float>(dof[s][4 * half + 2]), fmaf(x.w, static_cast<float>(dof[s][4 * half + 3]), dsum))));
                 }
         } else {
             X8 of[4];
@@ -448,7 +450,7 @@ extern "C" int cir_attention_train_fwd(const void* q, int64_t q_sg, int64_t q_sh
 
 extern "C" int cir_attention_train_bwd(const void* q, int64_t q_sg, int64_t q_sh, int64_t q_sr, const void* k, int64_t k_sg, int64_t k_sh,
                                        int64_t k_sr, const void* v, int64_t v_sg, int64_t v_sh, int64_t v_sr, const float* mask, const void* out,
-                                       const void* d_out, int64_t o_sg, int64_t o_sh, int64_t o_sr, const float* out32, const float* d_out32, const float* lse,
+                                       const void* d_out, int64_t o_sg, int64_t o_sh, int64_t o_sr, const float* out32, const float* lse,
                                        float* dsum_scratch,
                                        float* dq, int64_t dq_sg, int64_t dq_sh, int64_t dq_sr, float* dk, int64_t dk_sg, int64_t dk_sh,
                                        int64_t dk_sr, float* dv, int64_t dv_sg, int64_t dv_sh, int64_t dv_sr, int G, int H, int Lq, int Lk,
@@ -461,9 +463,8 @@ extern "C" int cir_attention_train_bwd(const void* q, int64_t q_sg, int64_t q_sh
     a.k = k; a.k_sg = k_sg; a.k_sh = k_sh; a.k_sr = k_sr;
     a.v = v; a.v_sg = v_sg; a.v_sh = v_sh; a.v_sr = v_sr;
     a.o = out; a.d_o = d_out; a.o_sg = o_sg; a.o_sh = o_sh; a.o_sr = o_sr;
-    a.o32 = const_cast<float*>(out32); a.do32 = d_out32;
-    if ((out32 == nullptr) != (d_out32 == nullptr)) return CIR_EINVAL;
-    if (out32 != nullptr && (!cir_aligned16(out32) || !cir_aligned16(d_out32))) return CIR_EALIGN;
+    a.o32 = const_cast<float*>(out32);
+    if (out32 != nullptr && !cir_aligned16(out32)) return CIR_EALIGN;
     a.mask = mask; a.lse = const_cast<float*>(lse); a.dsum = dsum_scratch;
     a.dq = dq; a.dq_sg = dq_sg; a.dq_sh = dq_sh; a.dq_sr = dq_sr;
     a.dk = dk; a.dk_sg = dk_sg; a.dk_sh = dk_sh; a.dk_sr = dk_sr;

@@ -270,7 +270,7 @@ class NlvrTrainer:
             # round 4: ONE kernel - scores, mask, softmax, dropout, P.V tile by tile in registers - and a log-sum-exp per row for the
             # recomputing backward; no score / probability tensor is materialised (cir_attention_train_fwd)
             ctx = torch.empty((nb1 * mq, d), dtype=q4.dtype, device=q4.device)
-            ctx32 = torch.empty((nb1 * mq, d), dtype=torch.float32, device=q4.device)    # fp32 twin: D = rowsum(dO * O) of the backward
+            ctx32 = torch.empty((nb1 * mq, d), dtype=torch.float32, device=q4.device)    # fp32 twin of the context: the backward's D = rowsum(dO * O) (cirrank.h)
             lse = T.attention_train_fwd(q4, k4, v4, mask, self._heads(ctx, nb1, mq), self._scale, self.p_attn, site, out32=self._heads(ctx32, nb1, mq))
             return ctx, (lse, mask, site, ctx, ctx32)
         ld = (mk + 7) // 8 * 8                                                       # padded score rows: 16-byte loads in cir_bmm
@@ -287,9 +287,8 @@ class NlvrTrainer:
         nb1, h_n, mq, _ = q4.shape
         if len(saved) == 5:                                                          # fused pair (see _attn_fwd)
             lse, mask, site, ctx, ctx32 = saved
-            dctx = dctx.contiguous()
             T.attention_train_bwd(q4, k4, v4, mask, self._heads(ctx, nb1, mq), self._heads(_cast(dctx, q4.dtype), nb1, mq), lse, dq4, dk4, dv4,
-                                  self._scale, self.p_attn, site, out32=self._heads(ctx32, nb1, mq), dout32=self._heads(dctx, nb1, mq))
+                                  self._scale, self.p_attn, site, out32=self._heads(ctx32, nb1, mq))
             return
         p, pd, site = saved
         mk, ld = k4.shape[2], p.shape[1]

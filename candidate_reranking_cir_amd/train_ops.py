@@ -111,7 +111,7 @@ def attention_train_fwd(q4: torch.Tensor, k4: torch.Tensor, v4: torch.Tensor, ma
     return lse
 
 
-def attention_train_bwd(q4, k4, v4, mask, out4, dout4, lse, dq4, dk4, dv4, scale: float, p_drop: float, seed: int, out32=None, dout32=None):
+def attention_train_bwd(q4, k4, v4, mask, out4, dout4, lse, dq4, dk4, dv4, scale: float, p_drop: float, seed: int, out32=None):
     """Recomputing backward of `attention_train_fwd`: dout4 16-bit in out4's layout; dq4 / dk4 / dv4 fp32 head views (written)."""
     _need_cuda(q4, k4, v4, mask, out4, dout4, lse, dq4, dk4, dv4)
     g, h, lq, _ = q4.shape
@@ -121,10 +121,9 @@ def attention_train_bwd(q4, k4, v4, mask, out4, dout4, lse, dq4, dk4, dv4, scale
     assert dq4.shape == q4.shape and dk4.shape == k4.shape and dv4.shape == v4.shape and dq4.dtype == dk4.dtype == dv4.dtype == torch.float32
     dsum = torch.empty((g, h, lq), dtype=torch.float32, device=q4.device)
     qo = _hv(out4)
-    for t32 in (out32, dout32):
-        assert t32 is None or (t32.dtype == torch.float32 and t32.shape == out4.shape and t32.stride() == out4.stride())
+    assert out32 is None or (out32.dtype == torch.float32 and out32.shape == out4.shape and out32.stride() == out4.stride())
     _lib.check(_lib.load().cir_attention_train_bwd(*_hv(q4), *_hv(k4), *_hv(v4), _ptr(mask), qo[0], dout4.data_ptr(), qo[1], qo[2], qo[3],
-                                                   _ptr(out32), _ptr(dout32), lse.data_ptr(),
+                                                   _ptr(out32), lse.data_ptr(),
                                                    dsum.data_ptr(), *_hv(dq4), *_hv(dk4), *_hv(dv4), g, h, lq, lk, float(scale), float(p_drop),
                                                    int(seed) & (2 ** 63 - 1), _DT[q4.dtype], _stream()), "cir_attention_train_bwd")
 

@@ -225,8 +225,8 @@ int cir_softmax_dropout_bwd(const void* P, int64_t ld_p, const float* dPd, int64
  * out, d_out and lse; the probabilities are recomputed tile by tile and the dropout mask regenerated from its counter (element index
  * ((g * H + h) * Lq + query) * Lk + key), so no score / probability tensor exists in memory.  Tensors are head views: element
  * (g, h, row, d) at base + g * x_sg + h * x_sh + row * x_sr + d; out and d_out share one layout; mask fp32 (G, Lk) additive or NULL;
- * dsum_scratch fp32 (G * H * Lq) receives rowsum(d_out * out) - formed from the optional fp32 twins out32 (written by the forward) /
- * d_out32 (same layout as out, fp32) when both are given: rounding out to 16 bits first costs the bias gradients 2-3x.  Replaces, for BertSelfAttention.forward in train() mode
+ * dsum_scratch fp32 (G * H * Lq) receives rowsum(d_out * out) - with out taken from its optional fp32 twin out32 (written by the
+ * forward, same layout): it then equals sum_j Pd_ij dPd_ij term for term and the row sums of dS vanish.  Replaces, for BertSelfAttention.forward in train() mode
  * (nlvr_encoder.py:140-222, dropout :207) and its adjoint, the cir_bmm / cir_softmax_dropout[_bwd] chain. */
 int cir_attention_train_fwd(const void* q, int64_t q_sg, int64_t q_sh, int64_t q_sr, const void* k, int64_t k_sg, int64_t k_sh, int64_t k_sr,
                             const void* v, int64_t v_sg, int64_t v_sh, int64_t v_sr, const float* mask, void* out, int64_t o_sg, int64_t o_sh,
@@ -234,7 +234,7 @@ int cir_attention_train_fwd(const void* q, int64_t q_sg, int64_t q_sh, int64_t q
                             int dtype, void* stream);
 int cir_attention_train_bwd(const void* q, int64_t q_sg, int64_t q_sh, int64_t q_sr, const void* k, int64_t k_sg, int64_t k_sh, int64_t k_sr,
                             const void* v, int64_t v_sg, int64_t v_sh, int64_t v_sr, const float* mask, const void* out, const void* d_out,
-                            int64_t o_sg, int64_t o_sh, int64_t o_sr, const float* out32, const float* d_out32, const float* lse,
+                            int64_t o_sg, int64_t o_sh, int64_t o_sr, const float* out32, const float* lse,
                             float* dsum_scratch, float* dq, int64_t dq_sg,
                             int64_t dq_sh, int64_t dq_sr, float* dk, int64_t dk_sg, int64_t dk_sh, int64_t dk_sr, float* dv, int64_t dv_sg,
                             int64_t dv_sh, int64_t dv_sr, int G, int H, int Lq, int Lk, float scale, float p_drop, uint64_t seed, int dtype,

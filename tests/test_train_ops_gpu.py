@@ -233,16 +233,15 @@ def test_fused_training_attention_matches_torch_autograd(T, dtype, g, h, lq, lk,
     print(f"\\n[fused train attention {dtype} {g}x{h} {lq}x{lk} mask={masked} p={p}] ctx {e_o:.2e}  lse {e_l:.2e}  dq {e_q:.2e}  dk {e_k:.2e}  dv {e_v:.2e}")
     assert e_o < tol and e_l < 2e-3 and max(e_q, e_k, e_v) < (2e-2 if dtype == torch.bfloat16 else 3e-3)
     assert torch.isfinite(dq[:, 0]).all() and torch.isfinite(dkv).all() and torch.isnan(dq[:, 1:]).all()      # only the q slice of the fused buffer is written
-    # with the fp32 twins of O / dO (what the trainer passes): D = rowsum(dO * O) without the 16-bit rounding of O
+    # with the fp32 twin of O (what the trainer passes): D = rowsum(dO * O) equals sum_j Pd_ij dPd_ij term for term
     ctx32 = torch.empty((g * lq, h * 64), dtype=torch.float32, device=dev)
     o32 = ctx32.view(g, lq, h, 64).permute(0, 2, 1, 3)
     lse2 = T.attention_train_fwd(q4, k4, v4, mask, out4, scale, p, seed, out32=o32)
     assert torch.equal(lse2, lse) and (o32 - o_ref).abs().max().item() < tol
     assert (o32 - o_ref).abs().max().item() <= e_o + 1e-6                                              # fp32 twin: no output rounding
     dq2, dkv2 = torch.zeros_like(dq), torch.zeros_like(dkv)
-    dout32 = dout.float()
     T.attention_train_bwd(q4, k4, v4, mask, out4, dout.view(g, lq, h, 64).permute(0, 2, 1, 3), lse, heads(dq2, lq, 0, 3), heads(dkv2, lk, 0, 2),
-                          heads(dkv2, lk, 1, 2), scale, p, seed, out32=o32, dout32=dout32.view(g, lq, h, 64).permute(0, 2, 1, 3))
+                          heads(dkv2, lk, 1, 2), scale, p, seed, out32=o32)
     e_q2, e_k2 = rel(heads(dq2, lq, 0, 3), qf.grad), rel(heads(dkv2, lk, 0, 2), kf.grad)
-    print(f"   with fp32 twins: dq {e_q2:.2e}  dk {e_k2:.2e}")
+    print(f"   with the fp32 twin of O: dq {e_q2:.2e}  dk {e_k2:.2e}")
     assert max(e_q2, e_k2) < (2e-2 if dtype == torch.bfloat16 else 3e-3) and e_q2 < 1.1 * e_q + 1e-5
