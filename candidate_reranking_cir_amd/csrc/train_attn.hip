@@ -37,9 +37,10 @@ struct TAttnArgs {
     const float* mask;                                            // additive key mask (G, Lk) contiguous, or null
     float* lse;                                                   // (G, H, Lq) log2-domain log-sum-exp (forward: written)
     float* dsum;                                                  // (G, H, Lq) D = rowsum(dO * O) (dQ kernel: written; dK/dV kernel: read)
-    float* dq; int64_t dq_sg, dq_sh, dq_sr;
-    float* dk; int64_t dk_sg, dk_sh, dk_sr;
-    float* dv; int64_t dv_sg, dv_sh, dv_sr;
+    void* dq; int64_t dq_sg, dq_sh, dq_sr;                         // gradients: fp32, or (grad16) in the operand type - the next
+    void* dk; int64_t dk_sg, dk_sh, dk_sr;                         // dense layer's dgrad / wgrad operand as it is
+    void* dv; int64_t dv_sg, dv_sh, dv_sr;
+    int grad16;
     int G, H, Lq, Lk, nqt, nkt;
     float scale, p_drop;
     uint64_t seed;
@@ -112,6 +113,22 @@ __device__ __forceinline__ void store_f32(const f32x16 (&acc)[2], float* rowp /*
         for (int qd = 0; qd < 4; ++qd)
             *reinterpret_cast<float4*>(rowp + dt * 32 + 8 * qd) =
                 make_float4(acc[dt][qd * 4 + 0] * mul, acc[dt][qd * 4 + 1] * mul, acc[dt][qd * 4 + 2] * mul, acc[dt][qd * 4 + 3] * mul);
+}
+
+// gradient store of a transposed accumulator (same element map) at element offset `off` of `base`: fp32 or the operand type
+template <typename T>
+__device__ __forceinline__ void store_grad(const f32x16 (&acc)[2], void* base, int64_t off, int grad16) {
+    if (!grad16) { store_f32(acc, reinterpret_cast<float*>(base) + off, 1.0f); return; }
+    typedef __attribute__((ext_vector_type(4))) T t4;
+    T* rowp = reinterpret_cast<T*>(base) + off;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            t4 o = {static_cast<T>(acc[dt][qd * 4 + 0]), static_cast<T>(acc[dt][qd * 4 + 1]), static_cast<T>(acc[dt][qd * 4 + 2]),
+                    static_cast<T>(acc[dt][qd * 4 + 3])};
+            *reinterpret_cast<t4*>(rowp + dt * 32 + 8 * qd) = o;
+        }
 }
 
 // ------------------------------------------------------------------------------------------------------------------ forward
@@ -321,7 +338,7 @@ __global__ __launch_bounds__(256) void tattn_bwd_dq_kernel(const TAttnArgs a) {
         tr_accumulate<T>(dq, kl, voff, dsf);                    // dQ^T[dh][q] += K^T[dh][key] dS^T[key][q]
         __builtin_amdgcn_wave_barrier();
     }
-    if (qvalid) store_f32(dq, a.dq + g * a.dq_sg + h * a.dq_sh + (int64_t)(q0 + r) * a.dq_sr + 4 * hh, 1.0f);
+    if (qvalid) store_grad<T>(dq, a.dq, g * a.dq_sg + h * a.dq_sh + (int64_t)(q0 + r) * a.dq_sr + 4 * hh, a.grad16);
 }
 
 // ------------------------------------------------------------------------------------------------------------------ dK, dV
@@ -404,8 +421,8 @@ __global__ __launch_bounds__(256) void tattn_bwd_dkv_kernel(const TAttnArgs a) {
         __builtin_amdgcn_wave_barrier();
     }
     if (kvalid) {
-        store_f32(dk, a.dk + g * a.dk_sg + h * a.dk_sh + (int64_t)key * a.dk_sr + 4 * hh, 1.0f);
-        store_f32(dv, a.dv + g * a.dv_sg + h * a.dv_sh + (int64_t)key * a.dv_sr + 4 * hh, 1.0f);
+        store_grad<T>(dk, a.dk, g * a.dk_sg + h * a.dk_sh + (int64_t)key * a.dk_sr + 4 * hh, a.grad16);
+        store_grad<T>(dv, a.dv, g * a.dv_sg + h * a.dv_sh + (int64_t)key * a.dv_sr + 4 * hh, a.grad16);
     }
 }
 
@@ -452,9 +469,9 @@ extern "C" int cir_attention_train_bwd(const void* q, int64_t q_sg, int64_t q_sh
                                        int64_t k_sr, const void* v, int64_t v_sg, int64_t v_sh, int64_t v_sr, const float* mask, const void* out,
                                        const void* d_out, int64_t o_sg, int64_t o_sh, int64_t o_sr, const float* out32, const float* lse,
                                        float* dsum_scratch,
-                                       float* dq, int64_t dq_sg, int64_t dq_sh, int64_t dq_sr, float* dk, int64_t dk_sg, int64_t dk_sh,
-                                       int64_t dk_sr, float* dv, int64_t dv_sg, int64_t dv_sh, int64_t dv_sr, int G, int H, int Lq, int Lk,
-                                       float scale, float p_drop, uint64_t seed, int dtype, void* stream) {
+                                       void* dq, int64_t dq_sg, int64_t dq_sh, int64_t dq_sr, void* dk, int64_t dk_sg, int64_t dk_sh,
+                                       int64_t dk_sr, void* dv, int64_t dv_sg, int64_t dv_sh, int64_t dv_sr, int grad_dtype, int G, int H, int Lq,
+                                       int Lk, float scale, float p_drop, uint64_t seed, int dtype, void* stream) {
     using namespace cir;
     CIR_CHECK_PTR(q); CIR_CHECK_PTR(k); CIR_CHECK_PTR(v); CIR_CHECK_PTR(out); CIR_CHECK_PTR(d_out); CIR_CHECK_PTR(lse);
     CIR_CHECK_PTR(dsum_scratch); CIR_CHECK_PTR(dq); CIR_CHECK_PTR(dk); CIR_CHECK_PTR(dv);
@@ -469,6 +486,8 @@ extern "C" int cir_attention_train_bwd(const void* q, int64_t q_sg, int64_t q_sh
     a.dq = dq; a.dq_sg = dq_sg; a.dq_sh = dq_sh; a.dq_sr = dq_sr;
     a.dk = dk; a.dk_sg = dk_sg; a.dk_sh = dk_sh; a.dk_sr = dk_sr;
     a.dv = dv; a.dv_sg = dv_sg; a.dv_sh = dv_sh; a.dv_sr = dv_sr;
+    if (grad_dtype != CIR_F32 && grad_dtype != dtype) return CIR_EDTYPE;
+    a.grad16 = grad_dtype != CIR_F32;
     a.G = G; a.H = H; a.Lq = Lq; a.Lk = Lk; a.nqt = (Lq + 31) / 32; a.nkt = (Lk + 31) / 32;
     a.scale = scale; a.p_drop = p_drop; a.seed = seed;
     if (const int e = tattn_check(a, dtype)) return e;

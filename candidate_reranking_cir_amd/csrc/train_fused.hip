@@ -1,0 +1,313 @@
+// Fused row kernels of the TRAINING pass (round 4).  Round 3 ran every step of BertSelfOutput / BertOutput
+// (nlvr_encoder.py:248-264, 399-409: dense -> dropout -> + residual -> LayerNorm) and of its adjoint as its own launch over fp32
+// tensors - 41 elementwise and 25 column-sum launches per layer, 17 ms of a 65 ms step.  Here each block of that chain is ONE pass:
+//   forward   cir_residual_layernorm_train : pre = dropout(alpha * (t0 + t1)) + residual ; y = LayerNorm(pre)   -> pre, y (fp32), y (16-bit)
+//   backward  cir_layernorm_bwd_fused      : d pre from dy ; dgamma, dbeta ; and the gradient that flows back through the dropout to
+//                                            the dense layer, alpha * dropout'(d pre + t_add), as the 16-bit operand of that layer's
+//                                            dgrad / wgrad products together with its column sums (the dense layer's bias gradient)
+//             cir_rows16_colsum            : column sums of a 16-bit gradient (bias gradients behind the attention adjoints), or
+//                                            dz = df * gelu'(z) on 16-bit tensors with the column sums of dz in the same pass
+// Gradients between the dense layers travel as 16-bit tensors (what autocast's backward gives the reference, stage2_train.py:208-216);
+// the residual-stream gradient stays fp32.
+#include "common.hpp"
+
+namespace cir {
+
+__device__ __forceinline__ float uniform01_f(uint64_t seed, uint64_t idx) {   // = train.hip's uniform01 (splitmix64 of (seed, index))
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+constexpr int kRowVec = 4;       // float4 groups per lane: cols <= 1024, cols % 4 == 0
+
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const float (&v)[4]) {
+    typedef __attribute__((ext_vector_type(4))) T t4;
+    t4 o = {static_cast<T>(v[0]), static_cast<T>(v[1]), static_cast<T>(v[2]), static_cast<T>(v[3])};
+    *reinterpret_cast<t4*>(p) = o;
+}
+
+// ---- forward: dropout + residual + LayerNorm, one wave per row ------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void res_ln_train_kernel(const float* t0, const float* t1, const float* res, const float* gamma, const float* beta,
+                                                           float* pre, float* y32, T* y16, int64_t rows, int cols, float eps, float alpha,
+                                                           float p_drop, uint64_t seed) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const float keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const int64_t base = row * cols;
+    float v[kRowVec][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kRowVec; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < cols) {
+            float4 a = *reinterpret_cast<const float4*>(t0 + base + c);
+            if (t1 != nullptr) {
+                const float4 b = *reinterpret_cast<const float4*>(t1 + base + c);
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            const float4 r = *reinterpret_cast<const float4*>(res + base + c);
+            const float tv[4] = {a.x, a.y, a.z, a.w}, rv[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool kept = p_drop <= 0.f || uniform01_f(seed, (uint64_t)(base + c + e)) >= p_drop;
+                v[i][e] = (kept ? tv[e] * alpha * keep : 0.f) + rv[e];
+                s += v[i][e];
+            }
+            *reinterpret_cast<float4*>(pre + base + c) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kRowVec; ++i)
+        if ((lane + 64 * i) * 4 < cols) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    const float rstd = rsqrtf(wave_sum(q) / cols + eps);
+#pragma unroll
+    for (int i = 0; i < kRowVec; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < cols) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+            const float gv[4] = {g.x, g.y, g.z, g.w}, bv[4] = {b.x, b.y, b.z, b.w};
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gv[e] + bv[e];
+            if (y32 != nullptr) *reinterpret_cast<float4*>(y32 + base + c) = make_float4(y[0], y[1], y[2], y[3]);
+            if (y16 != nullptr) store4<T>(y16 + base + c, y);
+        }
+    }
+}
+
+// ---- backward: LayerNorm adjoint + the dropout adjoint of the dense branch + that branch's bias gradient -------------------------
+// One wave per row, 32 rows per block; the per-column sums (dgamma, dbeta, bias gradient) of a block's rows stay in registers and are
+// added once per block.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta,
+                                                           const float* t_add, T* dt16, float* db1, float* db2, int64_t rows, int cols, float eps,
+                                                           float alpha, float p_drop, uint64_t seed) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    float pg[kRowVec][4], pb[kRowVec][4], pd[kRowVec][4];
+#pragma unroll
+    for (int i = 0; i < kRowVec; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pg[i][e] = 0.f; pb[i][e] = 0.f; pd[i][e] = 0.f; }
+    float gv[kRowVec][4];
+#pragma unroll
+    for (int i = 0; i < kRowVec; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        const float4 g = c < cols ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        gv[i][0] = g.x; gv[i][1] = g.y; gv[i][2] = g.z; gv[i][3] = g.w;
+    }
+    for (int it = 0; it < 8; ++it) {
+        const int64_t row = (int64_t)blockIdx.x * 32 + it * 4 + wave;
+        if (row >= rows) break;
+        const int64_t base = row * cols;
+        float xv[kRowVec][4], dv[kRowVec][4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < kRowVec; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            const bool in = c < cols;
+            const float4 a = in ? *reinterpret_cast<const float4*>(x + base + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 d = in ? *reinterpret_cast<const float4*>(dy + base + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[i][0] = a.x; xv[i][1] = a.y; xv[i][2] = a.z; xv[i][3] = a.w;
+            dv[i][0] = d.x; dv[i][1] = d.y; dv[i][2] = d.z; dv[i][3] = d.w;
+            s += (a.x + a.y) + (a.z + a.w);
+        }
+        const float mean = wave_sum(s) / cols;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < kRowVec; ++i)
+            if ((lane + 64 * i) * 4 < cols) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = xv[i][e] - mean; q += d * d; }
+            }
+        const float rstd = rsqrtf(wave_sum(q) / cols + eps);
+        float a = 0.f, b = 0.f;           // mean(dy*gamma), mean(dy*gamma*xhat)
+#pragma unroll
+        for (int i = 0; i < kRowVec; ++i)
+            if ((lane + 64 * i) * 4 < cols) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xv[i][e] = (xv[i][e] - mean) * rstd;                           // xhat from here on
+                    const float gq = dv[i][e] * gv[i][e];
+                    a += gq; b += gq * xv[i][e];
+                }
+            }
+        a = wave_sum(a) / cols; b = wave_sum(b) / cols;
+#pragma unroll
+        for (int i = 0; i < kRowVec; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < cols) {
+                float r[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    r[e] = rstd * (dv[i][e] * gv[i][e] - a - xv[i][e] * b);
+                    pg[i][e] += dv[i][e] * xv[i][e];
+                    pb[i][e] += dv[i][e];
+                }
+                if (dx != nullptr) *reinterpret_cast<float4*>(dx + base + c) = make_float4(r[0], r[1], r[2], r[3]);
+                if (dt16 != nullptr) {
+                    if (t_add != nullptr) {
+                        const float4 t = *reinterpret_cast<const float4*>(t_add + base + c);
+                        r[0] += t.x; r[1] += t.y; r[2] += t.z; r[3] += t.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool kept = p_drop <= 0.f || uniform01_f(seed, (uint64_t)(base + c + e)) >= p_drop;
+                        r[e] = kept ? r[e] * alpha * keep : 0.f;
+                        pd[i][e] += r[e];
+                    }
+                    store4<T>(dt16 + base + c, r);
+                }
+            }
+        }
+    }
+    __shared__ float red[4][64 * kRowVec * 4];
+    const bool bias = dt16 != nullptr && db1 != nullptr;
+    for (int pass = 0; pass < (bias ? 3 : 2); ++pass) {
+        if (pass) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kRowVec; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wave][(lane + 64 * i) * 4 + e] = pass == 0 ? pg[i][e] : pass == 1 ? pb[i][e] : pd[i][e];
+        __syncthreads();
+        for (int c = threadIdx.x; c < cols; c += 256) {
+            const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+            if (pass == 0) atomicAdd(dgamma + c, v);
+            else if (pass == 1) atomicAdd(dbeta + c, v);
+            else { atomicAdd(db1 + c, v); if (db2 != nullptr) atomicAdd(db2 + c, v); }
+        }
+    }
+}
+
+// ---- 16-bit rows: column sums, optionally behind dz = a * gelu'(z) -----------------------------------------------------------------
+// block = 32 column groups (8 columns each: one 16-byte load) x 8 row lanes, 64 rows per block; column sums over the block's rows in
+// registers, then across the row lanes through LDS, one atomic per column and block.
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+template <typename T, int MODE>      // MODE 0: sums of a;  1: out = a * gelu'(z), sums of out
+__global__ __launch_bounds__(256) void rows16_colsum_kernel(const T* a, int64_t lda, const T* z, int64_t ldz, T* out, int64_t ldo, float* sums,
+                                                            int64_t rows, int cols) {
+    typedef typename Elem<T>::x8 X8;
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = (blockIdx.x * 32 + cg) * 8;
+    const int64_t r0 = (int64_t)blockIdx.y * 64;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (c < cols) {
+#pragma unroll 2
+        for (int it = 0; it < 8; ++it) {
+            const int64_t r = r0 + it * 8 + rl;
+            if (r >= rows) break;
+            const X8 av = *reinterpret_cast<const X8*>(a + r * lda + c);
+            if (MODE == 1) {
+                const X8 zv = *reinterpret_cast<const X8*>(z + r * ldz + c);
+                X8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = static_cast<float>(av[e]) * gelu_grad_f(static_cast<float>(zv[e]));
+                    o[e] = static_cast<T>(v);
+                    acc[e] += v;
+                }
+                *reinterpret_cast<X8*>(out + r * ldo + c) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += static_cast<float>(av[e]);
+            }
+        }
+    }
+    if (sums == nullptr) return;
+    __shared__ float red[8][256 + 8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = acc[e];
+    __syncthreads();
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc < cols) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += red[j][threadIdx.x];
+        atomicAdd(sums + cc, v);
+    }
+}
+
+}  // namespace cir
+
+using namespace cir;
+
+extern "C" int cir_residual_layernorm_train(const float* t0, const float* t1, const float* residual, const float* gamma, const float* beta, float* pre,
+                                            float* y32, void* y16, int64_t rows, int cols, float eps, float alpha, float p_drop, uint64_t seed,
+                                            int dtype16, void* stream) {
+    CIR_CHECK_PTR(t0); CIR_CHECK_PTR(residual); CIR_CHECK_PTR(gamma); CIR_CHECK_PTR(beta); CIR_CHECK_PTR(pre);
+    if (rows <= 0 || cols <= 0 || p_drop < 0.f || p_drop >= 1.f) return CIR_EINVAL;
+    if (cols % 4 != 0 || cols > 256 * kRowVec) return CIR_ESHAPE;
+    if (dtype16 != CIR_BF16 && dtype16 != CIR_F16) return CIR_EDTYPE;
+    if (!cir_aligned16(t0) || !cir_aligned16(t1) || !cir_aligned16(residual) || !cir_aligned16(pre) || !cir_aligned16(y32) || !cir_aligned16(gamma) ||
+        !cir_aligned16(beta) || (reinterpret_cast<uintptr_t>(y16) & 7u)) return CIR_EALIGN;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype16 == CIR_BF16)
+        hipLaunchKernelGGL((res_ln_train_kernel<__bf16>), grid, block, 0, s, t0, t1, residual, gamma, beta, pre, y32, reinterpret_cast<__bf16*>(y16), rows,
+                           cols, eps, alpha, p_drop, seed);
+    else
+        hipLaunchKernelGGL((res_ln_train_kernel<_Float16>), grid, block, 0, s, t0, t1, residual, gamma, beta, pre, y32, reinterpret_cast<_Float16*>(y16),
+                           rows, cols, eps, alpha, p_drop, seed);
+    CIR_LAUNCH_RESULT();
+}
+
+extern "C" int cir_layernorm_bwd_fused(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, const float* t_add,
+                                       void* dt16, float* dbias, float* dbias2, int64_t rows, int cols, float eps, float alpha, float p_drop,
+                                       uint64_t seed, int dtype16, void* stream) {
+    CIR_CHECK_PTR(x); CIR_CHECK_PTR(gamma); CIR_CHECK_PTR(dy); CIR_CHECK_PTR(dgamma); CIR_CHECK_PTR(dbeta);
+    if (dx == nullptr && dt16 == nullptr) return CIR_EINVAL;
+    if (rows <= 0 || cols <= 0 || p_drop < 0.f || p_drop >= 1.f) return CIR_EINVAL;
+    if (cols % 4 != 0 || cols > 256 * kRowVec) return CIR_ESHAPE;
+    if (dtype16 != CIR_BF16 && dtype16 != CIR_F16) return CIR_EDTYPE;
+    if (!cir_aligned16(x) || !cir_aligned16(gamma) || !cir_aligned16(dy) || !cir_aligned16(dx) || !cir_aligned16(t_add) ||
+        (reinterpret_cast<uintptr_t>(dt16) & 7u)) return CIR_EALIGN;
+    dim3 grid((unsigned)((rows + 31) / 32)), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype16 == CIR_BF16)
+        hipLaunchKernelGGL((ln_bwd_fused_kernel<__bf16>), grid, block, 0, s, x, gamma, dy, dx, dgamma, dbeta, t_add, reinterpret_cast<__bf16*>(dt16), dbias,
+                           dbias2, rows, cols, eps, alpha, p_drop, seed);
+    else
+        hipLaunchKernelGGL((ln_bwd_fused_kernel<_Float16>), grid, block, 0, s, x, gamma, dy, dx, dgamma, dbeta, t_add, reinterpret_cast<_Float16*>(dt16),
+                           dbias, dbias2, rows, cols, eps, alpha, p_drop, seed);
+    CIR_LAUNCH_RESULT();
+}
+
+extern "C" int cir_rows16_colsum(const void* a, int64_t lda, const void* z, int64_t ldz, void* out, int64_t ldo, float* sums, int64_t rows, int cols,
+                                 int mode, int dtype, void* stream) {
+    CIR_CHECK_PTR(a);
+    if (rows <= 0 || cols <= 0 || mode < 0 || mode > 1) return CIR_EINVAL;
+    if (mode == 0 && sums == nullptr) return CIR_EINVAL;
+    if (mode == 1 && (z == nullptr || out == nullptr)) return CIR_EINVAL;
+    if (cols % 8 != 0 || lda % 8 != 0 || (mode == 1 && (ldz % 8 != 0 || ldo % 8 != 0))) return CIR_ESHAPE;
+    if (dtype != CIR_BF16 && dtype != CIR_F16) return CIR_EDTYPE;
+    if (!cir_aligned16(a) || !cir_aligned16(z) || !cir_aligned16(out)) return CIR_EALIGN;
+    const int64_t row_blocks = (rows + 63) / 64;
+    if (row_blocks > 65535) return CIR_ESHAPE;
+    dim3 grid((cols + 255) / 256, (unsigned)row_blocks), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define CIR_R16(T, MODE) hipLaunchKernelGGL((rows16_colsum_kernel<T, MODE>), grid, block, 0, s, reinterpret_cast<const T*>(a), lda, \
+                                            reinterpret_cast<const T*>(z), ldz, reinterpret_cast<T*>(out), ldo, sums, rows, cols)
+    if (dtype == CIR_BF16) { if (mode) CIR_R16(__bf16, 1); else CIR_R16(__bf16, 0); }
+    else { if (mode) CIR_R16(_Float16, 1); else CIR_R16(_Float16, 0); }
+#undef CIR_R16
+    CIR_LAUNCH_RESULT();
+}

@@ -54,7 +54,12 @@ SIGNATURES = {
     "cir_attention_train_bwd": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
                                         c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
-                                        c_int, c_int, c_int, c_int, c_float, c_float, c_uint64, c_int, c_void_p]),
+                                        c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_uint64, c_int, c_void_p]),
+    "cir_residual_layernorm_train": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float,
+                                             c_float, c_float, c_uint64, c_int, c_void_p]),
+    "cir_layernorm_bwd_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                        c_int, c_float, c_float, c_float, c_uint64, c_int, c_void_p]),
+    "cir_rows16_colsum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "cir_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "cir_eltwise": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_uint64, c_void_p]),
     "cir_colsum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),

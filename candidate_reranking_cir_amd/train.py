@@ -123,11 +123,12 @@ class _Lin:
         self.dw = slab.span(slab.gflat, ws)
         self.db = slab.span(slab.gflat, bs) if has_bias else None
 
-    def fwd(self, x16: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
+    def fwd(self, x16: torch.Tensor, out_dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         m, k = x16.shape
         n = self.w16.shape[0]
         if _gemm_ok(m, n, k):
-            return ops.gemm(x16, self.w16, self.bias, out_dtype=out_dtype)
+            return ops.gemm(x16, self.w16, self.bias, out_dtype=out_dtype, out=out)
+        assert out is None
         y = T.bmm(x16.unsqueeze(0), self.w16.unsqueeze(0), False, True, out_dtype=torch.float32)[0]
         if self.bias is not None:
             y = T.eltwise(y, T.MODE_ADD, self.bias.unsqueeze(0).expand(m, n).contiguous())
@@ -155,6 +156,26 @@ class _Lin:
         return T.bmm(dy16.unsqueeze(0), self.w16.unsqueeze(0), False, False, out_dtype=torch.float32)[0]
 
 
+    def bwd16(self, x16: torch.Tensor, dy16: torch.Tensor, need_dx: bool = True, dx_dtype: torch.dtype = torch.float32,
+              residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, bias: bool = False) -> Optional[torch.Tensor]:
+        """dy16 (M, N) ALREADY the 16-bit operand (any row stride: written by the fused row kernels, the attention adjoint or the dgrad
+        product before): accumulates dW - and db when `bias` (otherwise the producer of dy16 summed it) -; returns
+        dx = dy . W (+ residual: the fp32 gradient arriving over the skip connection, added in the GEMM epilogue) in `dx_dtype`."""
+        m, k = x16.shape
+        n = self.w16.shape[0]
+        if bias and self.db is not None:
+            T.colsum16(dy16, self.db)
+        nb = _row_split(m, n, k)
+        if nb == 1:
+            T.bmm(dy16.unsqueeze(0), x16.unsqueeze(0), True, False, out=self.dw.unsqueeze(0), accumulate=True)
+        else:
+            part = T.bmm(dy16.unflatten(0, (nb, m // nb)), x16.unflatten(0, (nb, m // nb)), True, False, out_dtype=torch.float32)
+            T.colsum(part.view(nb, n * k), self.dw.view(-1))
+        if not need_dx:
+            return None
+        return ops.gemm(dy16, self.w16t, None, residual=residual, out_dtype=dx_dtype, out=out)
+
+
 class _LN:
     def __init__(self, slab: _Slab, name: str, eps: float):
         self.eps = eps
@@ -167,6 +188,14 @@ class _LN:
     def bwd(self, pre: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
         return T.layernorm_bwd(pre, self.g, dy, self.dg, self.db, self.eps)
 
+    def fwd_res(self, t0, t1, res, dtype, alpha=1.0, p_drop=0.0, seed=0, **out):
+        """(pre, y32, y16) of LayerNorm(dropout(alpha * (t0 + t1)) + res): one launch (cir_residual_layernorm_train)."""
+        return T.residual_layernorm_train(t0, t1, res, self.g, self.b, self.eps, dtype, alpha, p_drop, seed, **out)
+
+    def bwd_res(self, pre, dy, dtype, **kw):
+        """(d pre fp32, 16-bit gradient of the dense branch behind the dropout) - cir_layernorm_bwd_fused."""
+        return T.layernorm_bwd_fused(pre, self.g, dy, self.dg, self.db, self.eps, dtype, **kw)
+
 
 class NlvrTrainer:
     """Forward (with saved activations) and backward of the two-branch encoder + cls_head for a B x B training batch."""
@@ -178,7 +207,6 @@ class NlvrTrainer:
         self.step_no = 0
         self._hd = self.geo.hidden_size // self.geo.num_attention_heads
         self._scale = self._hd ** -0.5
-        self.fused_attention = True       # cir_attention_train_fwd / _bwd (head dimension 64); False: the un-fused bmm / softmax chain
 
     # ------------------------------------------------------------------------------------------------ parameters
     _EMB = "text_encoder.embeddings."
@@ -263,43 +291,23 @@ class NlvrTrainer:
         """q4 (G, H, mq, hd), k4 / v4 (G, H, mk, hd) head views of 16-bit projections: G groups of mq query rows and mk key rows;
         mask (groups, mk) additive fp32, one row per mq * H score rows, or None.  Self-attention: a group is a triplet;
         cross-attention: a group is a CANDIDATE with the B queries scored against it stacked in mq = B * L rows - its keys /
-        values exist once."""
+        values exist once.  ONE kernel - scores, mask, softmax, dropout, P.V tile by tile in registers - and a log-sum-exp per row
+        for the recomputing backward; no score / probability tensor is materialised (cir_attention_train_fwd; head dimension 64,
+        which config.BertGeometry enforces)."""
         nb1, h_n, mq, _ = q4.shape
-        mk, d = k4.shape[2], self.geo.hidden_size
-        if self.fused_attention and self._hd == 64:
-            # round 4: ONE kernel - scores, mask, softmax, dropout, P.V tile by tile in registers - and a log-sum-exp per row for the
-            # recomputing backward; no score / probability tensor is materialised (cir_attention_train_fwd)
-            ctx = torch.empty((nb1 * mq, d), dtype=q4.dtype, device=q4.device)
-            ctx32 = torch.empty((nb1 * mq, d), dtype=torch.float32, device=q4.device)    # fp32 twin of the context: the backward's D = rowsum(dO * O) (cirrank.h)
-            lse = T.attention_train_fwd(q4, k4, v4, mask, self._heads(ctx, nb1, mq), self._scale, self.p_attn, site, out32=self._heads(ctx32, nb1, mq))
-            return ctx, (lse, mask, site, ctx, ctx32)
-        ld = (mk + 7) // 8 * 8                                                       # padded score rows: 16-byte loads in cir_bmm
-        s = torch.empty((nb1, h_n, mq, ld), dtype=torch.float32, device=q4.device)
-        T.bmm(q4, k4, False, True, out=s[..., :mk])
-        p, pd = T.softmax_dropout(s.view(-1, ld), mask, h_n * mq, self._scale, self.p_attn, site, q4.dtype, cols=mk)
+        d = self.geo.hidden_size
         ctx = torch.empty((nb1 * mq, d), dtype=q4.dtype, device=q4.device)
-        T.bmm(pd.view(nb1, h_n, mq, ld)[..., :mk], v4, False, False, out=self._heads(ctx, nb1, mq))
-        return ctx, (p, pd, site)
+        ctx32 = torch.empty((nb1 * mq, d), dtype=torch.float32, device=q4.device)    # fp32 twin of the context: the backward's D = rowsum(dO * O) (cirrank.h)
+        lse = T.attention_train_fwd(q4, k4, v4, mask, self._heads(ctx, nb1, mq), self._scale, self.p_attn, site, out32=self._heads(ctx32, nb1, mq))
+        return ctx, (lse, mask, site, ctx, ctx32)
 
-    def _attn_bwd(self, dctx, q4, k4, v4, saved, dq4, dk4, dv4):
-        """dctx fp32 (G*mq, D) -> dq4 / dk4 / dv4: fp32 head views the gradients are written into (slices of the buffer the fused
-        projection's backward reads)."""
+    def _attn_bwd(self, dctx16, q4, k4, v4, saved, dq4, dk4, dv4):
+        """dctx16 (G*mq, D) in the operand type -> dq4 / dk4 / dv4: head views (same type) of the buffer the fused projection's
+        backward reads as its dy operand."""
         nb1, h_n, mq, _ = q4.shape
-        if len(saved) == 5:                                                          # fused pair (see _attn_fwd)
-            lse, mask, site, ctx, ctx32 = saved
-            T.attention_train_bwd(q4, k4, v4, mask, self._heads(ctx, nb1, mq), self._heads(_cast(dctx, q4.dtype), nb1, mq), lse, dq4, dk4, dv4,
-                                  self._scale, self.p_attn, site, out32=self._heads(ctx32, nb1, mq))
-            return
-        p, pd, site = saved
-        mk, ld = k4.shape[2], p.shape[1]
-        dc = self._heads(_cast(dctx, q4.dtype), nb1, mq)
-        pd4 = pd.view(nb1, h_n, mq, ld)[..., :mk]
-        dpd = torch.empty((nb1, h_n, mq, ld), dtype=torch.float32, device=dctx.device)
-        T.bmm(dc, v4, False, True, out=dpd[..., :mk])                                # dPd = dctx . V^T
-        T.bmm(pd4, dc, True, False, out=dv4)                                         # dV  = Pd^T . dctx
-        ds = T.softmax_dropout_bwd(p, dpd.view(-1, ld), self._scale, self.p_attn, site, cols=mk).view(nb1, h_n, mq, ld)[..., :mk]
-        T.bmm(ds, k4, False, False, out=dq4)                                         # dQ = dS . K
-        T.bmm(ds, q4, True, False, out=dk4)                                          # dK = dS^T . Q
+        lse, mask, site, ctx, ctx32 = saved
+        T.attention_train_bwd(q4, k4, v4, mask, self._heads(ctx, nb1, mq), self._heads(dctx16, nb1, mq), lse, dq4, dk4, dv4,
+                              self._scale, self.p_attn, site, out32=self._heads(ctx32, nb1, mq))
 
     # ------------------------------------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -313,6 +321,8 @@ class NlvrTrainer:
         n, d = feats.shape[1], g.hidden_size
         t_n = b_n * b_n
         r = t_n * l
+        ph = self.p_hidden
+        f32 = torch.float32
         # triplet t = j * B + i scores query i (caption, z_t) against target j - candidate-major, so that the B queries of one
         # target are consecutive rows and its cross-attention keys / values are projected ONCE (the reference recomputes them
         # for every query, blip_stage2.py:80-92; same values); the (B_j, B_i) result is transposed on the way out
@@ -321,66 +331,62 @@ class NlvrTrainer:
         self.sv = sv = {"ids": ids_t, "t_n": t_n, "l": l, "n": n, "b_n": b_n}
         # embeddings (BertEmbeddings: LayerNorm(word + pos), dropout) -> branch 1; z_t -> branch 0 (nlvr_encoder.py:880-892)
         pos_idx = torch.arange(l, device=dev).repeat(t_n)
-        pre_e = T.eltwise(ops.gather_rows(self.word, ids_t.view(-1), torch.float32), T.MODE_ADD,
-                          ops.gather_rows(self.pos, pos_idx, torch.float32))
+        pre_e = T.eltwise(ops.gather_rows(self.word, ids_t.view(-1), f32), T.MODE_ADD, ops.gather_rows(self.pos, pos_idx, f32))
         sv["pre_e"] = pre_e
         e32, _ = self.ln_e.fwd(pre_e, dt)
         e32 = self._drop(e32, self._site(9000))
-        h32 = [ops.gather_rows(z_t.to(dev).float().contiguous().view(b_n, l * d), qi, torch.float32).view(r, d), e32]
+        h32 = [ops.gather_rows(z_t.to(dev).float().contiguous().view(b_n, l * d), qi, f32).view(r, d), e32]
         h16 = [_cast(x, dt) for x in h32]
         cand16 = _cast(feats.to(dev).float().contiguous(), dt).view(b_n * n, -1)                          # (B*N, Dv): each target once
         sv["cand16"] = cand16
         smask = ((1.0 - attention_mask.to(dev).float()) * -10000.0)[qi].contiguous()                      # (T, L), nlvr_encoder.py:773-774
         sv["layers"] = []
         for i, ly in enumerate(self.layers):
-            s = {"h16": h16, "qkv": [], "sa": [], "ctx": [], "pre1": [], "a16": [], "cq": [], "ckv": [], "ca": [],
-                 "c": [], "pre2": [], "x16": [], "z": [], "f16": [], "pre3": []}
+            s = {"h16": h16, "qkv": [], "sa": [], "ctx": [], "pre1": [], "a16": [], "cq": [], "ckv": [], "ca": [], "c": []}
             a32, dd = [], []
+            cat16 = None if ly["merge"] is None else torch.empty((r, 2 * d), dtype=dt, device=dev)
             for b in (0, 1):
                 qkv = ly[f"qkv{b}"].fwd(h16[b], dt)                                   # (R, 3D)
                 ctx, sa = self._attn_fwd(*(self._heads(qkv, t_n, l, j, 3) for j in range(3)), smask, self._site(i, b, 1))
-                t = self._drop(ly[f"o{b}"].fwd(ctx, torch.float32), self._site(i, b, 2))
-                pre1 = T.eltwise(t, T.MODE_ADD, h32[b])
-                a, a16 = ly[f"ln1{b}"].fwd(pre1, dt)
+                # BertSelfOutput (nlvr_encoder.py:399-409): LayerNorm(dropout(dense(ctx)) + h) - dropout, sum and LayerNorm in one pass
+                pre1, a, a16 = ly[f"ln1{b}"].fwd_res(ly[f"o{b}"].fwd(ctx, f32), None, h32[b], dt, 1.0, ph, self._site(i, b, 2))
                 cq = ly[f"cq{b}"].fwd(a16, dt)
                 ckv = ly[f"ckv{b}"].fwd(cand16, dt)                                   # (B*N, 2D): each target's keys | values, once
                 c, ca = self._attn_fwd(self._heads(cq, b_n, b_n * l), self._heads(ckv, b_n, n, 0, 2), self._heads(ckv, b_n, n, 1, 2), None,
                                        self._site(i, b, 3))
-                dd.append(ly[f"d{b}"].fwd(c, torch.float32))
+                if cat16 is None:
+                    dd.append(ly[f"d{b}"].fwd(c, f32))
+                else:                                                                # the merge layer's operand: written in place, 16-bit
+                    ly[f"d{b}"].fwd(c, dt, out=cat16[:, b * d:(b + 1) * d])
                 a32.append(a)
                 for key, val in (("qkv", qkv), ("sa", sa), ("ctx", ctx), ("pre1", pre1), ("a16", a16), ("cq", cq), ("ckv", ckv), ("ca", ca),
                                  ("c", c)):
                     s[key].append(val)
-            if ly["merge"] is None:                                                 # layers < 6: average (nlvr_encoder.py:257-260)
-                m = T.eltwise(T.eltwise(dd[0], T.MODE_ADD, dd[1]), T.MODE_SCALE, p_drop=0.5)
+            if cat16 is None:                                                       # layers < 6: average (nlvr_encoder.py:257-260)
+                t0, t1, alpha = dd[0], dd[1], 0.5
             else:                                                                   # layers >= 6: merge_layer(cat) (:252-256)
-                cat16 = torch.cat([_cast(dd[0], dt), _cast(dd[1], dt)], dim=1).contiguous()
                 s["cat16"] = cat16
-                m = ly["merge"].fwd(cat16, torch.float32)
-            m = self._drop(m, self._site(i, 2, 4))
+                t0, t1, alpha = ly["merge"].fwd(cat16, f32), None, 1.0
+            # BertSelfOutput of the cross-attention: m = dropout(average | merge) (ONE mask for both branches), LayerNormA / B (m + a_b).
             # FFN: the SAME weights serve both branches (nlvr_encoder.py:469-476) - one pass over the 2R stacked rows (one GEMM pair,
-            # one GELU / dropout / LayerNorm launch, and in the backward one dgrad / wgrad product each instead of two half-sized ones)
-            pre2 = [T.eltwise(m, T.MODE_ADD, a32[b]) for b in (0, 1)]
-            x32 = torch.empty((2 * r, d), dtype=torch.float32, device=dev)
-            x16 = torch.empty((2 * r, d), dtype=dt, device=dev)
+            # one GELU / LayerNorm launch, and in the backward one dgrad / wgrad product each instead of two half-sized ones)
+            pre2 = torch.empty((2 * r, d), dtype=f32, device=dev)
+            x32, x16 = torch.empty_like(pre2), torch.empty((2 * r, d), dtype=dt, device=dev)
             for b in (0, 1):
-                ops.layernorm(pre2[b], ly[f"ln2{b}"].g, ly[f"ln2{b}"].b, g.layer_norm_eps, want32=True, dtype16=dt, stream_dtype=torch.float32,
-                              out32=x32[b * r:(b + 1) * r], out16=x16[b * r:(b + 1) * r])
-            z = ly["w1"].fwd(x16, torch.float32)
-            f16 = T.eltwise(z, T.MODE_GELU, out_dtype=dt)
-            o = self._drop(ly["w2"].fwd(f16, torch.float32), self._site(i, 0, 5))
-            pre3 = T.eltwise(o, T.MODE_ADD, x32)
-            hn, hn16 = ly["ln3"].fwd(pre3, dt)
-            h32n, h16n = [hn[:r], hn[r:]], [hn16[:r], hn16[r:]]
-            s.update(pre2=pre2, x16=x16, z=z, f16=f16, pre3=pre3)
+                rows = slice(b * r, (b + 1) * r)
+                ly[f"ln2{b}"].fwd_res(t0, t1, a32[b], dt, alpha, ph, self._site(i, 2, 4), pre=pre2[rows], y32=x32[rows], y16=x16[rows])
+            z16 = ly["w1"].fwd(x16, dt)                                             # the dense output in the operand type, as autocast leaves it
+            f16 = T.eltwise(z16, T.MODE_GELU, out_dtype=dt)
+            pre3, hn, hn16 = ly["ln3"].fwd_res(ly["w2"].fwd(f16, f32), None, x32, dt, 1.0, ph, self._site(i, 0, 5))
+            s.update(pre2=pre2, x16=x16, z16=z16, f16=f16, pre3=pre3)
             sv["layers"].append(s)
-            h32, h16 = h32n, h16n
+            h32, h16 = [hn[:r], hn[r:]], [hn16[:r], hn16[r:]]
         # cat(CLS_0, CLS_1) -> cls_head (nlvr_encoder.py:906-908, blip_stage2.py:50-54, 94-99)
         cls_rows = torch.arange(t_n, device=dev) * l
         hid16 = torch.cat([ops.gather_rows(h16[0], cls_rows, dt), ops.gather_rows(h16[1], cls_rows, dt)], dim=1).contiguous()
-        z1 = self.c0.fwd(hid16, torch.float32)
+        z1 = self.c0.fwd(hid16, f32)
         y16 = T.eltwise(z1, T.MODE_RELU, out_dtype=dt)
-        logits2 = self.c2.fwd(y16, torch.float32)                                   # (T, 2)
+        logits2 = self.c2.fwd(y16, f32)                                             # (T, 2)
         sv.update(hid16=hid16, z1=z1, y16=y16, cls_rows=cls_rows)
         return logits2[:, 0].contiguous().view(b_n, b_n).t().contiguous()           # (B_j, B_i) -> (B_i, B_j)
 
@@ -411,51 +417,55 @@ class NlvrTrainer:
         dy1 = self.c2.bwd(sv["y16"], dl2)
         dz1 = T.eltwise(sv["z1"], T.MODE_RELU_BWD, dy1)
         dhid = self.c0.bwd(sv["hid16"], dz1)                                        # (T, 2D)
-        dh = []
-        for b in (0, 1):
-            x = torch.zeros((r, d), dtype=torch.float32, device=dev)
-            x[sv["cls_rows"]] = dhid[:, b * d:(b + 1) * d]
-            dh.append(x)
-        add = lambda x, y: T.eltwise(x, T.MODE_ADD, y)
-        undrop = lambda x, site: x if self.p_hidden <= 0 else T.eltwise(x, T.MODE_DROPOUT, p_drop=self.p_hidden, seed=site)
+        # Between the dense layers every gradient is the 16-bit operand of the next product (written by the kernel that forms it -
+        # a fused LayerNorm adjoint, the attention adjoint, a dgrad epilogue), bias gradients are summed where it is formed, and
+        # the fp32 gradient of the residual stream joins in the dgrad GEMM's epilogue: no stand-alone cast / add / dropout pass.
+        dh = torch.zeros((2 * r, d), dtype=torch.float32, device=dev)               # both branches stacked, as the FFN saw them
+        dh[sv["cls_rows"]] = dhid[:, :d]
+        dh[sv["cls_rows"] + r] = dhid[:, d:]
+        ph, b_n = self.p_hidden, sv["b_n"]
         for i in reversed(range(len(self.layers))):
             ly, s = self.layers[i], sv["layers"][i]
-            dpre3 = ly["ln3"].bwd(s["pre3"], torch.cat([dh[0], dh[1]]))             # both branches: 2R stacked rows, shared FFN weights
-            do = undrop(dpre3, self._site(i, 0, 5))
-            df = ly["w2"].bwd(s["f16"], do)
-            dz = T.eltwise(s["z"], T.MODE_GELU_BWD, df)
-            dx = add(ly["w1"].bwd(s["x16"], dz), dpre3)
-            dpre2 = [ly[f"ln2{b}"].bwd(s["pre2"][b], dx[b * r:(b + 1) * r].contiguous()) for b in (0, 1)]
-            dm = undrop(add(dpre2[0], dpre2[1]), self._site(i, 2, 4))
-            if ly["merge"] is None:
-                half = T.eltwise(dm, T.MODE_SCALE, p_drop=0.5)
-                dd = [half, half]
+            w1, w2 = ly["w1"], ly["w2"]
+            dpre3, do16 = ly["ln3"].bwd_res(s["pre3"], dh, dt, dbias=w2.db, p_drop=ph, seed=self._site(i, 0, 5))
+            df16 = w2.bwd16(s["f16"], do16, dx_dtype=dt)
+            dz16 = T.gelu_bwd16(df16, s["z16"], sums=w1.db)
+            dx = w1.bwd16(s["x16"], dz16, residual=dpre3)                           # (2R, D) fp32: FFN branch + skip
+            # the two LayerNorms over m + a_b: d m = dropout'(d pre2_0 + d pre2_1) comes out of the second one's kernel
+            merge = ly["merge"]
+            dpre2 = [ly["ln20"].bwd_res(s["pre2"][:r], dx[:r], dt, want_dt=False)[0]]
+            if merge is None:                                                       # average: both output denses see 0.5 * d m
+                kw = dict(alpha=0.5, dbias=ly["d0"].db, dbias2=ly["d1"].db)
             else:
-                dcat = ly["merge"].bwd(s["cat16"], dm)
-                dd = [dcat[:, :d].contiguous(), dcat[:, d:].contiguous()]
-            dh_in = []
+                kw = dict(alpha=1.0, dbias=merge.db)
+            dp, dm16 = ly["ln21"].bwd_res(s["pre2"][r:], dx[r:], dt, t_add=dpre2[0], p_drop=ph, seed=self._site(i, 2, 4), **kw)
+            dpre2.append(dp)
+            if merge is None:
+                dd16 = [dm16, dm16]
+            else:
+                dcat16 = merge.bwd16(s["cat16"], dm16, dx_dtype=dt)                 # (R, 2D)
+                dd16 = [dcat16[:, :d], dcat16[:, d:]]
+            dh_in = torch.empty((2 * r, d), dtype=torch.float32, device=dev)
             for b in (0, 1):
-                dc = ly[f"d{b}"].bwd(s["c"][b], dd[b])
-                b_n = sv["b_n"]
+                dc16 = ly[f"d{b}"].bwd16(s["c"][b], dd16[b], dx_dtype=dt, bias=merge is not None)
                 cq, ckv = s["cq"][b], s["ckv"][b]
-                dcq = torch.empty((r, d), dtype=torch.float32, device=dev)
-                dckv = torch.empty((b_n * n, 2 * d), dtype=torch.float32, device=dev)
-                self._attn_bwd(dc, self._heads(cq, b_n, b_n * l), self._heads(ckv, b_n, n, 0, 2), self._heads(ckv, b_n, n, 1, 2), s["ca"][b],
-                               self._heads(dcq, b_n, b_n * l), self._heads(dckv, b_n, n, 0, 2), self._heads(dckv, b_n, n, 1, 2))
-                ly[f"ckv{b}"].bwd(sv["cand16"], dckv, need_dx=False)                # image tokens are inputs: no gradient beyond the weights
-                da = add(ly[f"cq{b}"].bwd(s["a16"][b], dcq), dpre2[b])
-                dpre1 = ly[f"ln1{b}"].bwd(s["pre1"][b], da)
-                dt_ = undrop(dpre1, self._site(i, b, 2))
-                dctx = ly[f"o{b}"].bwd(s["ctx"][b], dt_)
+                dcq16 = torch.empty((r, d), dtype=dt, device=dev)
+                dckv16 = torch.empty((b_n * n, 2 * d), dtype=dt, device=dev)
+                self._attn_bwd(dc16, self._heads(cq, b_n, b_n * l), self._heads(ckv, b_n, n, 0, 2), self._heads(ckv, b_n, n, 1, 2), s["ca"][b],
+                               self._heads(dcq16, b_n, b_n * l), self._heads(dckv16, b_n, n, 0, 2), self._heads(dckv16, b_n, n, 1, 2))
+                ly[f"ckv{b}"].bwd16(sv["cand16"], dckv16, need_dx=False, bias=True)  # image tokens are inputs: no gradient beyond the weights
+                da = ly[f"cq{b}"].bwd16(s["a16"][b], dcq16, residual=dpre2[b], bias=True)
+                o = ly[f"o{b}"]
+                dpre1, dt16 = ly[f"ln1{b}"].bwd_res(s["pre1"][b], da, dt, dbias=o.db, p_drop=ph, seed=self._site(i, b, 2))
+                dctx16 = o.bwd16(s["ctx"][b], dt16, dx_dtype=dt)
                 qkv = s["qkv"][b]
-                dqkv = torch.empty((r, 3 * d), dtype=torch.float32, device=dev)
-                self._attn_bwd(dctx, *(self._heads(qkv, t_n, l, j, 3) for j in range(3)), s["sa"][b],
-                               *(self._heads(dqkv, t_n, l, j, 3) for j in range(3)))
-                dhb = add(dpre1, ly[f"qkv{b}"].bwd(s["h16"][b], dqkv))
-                dh_in.append(dhb)
+                dqkv16 = torch.empty((r, 3 * d), dtype=dt, device=dev)
+                self._attn_bwd(dctx16, *(self._heads(qkv, t_n, l, j, 3) for j in range(3)), s["sa"][b],
+                               *(self._heads(dqkv16, t_n, l, j, 3) for j in range(3)))
+                ly[f"qkv{b}"].bwd16(s["h16"][b], dqkv16, residual=dpre1, out=dh_in[b * r:(b + 1) * r], bias=True)
             dh = dh_in
         # branch 1 entered through BertEmbeddings; branch 0 is z_t (frozen stage I)
-        de = undrop(dh[1], self._site(9000))
+        de = dh[r:] if ph <= 0 else T.eltwise(dh[r:], T.MODE_DROPOUT, p_drop=ph, seed=self._site(9000))
         dpre_e = self.ln_e.bwd(sv["pre_e"], de)
         T.embed_bwd(sv["ids"].view(-1), dpre_e, self.dword, self.dpos, l)
         return self._collect()

@@ -112,19 +112,20 @@ def attention_train_fwd(q4: torch.Tensor, k4: torch.Tensor, v4: torch.Tensor, ma
 
 
 def attention_train_bwd(q4, k4, v4, mask, out4, dout4, lse, dq4, dk4, dv4, scale: float, p_drop: float, seed: int, out32=None):
-    """Recomputing backward of `attention_train_fwd`: dout4 16-bit in out4's layout; dq4 / dk4 / dv4 fp32 head views (written)."""
+    """Recomputing backward of `attention_train_fwd`: dout4 16-bit in out4's layout; dq4 / dk4 / dv4 head views (written), all fp32 or all in
+    the operand type (then the projection's backward products read them as they are)."""
     _need_cuda(q4, k4, v4, mask, out4, dout4, lse, dq4, dk4, dv4)
     g, h, lq, _ = q4.shape
     lk = k4.shape[2]
     assert dout4.shape == out4.shape and dout4.stride() == out4.stride() and dout4.dtype == out4.dtype == q4.dtype
     assert lse.shape == (g, h, lq) and lse.is_contiguous() and lse.dtype == torch.float32
-    assert dq4.shape == q4.shape and dk4.shape == k4.shape and dv4.shape == v4.shape and dq4.dtype == dk4.dtype == dv4.dtype == torch.float32
+    assert dq4.shape == q4.shape and dk4.shape == k4.shape and dv4.shape == v4.shape and dq4.dtype == dk4.dtype == dv4.dtype and dq4.dtype in (torch.float32, q4.dtype)
     dsum = torch.empty((g, h, lq), dtype=torch.float32, device=q4.device)
     qo = _hv(out4)
     assert out32 is None or (out32.dtype == torch.float32 and out32.shape == out4.shape and out32.stride() == out4.stride())
     _lib.check(_lib.load().cir_attention_train_bwd(*_hv(q4), *_hv(k4), *_hv(v4), _ptr(mask), qo[0], dout4.data_ptr(), qo[1], qo[2], qo[3],
                                                    _ptr(out32), lse.data_ptr(),
-                                                   dsum.data_ptr(), *_hv(dq4), *_hv(dk4), *_hv(dv4), g, h, lq, lk, float(scale), float(p_drop),
+                                                   dsum.data_ptr(), *_hv(dq4), *_hv(dk4), *_hv(dv4), _DT[dq4.dtype], g, h, lq, lk, float(scale), float(p_drop),
                                                    int(seed) & (2 ** 63 - 1), _DT[q4.dtype], _stream()), "cir_attention_train_bwd")
 
 
@@ -137,6 +138,66 @@ def layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, dgamma
     _lib.check(_lib.load().cir_layernorm_bwd(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, cols,
                                              float(eps), _stream()), "cir_layernorm_bwd")
     return dx
+
+
+def residual_layernorm_train(t0: torch.Tensor, t1: Optional[torch.Tensor], residual: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+                             dtype16: torch.dtype, alpha: float = 1.0, p_drop: float = 0.0, seed: int = 0, pre: Optional[torch.Tensor] = None,
+                             y32: Optional[torch.Tensor] = None, y16: Optional[torch.Tensor] = None, want32: bool = True):
+    """pre = dropout(alpha * (t0 + t1)) + residual; y = LayerNorm(pre) in one pass (cir_residual_layernorm_train).  fp32 (rows, cols)
+    contiguous inputs -> (pre fp32, y fp32 or None, y 16-bit); outputs may be given (contiguous row ranges of larger buffers)."""
+    _need_cuda(t0, t1, residual, gamma, beta, pre, y32, y16)
+    rows, cols = t0.shape
+    for t in (t0, t1, residual, pre, y32):
+        assert t is None or (t.dtype == torch.float32 and t.shape == (rows, cols) and t.is_contiguous())
+    pre = torch.empty_like(t0) if pre is None else pre
+    if y32 is None and want32:
+        y32 = torch.empty_like(t0)
+    y16 = torch.empty((rows, cols), dtype=dtype16, device=t0.device) if y16 is None else y16
+    assert y16.dtype == dtype16 and y16.shape == (rows, cols) and y16.is_contiguous()
+    _lib.check(_lib.load().cir_residual_layernorm_train(t0.data_ptr(), _ptr(t1), residual.data_ptr(), gamma.data_ptr(), beta.data_ptr(), pre.data_ptr(),
+                                                        _ptr(y32), y16.data_ptr(), rows, cols, float(eps), float(alpha), float(p_drop),
+                                                        int(seed) & (2 ** 63 - 1), _DT[dtype16], _stream()), "cir_residual_layernorm_train")
+    return pre, y32, y16
+
+
+def layernorm_bwd_fused(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor, eps: float,
+                        dtype16: torch.dtype, t_add: Optional[torch.Tensor] = None, dbias: Optional[torch.Tensor] = None,
+                        dbias2: Optional[torch.Tensor] = None, alpha: float = 1.0, p_drop: float = 0.0, seed: int = 0, want_dx: bool = True,
+                        want_dt: bool = True, dx: Optional[torch.Tensor] = None):
+    """Adjoint of `residual_layernorm_train` (cir_layernorm_bwd_fused): x (the saved pre) / dy fp32 (rows, cols) -> (dx fp32: gradient of pre =
+    of the residual; dt16: alpha * dropout'(dx + t_add) in `dtype16`, the dense branch's gradient, its column sums accumulated into dbias /
+    dbias2).  dgamma / dbeta are accumulated."""
+    _need_cuda(x, gamma, dy, dgamma, dbeta, t_add, dbias, dbias2, dx)
+    rows, cols = x.shape
+    for t in (x, dy, t_add, dx):
+        assert t is None or (t.dtype == torch.float32 and t.shape == (rows, cols) and t.is_contiguous())
+    if dx is None and want_dx:
+        dx = torch.empty_like(x)
+    dt16 = torch.empty((rows, cols), dtype=dtype16, device=x.device) if want_dt else None
+    _lib.check(_lib.load().cir_layernorm_bwd_fused(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), _ptr(dx), dgamma.data_ptr(), dbeta.data_ptr(),
+                                                   _ptr(t_add), _ptr(dt16), _ptr(dbias), _ptr(dbias2), rows, cols, float(eps), float(alpha),
+                                                   float(p_drop), int(seed) & (2 ** 63 - 1), _DT[dtype16], _stream()), "cir_layernorm_bwd_fused")
+    return dx, dt16
+
+
+def colsum16(a: torch.Tensor, sums: torch.Tensor) -> torch.Tensor:
+    """sums (cols) fp32 += column sums of the 16-bit rows a (rows, cols) (unit last stride, row stride a multiple of 8)."""
+    _need_cuda(a, sums)
+    assert a.dim() == 2 and a.stride(1) == 1 and sums.dtype == torch.float32 and sums.shape == (a.shape[1],) and sums.is_contiguous()
+    _lib.check(_lib.load().cir_rows16_colsum(a.data_ptr(), a.stride(0), None, 0, None, 0, sums.data_ptr(), a.shape[0], a.shape[1], 0, _DT[a.dtype],
+                                             _stream()), "cir_rows16_colsum")
+    return sums
+
+
+def gelu_bwd16(df: torch.Tensor, z: torch.Tensor, sums: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dz = df * gelu'(z) on 16-bit (rows, cols) tensors; sums (cols) fp32 += column sums of dz (the dense layer's bias gradient)."""
+    _need_cuda(df, z, sums)
+    assert df.dim() == 2 and df.shape == z.shape and df.dtype == z.dtype and df.stride(1) == 1 and z.stride(1) == 1
+    assert sums is None or (sums.dtype == torch.float32 and sums.shape == (df.shape[1],) and sums.is_contiguous())
+    out = torch.empty(df.shape, dtype=df.dtype, device=df.device)
+    _lib.check(_lib.load().cir_rows16_colsum(df.data_ptr(), df.stride(0), z.data_ptr(), z.stride(0), out.data_ptr(), out.stride(0), _ptr(sums), df.shape[0],
+                                             df.shape[1], 1, _DT[df.dtype], _stream()), "cir_rows16_colsum")
+    return out
 
 
 def eltwise(z: torch.Tensor, mode: int, dy: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, p_drop: float = 0.0,

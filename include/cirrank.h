@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define CIR_ABI_VERSION 9
+#define CIR_ABI_VERSION 10
 
 enum { CIR_BF16 = 0, CIR_F16 = 1, CIR_F32 = 2 };
 enum { CIR_ACT_NONE = 0, CIR_ACT_GELU = 1, CIR_ACT_RELU = 2 };
@@ -221,7 +221,8 @@ int cir_softmax_dropout(const float* S, int64_t ld_s, const float* mask, int64_t
 int cir_softmax_dropout_bwd(const void* P, int64_t ld_p, const float* dPd, int64_t ld_d, void* dS, int64_t ld_ds, int64_t rows, int cols,
                             float scale, float p_drop, uint64_t seed, int dtype, void* stream);
 /* FUSED attention of the training pass (round 4): out = dropout(softmax(q k^T * scale + mask)) v per (group, head), head dimension 64, with
- * the log2-domain log-sum-exp of every row written to lse (G, H, Lq) - and its recomputing backward: dq / dk / dv (fp32) from q, k, v,
+ * the log2-domain log-sum-exp of every row written to lse (G, H, Lq) - and its recomputing backward: dq / dk / dv (grad_dtype: CIR_F32, or the operand type - ABI v10 - so that the
+ * projection's dgrad / wgrad products read them as they are) from q, k, v,
  * out, d_out and lse; the probabilities are recomputed tile by tile and the dropout mask regenerated from its counter (element index
  * ((g * H + h) * Lq + query) * Lk + key), so no score / probability tensor exists in memory.  Tensors are head views: element
  * (g, h, row, d) at base + g * x_sg + h * x_sh + row * x_sr + d; out and d_out share one layout; mask fp32 (G, Lk) additive or NULL;
@@ -235,13 +236,33 @@ int cir_attention_train_fwd(const void* q, int64_t q_sg, int64_t q_sh, int64_t q
 int cir_attention_train_bwd(const void* q, int64_t q_sg, int64_t q_sh, int64_t q_sr, const void* k, int64_t k_sg, int64_t k_sh, int64_t k_sr,
                             const void* v, int64_t v_sg, int64_t v_sh, int64_t v_sr, const float* mask, const void* out, const void* d_out,
                             int64_t o_sg, int64_t o_sh, int64_t o_sr, const float* out32, const float* lse,
-                            float* dsum_scratch, float* dq, int64_t dq_sg,
-                            int64_t dq_sh, int64_t dq_sr, float* dk, int64_t dk_sg, int64_t dk_sh, int64_t dk_sr, float* dv, int64_t dv_sg,
-                            int64_t dv_sh, int64_t dv_sr, int G, int H, int Lq, int Lk, float scale, float p_drop, uint64_t seed, int dtype,
-                            void* stream);
+                            float* dsum_scratch, void* dq, int64_t dq_sg,
+                            int64_t dq_sh, int64_t dq_sr, void* dk, int64_t dk_sg, int64_t dk_sh, int64_t dk_sr, void* dv, int64_t dv_sg,
+                            int64_t dv_sh, int64_t dv_sr, int grad_dtype, int G, int H, int Lq, int Lk, float scale, float p_drop, uint64_t seed,
+                            int dtype, void* stream);
 /* LayerNorm backward from the saved fp32 input x of the forward: dx (written), dgamma / dbeta (fp32, ACCUMULATED atomically). */
 int cir_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int64_t rows, int cols,
                       float eps, void* stream);
+/* FUSED row passes of the training step (ABI v10; train_fused.hip).  BertSelfOutput / BertOutput in train() mode
+ * (nlvr_encoder.py:248-264, 399-409: dense -> dropout -> + residual -> LayerNorm, incl. the averaged two-branch merge :257-260):
+ *   pre = dropout(alpha * (t0 + t1), p_drop, seed) + residual;  y = LayerNorm(pre; gamma, beta, eps)
+ * t0 / t1 (t1 may be NULL) / residual fp32 (rows, cols) contiguous; pre (fp32, kept for the backward), y32 (fp32 or NULL) and y16 (16-bit in
+ * dtype16, or NULL) are written.  cols % 4 == 0, cols <= 1024.  Dropout element index = row * cols + column. */
+int cir_residual_layernorm_train(const float* t0, const float* t1, const float* residual, const float* gamma, const float* beta, float* pre,
+                                 float* y32, void* y16, int64_t rows, int cols, float eps, float alpha, float p_drop, uint64_t seed, int dtype16,
+                                 void* stream);
+/* Its adjoint: dx = d pre from dy and the saved pre (x) as cir_layernorm_bwd (dx may be NULL when only the dense branch is wanted), dgamma / dbeta
+ * ACCUMULATED; and, when dt16 is given, the gradient of the dense branch  dt = alpha * dropout'(dx + t_add)  (t_add fp32 or NULL: a second
+ * LayerNorm's d pre over the SAME dense output, as behind the two-branch merge) written as the 16-bit operand (dtype16) of that layer's dgrad /
+ * wgrad products, with its column sums ACCUMULATED into dbias and dbias2 (either may be NULL): the dense layer's bias gradient. */
+int cir_layernorm_bwd_fused(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, const float* t_add,
+                            void* dt16, float* dbias, float* dbias2, int64_t rows, int cols, float eps, float alpha, float p_drop, uint64_t seed,
+                            int dtype16, void* stream);
+/* 16-bit rows (rows, cols), row strides lda / ldz / ldo (multiples of 8), cols % 8 == 0.  mode 0: sums[c] += sum_r a[r][c] (bias gradient of a
+ * dense layer whose output gradient is 16-bit: behind the attention adjoints);  mode 1: out = a * gelu'(z) (erf form) and, when sums is given,
+ * sums[c] += sum_r out[r][c] - BertIntermediate's adjoint (nlvr_encoder.py:383-396) with the bias gradient in the same pass. */
+int cir_rows16_colsum(const void* a, int64_t lda, const void* z, int64_t ldz, void* out, int64_t ldo, float* sums, int64_t rows, int cols, int mode,
+                      int dtype, void* stream);
 /* mode 0: out = gelu(z) (erf form, ACT2FN['gelu']); 1: out = dy * gelu'(z); 2: relu(z); 3: dy * (z > 0); 4: dropout(z, p_drop, seed);
  * 5: z + dy; 6: p_drop * z (scale).  z in z_dtype (CIR_F32 / CIR_BF16 / CIR_F16), dy fp32, out in out_dtype. */
 int cir_eltwise(const void* z, int z_dtype, const float* dy, void* out, int out_dtype, int64_t n, int mode, float p_drop, uint64_t seed, void* stream);

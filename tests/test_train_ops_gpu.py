@@ -245,3 +245,102 @@ def test_fused_training_attention_matches_torch_autograd(T, dtype, g, h, lq, lk,
     e_q2, e_k2 = rel(heads(dq2, lq, 0, 3), qf.grad), rel(heads(dkv2, lk, 0, 2), kf.grad)
     print(f"   with the fp32 twin of O: dq {e_q2:.2e}  dk {e_k2:.2e}")
     assert max(e_q2, e_k2) < (2e-2 if dtype == torch.bfloat16 else 3e-3) and e_q2 < 1.1 * e_q + 1e-5
+
+
+def test_fused_training_attention_16bit_gradients(T):
+    """grad_dtype = operand type (ABI v10): the same gradients, rounded once on the way out, into strided head views."""
+    dev, dtype, g, h, lq, lk = torch.device("cuda"), HF, 3, 4, 40, 70
+    gen = torch.Generator().manual_seed(5)
+    qkv = torch.randn((g * lq, 3, h * 64), generator=gen).to(dtype).to(dev)
+    kvx = torch.randn((g * lk, 2, h * 64), generator=gen).to(dtype).to(dev)
+    heads = lambda x, rows, part, parts: x.view(g, rows, parts, h, 64)[:, :, part].permute(0, 2, 1, 3)
+    q4, k4, v4 = heads(qkv, lq, 0, 3), heads(kvx, lk, 0, 2), heads(kvx, lk, 1, 2)
+    ctx = torch.empty((g * lq, h * 64), dtype=dtype, device=dev)
+    out4 = ctx.view(g, lq, h, 64).permute(0, 2, 1, 3)
+    lse = T.attention_train_fwd(q4, k4, v4, None, out4, 0.125, 0.1, 99)
+    dout = (torch.randn((g * lq, h * 64), generator=gen) * 0.5).to(dtype).to(dev).view(g, lq, h, 64).permute(0, 2, 1, 3)
+    res = {}
+    for gd in (torch.float32, dtype):
+        dq = torch.full((g * lq, 3, h * 64), float("nan"), dtype=gd, device=dev)
+        dkv = torch.full((g * lk, 2, h * 64), float("nan"), dtype=gd, device=dev)
+        T.attention_train_bwd(q4, k4, v4, None, out4, dout, lse, heads(dq, lq, 0, 3), heads(dkv, lk, 0, 2), heads(dkv, lk, 1, 2), 0.125, 0.1, 99)
+        res[gd] = (dq, dkv)
+    assert torch.equal(res[dtype][0][:, 0], res[torch.float32][0][:, 0].to(dtype)) and torch.isnan(res[dtype][0][:, 1:]).all()
+    assert torch.equal(res[dtype][1], res[torch.float32][1].to(dtype))
+    with pytest.raises(AssertionError):
+        T.attention_train_bwd(q4, k4, v4, None, out4, dout, lse, heads(res[dtype][0], lq, 0, 3), heads(res[torch.float32][1], lk, 0, 2),
+                              heads(res[torch.float32][1], lk, 1, 2), 0.125, 0.1, 99)
+
+
+# ------------------------------------------------------------------------------------------------ fused row passes (round 4, train_fused.hip)
+def _keep_flat(seed: int, n: int, p: float) -> torch.Tensor:
+    return _keep_mask(seed, 1, 1, 1, n, p).view(-1)
+
+
+@pytest.mark.parametrize("dtype", [BF, HF], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("rows,cols,two,p", [(203, 768, False, 0.1), (64, 1024, True, 0.1), (7, 128, True, 0.0), (130, 132, False, 0.25)])
+def test_residual_layernorm_train_and_adjoint(T, dtype, rows, cols, two, p):
+    """cir_residual_layernorm_train / cir_layernorm_bwd_fused against torch autograd of LayerNorm(dropout(alpha (t0 + t1)) + res) with the
+    kernel's own dropout mask (host-regenerated): pre, y (fp32 and 16-bit); d pre, dgamma, dbeta, the dense branch's 16-bit gradient incl.
+    a second LayerNorm's contribution (t_add), and its column sums into two bias gradients."""
+    dev = torch.device("cuda")
+    t0, t1, res = _r((rows, cols), 31), (_r((rows, cols), 32) if two else None), _r((rows, cols), 33, 2.0)
+    gam, bet = _r((cols,), 34) * 0.1 + 1.0, _r((cols,), 35)
+    alpha, seed, eps = (0.5 if two else 1.0), 4242 + rows, 1e-12
+    pre, y32, y16 = T.residual_layernorm_train(t0, t1, res, gam, bet, eps, dtype, alpha, p, seed)
+    keep = _keep_flat(seed, rows * cols, p).view(rows, cols).to(dev) if p > 0 else torch.ones((rows, cols), dtype=torch.bool, device=dev)
+    tr = (t0 + t1 if two else t0.clone()).requires_grad_(True)
+    rr, gr, br = res.clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    pre_ref = tr * alpha * keep / (1.0 - p) + rr
+    y_ref = F.layer_norm(pre_ref, (cols,), gr, br, eps)
+    torch.testing.assert_close(pre, pre_ref, atol=1e-6, rtol=1e-6)
+    torch.testing.assert_close(y32, y_ref, atol=2e-5, rtol=1e-5)
+    assert torch.equal(y16, y32.to(dtype))
+    # outputs into row ranges of larger buffers, no fp32 y
+    big_pre, big16 = torch.zeros((rows + 8, cols), device=dev), torch.zeros((rows + 8, cols), dtype=dtype, device=dev)
+    _, none32, _ = T.residual_layernorm_train(t0, t1, res, gam, bet, eps, dtype, alpha, p, seed, pre=big_pre[4:4 + rows], y16=big16[4:4 + rows], want32=False)
+    assert none32 is None and torch.equal(big_pre[4:4 + rows], pre) and torch.equal(big16[4:4 + rows], y16) and not big_pre[:4].any() and not big16[-4:].any()
+    # ---- adjoint
+    dy, t_add = _r((rows, cols), 36), _r((rows, cols), 37, 0.5)
+    (y_ref * dy).sum().backward()
+    dg, db = torch.zeros(cols, device=dev), torch.zeros(cols, device=dev)
+    b1, b2 = torch.zeros(cols, device=dev), torch.ones(cols, device=dev)
+    dx, dt16 = T.layernorm_bwd_fused(pre, gam, dy, dg, db, eps, dtype, t_add=t_add, dbias=b1, dbias2=b2, alpha=alpha, p_drop=p, seed=seed)
+    torch.testing.assert_close(dx, rr.grad, atol=2e-5, rtol=1e-4)
+    torch.testing.assert_close(dg, gr.grad, atol=2e-3, rtol=1e-4)
+    torch.testing.assert_close(db, br.grad, atol=2e-3, rtol=1e-4)
+    dt_ref = (rr.grad + t_add) * alpha * keep / (1.0 - p)
+    tol = dict(atol=2e-2, rtol=1e-2) if dtype == BF else dict(atol=2e-3, rtol=2e-3)
+    torch.testing.assert_close(dt16.float(), dt_ref, **tol)
+    torch.testing.assert_close(b1, dt_ref.sum(0), atol=3e-3, rtol=1e-4)
+    torch.testing.assert_close(b2 - 1.0, dt_ref.sum(0), atol=3e-3, rtol=1e-4)
+    # without t_add the dense gradient is the dropout adjoint of d pre itself (= torch's gradient of t)
+    dg2, db2 = torch.zeros(cols, device=dev), torch.zeros(cols, device=dev)
+    dx2, dt2 = T.layernorm_bwd_fused(pre, gam, dy, dg2, db2, eps, dtype, alpha=alpha, p_drop=p, seed=seed)
+    assert torch.equal(dx2, dx)
+    torch.testing.assert_close(dt2.float(), tr.grad, **tol)
+    only_dx, none16 = T.layernorm_bwd_fused(pre, gam, dy, dg2, db2, eps, dtype, want_dt=False)
+    assert none16 is None and torch.equal(only_dx, dx)
+
+
+@pytest.mark.parametrize("dtype", [BF, HF], ids=["bf16", "fp16"])
+def test_rows16_colsum_and_gelu_adjoint(T, dtype):
+    dev = torch.device("cuda")
+    rows, cols = 333, 3072
+    a, z = _r((rows, cols), 41, dtype=dtype), _r((rows, cols), 42, 2.0, dtype=dtype)
+    sums = torch.full((cols,), 2.0, device=dev)
+    T.colsum16(a, sums)
+    torch.testing.assert_close(sums - 2.0, a.float().sum(0), atol=2e-3, rtol=1e-4)
+    wide = _r((70, 2 * 776), 43, dtype=dtype)                                         # strided halves (the merge layer's d cat)
+    for half in (0, 1):
+        v = wide[:, half * 776:(half + 1) * 776]
+        s2 = torch.zeros(776, device=dev)
+        torch.testing.assert_close(T.colsum16(v, s2), v.float().sum(0), atol=1e-3, rtol=1e-4)
+    zr = z.float().requires_grad_(True)
+    (F.gelu(zr) * a.float()).sum().backward()
+    sb = torch.zeros(cols, device=dev)
+    dz = T.gelu_bwd16(a, z, sums=sb)
+    tol = dict(atol=2e-2, rtol=1e-2) if dtype == BF else dict(atol=2e-3, rtol=2e-3)
+    torch.testing.assert_close(dz.float(), zr.grad, **tol)
+    torch.testing.assert_close(sb, zr.grad.sum(0), atol=5e-2 if dtype == BF else 5e-3, rtol=1e-3)
+    assert torch.equal(T.gelu_bwd16(a, z), dz)
