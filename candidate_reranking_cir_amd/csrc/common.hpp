@@ -164,6 +164,25 @@ __device__ __forceinline__ void gelu_erf8(float (&v)[8]) {
     for (int j = 0; j < 4; ++j) { const f32x2 y = x[j] * t[j]; v[2 * j] = y.x; v[2 * j + 1] = y.y; }
 }
 
+// ---- counter-based dropout of the fused training kernels (train_attn.hip, train_fused.hip) ---------------------------------------
+// Element (row, col) of a launch is DROPPED iff its 16 random bits are below round(p * 65536).  One 32-bit hash gives the bits of the
+// two adjacent columns (2j, 2j + 1) of a row: bits = hash32(row_key ^ j), row_key = a Weyl sequence over the rows offset by the seed -
+// so a lane that owns 4 consecutive columns pays two hashes (4 integer multiplies), where the splitmix64 of (seed, flat index) of the
+// stand-alone kernels (train.hip) costs three 64-bit multiplies per element: at 16 score elements per lane and key tile that hash alone
+// was ~10x the tile's MFMA time in the attention kernels.  The forward and backward kernels regenerate the same mask from
+// (seed, row, col); tests/test_train_ops_gpu.py holds the host replica.
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {      // "lowbias32": full avalanche, two multiplies
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+constexpr uint32_t kDropWeyl = 0x9E3779B9u;
+__device__ __forceinline__ uint32_t drop_threshold(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
+__device__ __forceinline__ uint32_t drop_row_key(uint64_t seed, uint64_t row) {
+    return (uint32_t)seed + (uint32_t)(seed >> 32) * 0x85EBCA6Bu + (uint32_t)row * kDropWeyl + (uint32_t)(row >> 32) * 0xC2B2AE35u;
+}
+__device__ __forceinline__ uint32_t drop_bits(uint32_t row_key, uint32_t col) { return hash32(row_key ^ (col >> 1)); }
+__device__ __forceinline__ bool drop_kept(uint32_t bits, uint32_t col, uint32_t thr) { return ((col & 1u) ? (bits >> 16) : (bits & 0xffffu)) >= thr; }
+
 // bijective XCD remap: consecutive "logical" ids land on one XCD (blocks b and b+8 share an XCD)
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int q = nblk >> 3, r = nblk & 7, x = bid & 7;

@@ -295,6 +295,9 @@ __global__ __launch_bounds__(256, 3) void bmm_mfma_kernel(BmmArgs a) {      // t
                 const int m = m0 + wm * 16 * F + mi * 16 + g * 4 + jj;
                 if (m >= a.M) continue;
                 TO* cp = C + (int64_t)m * a.ldc + n;
+                if constexpr (sizeof(TO) == 4) {
+                    if (a.accumulate == 2) { atomicAdd(cp, a.alpha * acc[mi][ni][jj]); continue; }     // split-K batches summing into ONE C
+                }
                 const float v = a.alpha * acc[mi][ni][jj] + (a.accumulate ? static_cast<float>(*cp) : 0.f);
                 *cp = static_cast<TO>(v);
             }
@@ -580,8 +583,10 @@ extern "C" int cir_bmm(const void* A, const void* B, void* C, int M, int N, int 
     if (M <= 0 || N <= 0 || K <= 0 || nb1 <= 0 || nb2 <= 0) return CIR_EINVAL;
     if ((int64_t)nb1 * nb2 > 65535) return CIR_ESHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (accumulate < 0 || accumulate > 2) return CIR_EINVAL;
     if (in_dtype == CIR_F32) {                               // fp32 operands: the plain kernel
         if (out_dtype != CIR_F32) return CIR_EDTYPE;
+        if (accumulate == 2) return CIR_EDTYPE;
         dim3 grid((N + 15) / 16, (M + 15) / 16, nb1 * nb2), block(256);
         hipLaunchKernelGGL((bmm_kernel<float, float>), grid, block, 0, s, reinterpret_cast<const float*>(A), reinterpret_cast<const float*>(B),
                            reinterpret_cast<float*>(C), M, N, K, lda, ldb, ldc, trans_a, trans_b, nb2, sA1, sA2, sB1, sB2, sC1, sC2, alpha, accumulate);
@@ -589,6 +594,7 @@ extern "C" int cir_bmm(const void* A, const void* B, void* C, int M, int N, int 
     }
     if (in_dtype != CIR_BF16 && in_dtype != CIR_F16) return CIR_EDTYPE;
     if (out_dtype != CIR_F32 && out_dtype != in_dtype) return CIR_EDTYPE;
+    if (accumulate == 2 && out_dtype != CIR_F32) return CIR_EDTYPE;
     auto vec_ok = [](const void* p, int64_t ld, int64_t s1, int64_t s2) {
         return (reinterpret_cast<uintptr_t>(p) % 16 == 0 && ld % 8 == 0 && s1 % 8 == 0 && s2 % 8 == 0) ? 1 : 0;
     };

@@ -12,21 +12,13 @@
 //   dK, dV   wave = 32 keys, streams queries:  S   = Q K^T      dPd   = dO V^T           dV^T += dO^T Pd,  dK^T += Q^T dS   (Q, dO tiles in LDS)
 // with P = exp2(S * scale*log2e + mask*log2e - LSE2), Pd = dropout(P), dS = scale * P * (dropout'(dPd) - D), D = rowsum(dO * O).
 // Tensors are head views (group, head, row, 64) given by three element strides each; rows beyond an extent are clamped on load and
-// their probabilities forced to zero.  Dropout element index = ((group * H + head) * Lq + query) * Lk + key.
+// their probabilities forced to zero.  Dropout: element (row = (group * H + head) * Lq + query, col = key) of common.hpp's pair hash.
 #include "common.hpp"
 
 namespace cir {
 
 constexpr float kLog2eT = 1.4426950408889634f;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr_t;
-
-__device__ __forceinline__ float uniform01_t(uint64_t seed, uint64_t idx) {   // = train.hip's uniform01 (splitmix64 of (seed, index))
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
 
 struct TAttnArgs {
     const void* q; int64_t q_sg, q_sh, q_sr;
@@ -157,7 +149,7 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const TAttnArgs a) {
     tr_offsets(lane, voff);
     const float sl = a.scale * kLog2eT;
     const float keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
-    const uint64_t rowbase = (uint64_t)(gh * a.Lq + qrow) * (uint64_t)a.Lk;
+    const uint32_t rkey = drop_row_key(a.seed, (uint64_t)(gh * a.Lq + qrow)), thr = drop_threshold(a.p_drop);
 
     float m_run = -INFINITY, l_run = 0.f;
     f32x16 o[2];
@@ -196,14 +188,15 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const TAttnArgs a) {
         for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
         m_run = m_new;
         float psum = 0.f;
+        uint32_t bits = 0;
         X8 pf[2];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float p = __builtin_amdgcn_exp2f(sv[i] - m_run);
             psum += p;
-            float pd = p;
-            if (a.p_drop > 0.f) pd = uniform01_t(a.seed, rowbase + (uint64_t)(key0 + acc_row(i, hh))) >= a.p_drop ? p * keep : 0.f;
-            pf[i >> 3][i & 7] = static_cast<T>(pd);
+            const uint32_t key = key0 + acc_row(i, hh);
+            if (thr != 0 && (i & 1) == 0) bits = drop_bits(rkey, key);   // keys (2j, 2j + 1) = accumulator rows (i, i + 1)
+            pf[i >> 3][i & 7] = static_cast<T>(drop_kept(bits, key, thr) ? p * keep : 0.f);
         }
         psum += __shfl_xor(psum, 32, 64);
         l_run += psum;
@@ -235,10 +228,9 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const TAttnArgs a) {
 // sums of dS are off by the rounding of P and the (column-summed) query-bias gradients lose a factor 2-3 of accuracy.
 struct Adj { float pd, ds; };
 template <typename T>
-__device__ __forceinline__ Adj adjoint(float s, float dp, float sl, float maskv, float lse, float dsum, bool valid, float scale, float p_drop,
-                                        float keep, uint64_t seed, uint64_t idx) {
+__device__ __forceinline__ Adj adjoint(float s, float dp, float sl, float maskv, float lse, float dsum, bool valid, float scale, float keep,
+                                        bool kept) {
     const float p = valid ? __builtin_amdgcn_exp2f(fmaf(s, sl, maskv) - lse) : 0.f;
-    const bool kept = p_drop <= 0.f || uniform01_t(seed, idx) >= p_drop;
     Adj r;
     r.pd = kept ? static_cast<float>(static_cast<T>(p * keep)) : 0.f;
     const float pf = kept ? r.pd * (1.0f / keep) : p;
@@ -301,7 +293,7 @@ __global__ __launch_bounds__(256) void tattn_bwd_dq_kernel(const TAttnArgs a) {
     tr_offsets(lane, voff);
     const float sl = a.scale * kLog2eT;
     const float keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
-    const uint64_t rowbase = (uint64_t)(gh * a.Lq + qrow) * (uint64_t)a.Lk;
+    const uint32_t rkey = drop_row_key(a.seed, (uint64_t)(gh * a.Lq + qrow)), thr = drop_threshold(a.p_drop);
     const bool qvalid = q0 + r < a.Lq;
 
     f32x16 dq[2];
@@ -325,12 +317,14 @@ __global__ __launch_bounds__(256) void tattn_bwd_dq_kernel(const TAttnArgs a) {
             tile_load<T>(kb, a.k_sr, key0 + 32, a.Lk, lane, kr);
         }
         X8 dsf[2];
+        uint32_t bits = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int key = key0 + acc_row(i, hh);
             float maskv = 0.f;
             if constexpr (MASKED) maskv = fmaxf(mp[min(key, a.Lk - 1)], -2.0e38f) * kLog2eT;
-            const Adj ad = adjoint<T>(s[i], dp[i], sl, maskv, lse, dsum, qvalid && key < a.Lk, a.scale, a.p_drop, keep, a.seed, rowbase + (uint64_t)key);
+            if (thr != 0 && (i & 1) == 0) bits = drop_bits(rkey, key);
+            const Adj ad = adjoint<T>(s[i], dp[i], sl, maskv, lse, dsum, qvalid && key < a.Lk, a.scale, keep, drop_kept(bits, key, thr));
             dsf[i >> 3][i & 7] = static_cast<T>(ad.ds);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -374,6 +368,8 @@ __global__ __launch_bounds__(256) void tattn_bwd_dkv_kernel(const TAttnArgs a) {
     const float keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
     const float* lsep = a.lse + gh * a.Lq;
     const float* dsp = a.dsum + gh * a.Lq;
+    const uint32_t thr = drop_threshold(a.p_drop);
+    const uint32_t rkey0 = drop_row_key(a.seed, (uint64_t)(gh * a.Lq + 4 * hh));    // + (query - 4 hh) * kDropWeyl: the rows of a tile are a Weyl step apart
 
     f32x16 dk[2], dv[2];
 #pragma unroll
@@ -409,8 +405,9 @@ __global__ __launch_bounds__(256) void tattn_bwd_dkv_kernel(const TAttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int qi = q0 + acc_row(i, hh);
-            const uint64_t idx = (uint64_t)(gh * a.Lq + min(qi, a.Lq - 1)) * (uint64_t)a.Lk + (uint64_t)krow;
-            const Adj ad = adjoint<T>(s[i], dp[i], sl, maskv, lse_i[i], ds_i[i], kvalid && qi < a.Lq, a.scale, a.p_drop, keep, a.seed, idx);
+            // (rows past Lq carry p = 0: their mask bit is irrelevant, no clamp)
+            const uint32_t bits = thr != 0 ? drop_bits(rkey0 + (uint32_t)(q0 + (i & 3) + 8 * (i >> 2)) * kDropWeyl, (uint32_t)krow) : 0u;
+            const Adj ad = adjoint<T>(s[i], dp[i], sl, maskv, lse_i[i], ds_i[i], kvalid && qi < a.Lq, a.scale, keep, drop_kept(bits, (uint32_t)krow, thr));
             pdf[i >> 3][i & 7] = static_cast<T>(ad.pd);
             dsf[i >> 3][i & 7] = static_cast<T>(ad.ds);
         }
@@ -434,6 +431,7 @@ static int tattn_check(const TAttnArgs& a, int dtype) {
     for (int64_t s : s16)
         if (s % 8) return CIR_EALIGN;
     if (!cir_aligned16(a.q) || !cir_aligned16(a.k) || !cir_aligned16(a.v) || !cir_aligned16(a.o)) return CIR_EALIGN;
+    if ((int64_t)a.G * a.H * a.Lq > 0xffffffffLL) return CIR_ESHAPE;                 // dropout rows are numbered in 32 bits
     if ((int64_t)a.G * a.H * ((a.Lq + 31) / 32) > 0x7fffffffLL || (int64_t)a.G * a.H * ((a.Lk + 31) / 32) > 0x7fffffffLL) return CIR_ESHAPE;
     return CIR_OK;
 }

@@ -13,14 +13,6 @@
 
 namespace cir {
 
-__device__ __forceinline__ float uniform01_f(uint64_t seed, uint64_t idx) {   // = train.hip's uniform01 (splitmix64 of (seed, index))
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
-
 constexpr int kRowVec = 4;       // float4 groups per lane: cols <= 1024, cols % 4 == 0
 
 template <typename T>
@@ -40,6 +32,7 @@ __global__ __launch_bounds__(256) void res_ln_train_kernel(const float* t0, cons
     if (row >= rows) return;
     const float keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
     const int64_t base = row * cols;
+    const uint32_t rkey = drop_row_key(seed, (uint64_t)row), thr = drop_threshold(p_drop);
     float v[kRowVec][4];
     float s = 0.f;
 #pragma unroll
@@ -53,9 +46,10 @@ __global__ __launch_bounds__(256) void res_ln_train_kernel(const float* t0, cons
             }
             const float4 r = *reinterpret_cast<const float4*>(res + base + c);
             const float tv[4] = {a.x, a.y, a.z, a.w}, rv[4] = {r.x, r.y, r.z, r.w};
+            const uint32_t b01 = thr ? drop_bits(rkey, c) : 0u, b23 = thr ? drop_bits(rkey, c + 2) : 0u;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const bool kept = p_drop <= 0.f || uniform01_f(seed, (uint64_t)(base + c + e)) >= p_drop;
+                const bool kept = drop_kept(e < 2 ? b01 : b23, (uint32_t)e, thr);
                 v[i][e] = (kept ? tv[e] * alpha * keep : 0.f) + rv[e];
                 s += v[i][e];
             }
@@ -98,6 +92,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* x, const
                                                            float alpha, float p_drop, uint64_t seed) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const uint32_t thr = drop_threshold(p_drop);
     float pg[kRowVec][4], pb[kRowVec][4], pd[kRowVec][4];
 #pragma unroll
     for (int i = 0; i < kRowVec; ++i)
@@ -114,6 +109,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* x, const
         const int64_t row = (int64_t)blockIdx.x * 32 + it * 4 + wave;
         if (row >= rows) break;
         const int64_t base = row * cols;
+        const uint32_t rkey = drop_row_key(seed, (uint64_t)row);
         float xv[kRowVec][4], dv[kRowVec][4];
         float s = 0.f;
 #pragma unroll
@@ -164,9 +160,10 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* x, const
                         const float4 t = *reinterpret_cast<const float4*>(t_add + base + c);
                         r[0] += t.x; r[1] += t.y; r[2] += t.z; r[3] += t.w;
                     }
+                    const uint32_t b01 = thr ? drop_bits(rkey, c) : 0u, b23 = thr ? drop_bits(rkey, c + 2) : 0u;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const bool kept = p_drop <= 0.f || uniform01_f(seed, (uint64_t)(base + c + e)) >= p_drop;
+                        const bool kept = drop_kept(e < 2 ? b01 : b23, (uint32_t)e, thr);
                         r[e] = kept ? r[e] * alpha * keep : 0.f;
                         pd[i][e] += r[e];
                     }

@@ -16,6 +16,12 @@ CIR_BF16, CIR_F16, CIR_F32 = 0, 1, 2
 TUNE_GEMM_TILE, TUNE_GEMM_GROUP_W, TUNE_ATTN_SHARED_MAX = 0, 1, 2   # cir_set_tuning knobs (tests / A-B only)
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
+class WgradDesc(ctypes.Structure):
+    """cir_wgrad_desc of include/cirrank.h (one problem of cir_wgrad_grouped)."""
+    _fields_ = [("dy", c_void_p), ("ldy", c_int64), ("x", c_void_p), ("ldx", c_int64), ("dw", c_void_p), ("ldw", c_int64), ("rows", c_int64),
+                ("N", c_int), ("K", c_int), ("splits", c_int)]
+
+
 # name -> argtypes; mirrors include/cirrank.h declaration by declaration
 SIGNATURES = {
     "cir_version": (c_int, []),
@@ -60,6 +66,8 @@ SIGNATURES = {
     "cir_layernorm_bwd_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                         c_int, c_float, c_float, c_float, c_uint64, c_int, c_void_p]),
     "cir_rows16_colsum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "cir_wgrad_grouped": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "cir_wgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "cir_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "cir_eltwise": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_uint64, c_void_p]),
     "cir_colsum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),

@@ -157,7 +157,8 @@ class _Lin:
 
 
     def bwd16(self, x16: torch.Tensor, dy16: torch.Tensor, need_dx: bool = True, dx_dtype: torch.dtype = torch.float32,
-              residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, bias: bool = False) -> Optional[torch.Tensor]:
+              residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, bias: bool = False,
+              queue: Optional[list] = None) -> Optional[torch.Tensor]:
         """dy16 (M, N) ALREADY the 16-bit operand (any row stride: written by the fused row kernels, the attention adjoint or the dgrad
         product before): accumulates dW - and db when `bias` (otherwise the producer of dy16 summed it) -; returns
         dx = dy . W (+ residual: the fp32 gradient arriving over the skip connection, added in the GEMM epilogue) in `dx_dtype`."""
@@ -165,12 +166,19 @@ class _Lin:
         n = self.w16.shape[0]
         if bias and self.db is not None:
             T.colsum16(dy16, self.db)
-        nb = _row_split(m, n, k)
-        if nb == 1:
-            T.bmm(dy16.unsqueeze(0), x16.unsqueeze(0), True, False, out=self.dw.unsqueeze(0), accumulate=True)
+        # dW (N, K) += dy^T x with both operands read as stored, the rows split over workgroups so that the 36-tile product of a
+        # 768 x 768 weight fills the chip; every workgroup adds its partial tile straight into dW (atomics: no partial tensor)
+        if n % 128 == 0 and k % 128 == 0:
+            # LDS-DMA / transposing-read kernel (train_wgrad.hip).  `queue` (a list): the product is deferred and launched together with
+            # the layer's other weight gradients - ~940 output tiles fill the chip without splitting any tile's rows over workgroups
+            if queue is not None:
+                queue.append((dy16, x16, self.dw))
+            else:
+                T.wgrad(dy16, x16, self.dw)
         else:
-            part = T.bmm(dy16.unflatten(0, (nb, m // nb)), x16.unflatten(0, (nb, m // nb)), True, False, out_dtype=torch.float32)
-            T.colsum(part.view(nb, n * k), self.dw.view(-1))
+            nb = _row_split(m, n, k)
+            T.bmm(dy16.unflatten(0, (nb, m // nb)), x16.unflatten(0, (nb, m // nb)), True, False, out=self.dw.unsqueeze(0).expand(nb, n, k),
+                  accumulate="atomic")
         if not need_dx:
             return None
         return ops.gemm(dy16, self.w16t, None, residual=residual, out_dtype=dx_dtype, out=out)
@@ -427,10 +435,11 @@ class NlvrTrainer:
         for i in reversed(range(len(self.layers))):
             ly, s = self.layers[i], sv["layers"][i]
             w1, w2 = ly["w1"], ly["w2"]
+            wq: list = []                                                           # this layer's weight-gradient products: ONE launch at its end
             dpre3, do16 = ly["ln3"].bwd_res(s["pre3"], dh, dt, dbias=w2.db, p_drop=ph, seed=self._site(i, 0, 5))
-            df16 = w2.bwd16(s["f16"], do16, dx_dtype=dt)
+            df16 = w2.bwd16(s["f16"], do16, dx_dtype=dt, queue=wq)
             dz16 = T.gelu_bwd16(df16, s["z16"], sums=w1.db)
-            dx = w1.bwd16(s["x16"], dz16, residual=dpre3)                           # (2R, D) fp32: FFN branch + skip
+            dx = w1.bwd16(s["x16"], dz16, residual=dpre3, queue=wq)                           # (2R, D) fp32: FFN branch + skip
             # the two LayerNorms over m + a_b: d m = dropout'(d pre2_0 + d pre2_1) comes out of the second one's kernel
             merge = ly["merge"]
             dpre2 = [ly["ln20"].bwd_res(s["pre2"][:r], dx[:r], dt, want_dt=False)[0]]
@@ -443,26 +452,27 @@ class NlvrTrainer:
             if merge is None:
                 dd16 = [dm16, dm16]
             else:
-                dcat16 = merge.bwd16(s["cat16"], dm16, dx_dtype=dt)                 # (R, 2D)
+                dcat16 = merge.bwd16(s["cat16"], dm16, dx_dtype=dt, queue=wq)                 # (R, 2D)
                 dd16 = [dcat16[:, :d], dcat16[:, d:]]
             dh_in = torch.empty((2 * r, d), dtype=torch.float32, device=dev)
             for b in (0, 1):
-                dc16 = ly[f"d{b}"].bwd16(s["c"][b], dd16[b], dx_dtype=dt, bias=merge is not None)
+                dc16 = ly[f"d{b}"].bwd16(s["c"][b], dd16[b], dx_dtype=dt, bias=merge is not None, queue=wq)
                 cq, ckv = s["cq"][b], s["ckv"][b]
                 dcq16 = torch.empty((r, d), dtype=dt, device=dev)
                 dckv16 = torch.empty((b_n * n, 2 * d), dtype=dt, device=dev)
                 self._attn_bwd(dc16, self._heads(cq, b_n, b_n * l), self._heads(ckv, b_n, n, 0, 2), self._heads(ckv, b_n, n, 1, 2), s["ca"][b],
                                self._heads(dcq16, b_n, b_n * l), self._heads(dckv16, b_n, n, 0, 2), self._heads(dckv16, b_n, n, 1, 2))
-                ly[f"ckv{b}"].bwd16(sv["cand16"], dckv16, need_dx=False, bias=True)  # image tokens are inputs: no gradient beyond the weights
-                da = ly[f"cq{b}"].bwd16(s["a16"][b], dcq16, residual=dpre2[b], bias=True)
+                ly[f"ckv{b}"].bwd16(sv["cand16"], dckv16, need_dx=False, bias=True, queue=wq)  # image tokens are inputs: no gradient beyond the weights
+                da = ly[f"cq{b}"].bwd16(s["a16"][b], dcq16, residual=dpre2[b], bias=True, queue=wq)
                 o = ly[f"o{b}"]
                 dpre1, dt16 = ly[f"ln1{b}"].bwd_res(s["pre1"][b], da, dt, dbias=o.db, p_drop=ph, seed=self._site(i, b, 2))
-                dctx16 = o.bwd16(s["ctx"][b], dt16, dx_dtype=dt)
+                dctx16 = o.bwd16(s["ctx"][b], dt16, dx_dtype=dt, queue=wq)
                 qkv = s["qkv"][b]
                 dqkv16 = torch.empty((r, 3 * d), dtype=dt, device=dev)
                 self._attn_bwd(dctx16, *(self._heads(qkv, t_n, l, j, 3) for j in range(3)), s["sa"][b],
                                *(self._heads(dqkv16, t_n, l, j, 3) for j in range(3)))
-                ly[f"qkv{b}"].bwd16(s["h16"][b], dqkv16, residual=dpre1, out=dh_in[b * r:(b + 1) * r], bias=True)
+                ly[f"qkv{b}"].bwd16(s["h16"][b], dqkv16, residual=dpre1, out=dh_in[b * r:(b + 1) * r], bias=True, queue=wq)
+            T.wgrad_grouped(wq)
             dh = dh_in
         # branch 1 entered through BertEmbeddings; branch 0 is z_t (frozen stage I)
         de = dh[r:] if ph <= 0 else T.eltwise(dh[r:], T.MODE_DROPOUT, p_drop=ph, seed=self._site(9000))

@@ -2,6 +2,7 @@
 SURVEY section 8(f)-4).  Same rules as `ops`: CUDA tensors only, no fallback, work on torch's current stream."""
 from __future__ import annotations
 
+import ctypes
 from typing import Optional
 
 import torch
@@ -28,9 +29,10 @@ def transpose16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Te
 
 
 def bmm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False, out: Optional[torch.Tensor] = None,
-        out_dtype: Optional[torch.dtype] = None, alpha: float = 1.0, accumulate: bool = False) -> torch.Tensor:
+        out_dtype: Optional[torch.dtype] = None, alpha: float = 1.0, accumulate=False) -> torch.Tensor:
     """out[z] = alpha * op(a[z]) @ op(b[z]) (+ out[z]); a, b, out are (B, ., .) or (B1, B2, ., .) views with unit last stride and
-    any row / batch strides (0 = broadcast over that batch level).  16-bit operands run on the MFMA kernel."""
+    any row / batch strides (0 = broadcast over that batch level).  16-bit operands run on the MFMA kernel.  accumulate: False / True
+    (out += per batch item) / "atomic" (fp32 out, batch items may share an out through stride-0 views: split-K sums)."""
     _need_cuda(a, b, out)
     assert a.dim() == b.dim() and a.dim() in (3, 4) and a.shape[:-2] == b.shape[:-2] and a.stride(-1) == 1 and b.stride(-1) == 1 and a.dtype == b.dtype
     was3 = a.dim() == 3
@@ -53,8 +55,41 @@ def bmm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool =
         z1 = min(nb1, z0 + step)
         _lib.check(lib.cir_bmm(a[z0:z1].data_ptr(), b[z0:z1].data_ptr(), out4[z0:z1].data_ptr(), m, n, k, a.stride(2), b.stride(2), out4.stride(2),
                                int(trans_a), int(trans_b), z1 - z0, nb2, a.stride(0), a.stride(1), b.stride(0), b.stride(1), out4.stride(0),
-                               out4.stride(1), float(alpha), int(accumulate), _DT[a.dtype], _DT[out_dtype], _stream()), "cir_bmm")
+                               out4.stride(1), float(alpha), 2 if accumulate == "atomic" else int(bool(accumulate)), _DT[a.dtype], _DT[out_dtype], _stream()), "cir_bmm")
     return out4.squeeze(1) if was3 else out4
+
+
+def wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, splits: int = 0) -> torch.Tensor:
+    """dw (N, K) fp32 += dy^T x (cir_wgrad): dy (rows, N), x (rows, K) 16-bit with unit last stride, read as stored; N, K multiples of 128."""
+    _need_cuda(dy, x, dw)
+    rows, n = dy.shape
+    k = x.shape[1]
+    assert x.shape[0] == rows and dy.dtype == x.dtype and dy.stride(1) == 1 and x.stride(1) == 1
+    assert dw.dtype == torch.float32 and dw.shape == (n, k) and dw.stride(1) == 1
+    _lib.check(_lib.load().cir_wgrad(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0), rows, n, k, int(splits),
+                                     _DT[dy.dtype], _stream()), "cir_wgrad")
+    return dw
+
+
+WGRAD_GROUP_MAX = 16
+
+
+def wgrad_grouped(problems) -> None:
+    """[(dy (rows, N), x (rows, K), dw (N, K) fp32), ...]: dw_i += dy_i^T x_i, up to 16 problems per launch (cir_wgrad_grouped) - the
+    weight gradients of one encoder layer fill the chip together without row splits."""
+    lib = _lib.load()
+    for g0 in range(0, len(problems), WGRAD_GROUP_MAX):
+        grp = problems[g0:g0 + WGRAD_GROUP_MAX]
+        arr = (_lib.WgradDesc * len(grp))()
+        for d, (dy, x, dw) in zip(arr, grp):
+            _need_cuda(dy, x, dw)
+            rows, n = dy.shape
+            k = x.shape[1]
+            assert x.shape[0] == rows and dy.dtype == x.dtype == grp[0][0].dtype and dy.stride(1) == 1 and x.stride(1) == 1
+            assert dw.dtype == torch.float32 and dw.shape == (n, k) and dw.stride(1) == 1
+            d.dy, d.ldy, d.x, d.ldx, d.dw, d.ldw, d.rows, d.N, d.K, d.splits = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), \
+                dw.stride(0), rows, n, k, 0
+        _lib.check(lib.cir_wgrad_grouped(ctypes.addressof(arr), len(grp), _DT[grp[0][0].dtype], _stream()), "cir_wgrad_grouped")
 
 
 def softmax_dropout(s: torch.Tensor, mask: Optional[torch.Tensor], rows_per_mask: int, scale: float, p_drop: float, seed: int, dtype: torch.dtype,

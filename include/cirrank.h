@@ -198,7 +198,8 @@ int cir_l2_normalize(const float* x, float* y, int64_t rows, int cols, void* str
  * besides the operators above (blip_stage2.py:65-99 driven by stage2_train.py:202-216; dropout nlvr_encoder.py:86-90, 207,
  * 250-264, 397).  The dense layers' forward and dgrad run on cir_gemm_bias_act (dgrad over a transposed weight copy, cir_transpose16),
  * the weight gradients on cir_bmm.
- * Dropout is counter-based: element i of a launch is kept iff hash(seed, i) >= p, scaled by 1 / (1 - p); the backward
+ * Dropout is counter-based: element i of a launch is kept iff hash(seed, i) >= p, scaled by 1 / (1 - p) (stand-alone operators: splitmix64 of
+ * (seed, flat index); fused operators: the pair hash described at cir_residual_layernorm_train); the backward
  * operators regenerate the same mask from the same (seed, p) - no mask tensor exists.  None of these is on the inference path.
  */
 /* dst[b][c][r] = src[b][r][c], 16-bit elements (dtype CIR_BF16 / CIR_F16 names the payload only). */
@@ -209,10 +210,25 @@ int cir_transpose16(const void* src, void* dst, int rows, int cols, int64_t ld_s
  * level and operand (element units; 0 broadcasts), nb1 * nb2 <= 65535.  in_dtype CIR_BF16 / CIR_F16: MFMA kernel (64 x 64 tiles,
  * edges predicated, 16-byte loads when base / ld / strides allow, 2-byte loads otherwise), out_dtype = in_dtype or CIR_F32;
  * in_dtype CIR_F32: plain kernel, fp32 out.  Used for the un-fused attention of the training pass (Q K^T, P V and their four
- * adjoints per (candidate or triplet, head)) and, with trans_a = 1 and a batch over row chunks, for the weight gradients. */
+ * adjoints per (candidate or triplet, head)) and, with trans_a = 1 and a batch over row chunks, for the weight gradients.
+ * accumulate: 0 C = ..., 1 C += ... (read-modify-write: batch items must own their C), 2 (ABI v10; MFMA kernel, fp32 C) atomic C += ... -
+ * batch items may share one C (stride 0): the row chunks of a weight gradient sum straight into dW, in no fixed order. */
 int cir_bmm(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int trans_a, int trans_b,
             int nb1, int nb2, int64_t sA1, int64_t sA2, int64_t sB1, int64_t sB2, int64_t sC1, int64_t sC2, float alpha, int accumulate,
             int in_dtype, int out_dtype, void* stream);
+/* Weight gradient of a dense layer (ABI v10; train_wgrad.hip): dw (N, K) fp32 (row stride ldw) += dy^T x, dy (rows, N) and x (rows, K) 16-bit
+ * row-major (strides ldy, ldx; multiples of 8) read AS STORED - LDS-DMA staging, transposing LDS reads, 128 x 128 output tiles, the rows split
+ * over `splits` workgroups per tile (0: chosen from the shape) that add their partial tiles into dw atomically (no fixed summation order).
+ * N % 128 == 0 and K % 128 == 0 (CIR_ESHAPE otherwise: use cir_bmm with trans_a); any row count (a tail below 64 rows runs on cir_bmm's kernel).
+ * Adjoint of nn.Linear's weight (nlvr_encoder.py:150-168, 250-264, 383-409 under stage2_train.py:216's backward). */
+int cir_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, float* dw, int64_t ldw, int64_t rows, int N, int K, int splits, int in_dtype,
+              void* stream);
+/* Up to 16 weight gradients in ONE launch: dw_i += dy_i^T x_i.  The 13 weight gradients of one two-branch BertLayer together have ~940 output
+ * tiles - enough to fill the chip with every tile's row sum formed by one workgroup (plain adds, no atomics; a 768 x 768 weight alone has 36
+ * tiles and needs an 8 .. 16-way row split whose atomic traffic costs as much as the product).  Units are balanced by splitting the longer row
+ * counts (the FFN's stacked 2R rows) to the shortest one's length.  Same shape rules as cir_wgrad; splits 0 = automatic. */
+typedef struct { const void* dy; int64_t ldy; const void* x; int64_t ldx; float* dw; int64_t ldw; int64_t rows; int N, K, splits; } cir_wgrad_desc;
+int cir_wgrad_grouped(const cir_wgrad_desc* problems, int count, int in_dtype, void* stream);
 /* P = softmax(S * scale + mask) per row (S fp32 (rows, cols); mask fp32 (cols) shared by each group of rows_per_mask rows, or
  * NULL), Pd = dropout(P, p_drop, seed); both 16-bit (dtype).  nlvr_encoder.py:183-207. */
 int cir_softmax_dropout(const float* S, int64_t ld_s, const float* mask, int64_t rows_per_mask, int64_t ld_mask, void* P, void* Pd, int64_t ld_p,
@@ -223,8 +239,8 @@ int cir_softmax_dropout_bwd(const void* P, int64_t ld_p, const float* dPd, int64
 /* FUSED attention of the training pass (round 4): out = dropout(softmax(q k^T * scale + mask)) v per (group, head), head dimension 64, with
  * the log2-domain log-sum-exp of every row written to lse (G, H, Lq) - and its recomputing backward: dq / dk / dv (grad_dtype: CIR_F32, or the operand type - ABI v10 - so that the
  * projection's dgrad / wgrad products read them as they are) from q, k, v,
- * out, d_out and lse; the probabilities are recomputed tile by tile and the dropout mask regenerated from its counter (element index
- * ((g * H + h) * Lq + query) * Lk + key), so no score / probability tensor exists in memory.  Tensors are head views: element
+ * out, d_out and lse; the probabilities are recomputed tile by tile and the dropout mask regenerated from its counter (the pair hash of the
+ * fused kernels, see below: row = (g * H + h) * Lq + query, col = key), so no score / probability tensor exists in memory.  Tensors are head views: element
  * (g, h, row, d) at base + g * x_sg + h * x_sh + row * x_sr + d; out and d_out share one layout; mask fp32 (G, Lk) additive or NULL;
  * dsum_scratch fp32 (G * H * Lq) receives rowsum(d_out * out) - with out taken from its optional fp32 twin out32 (written by the
  * forward, same layout): it then equals sum_j Pd_ij dPd_ij term for term and the row sums of dS vanish.  Replaces, for BertSelfAttention.forward in train() mode
@@ -247,7 +263,12 @@ int cir_layernorm_bwd(const float* x, const float* gamma, const float* dy, float
  * (nlvr_encoder.py:248-264, 399-409: dense -> dropout -> + residual -> LayerNorm, incl. the averaged two-branch merge :257-260):
  *   pre = dropout(alpha * (t0 + t1), p_drop, seed) + residual;  y = LayerNorm(pre; gamma, beta, eps)
  * t0 / t1 (t1 may be NULL) / residual fp32 (rows, cols) contiguous; pre (fp32, kept for the backward), y32 (fp32 or NULL) and y16 (16-bit in
- * dtype16, or NULL) are written.  cols % 4 == 0, cols <= 1024.  Dropout element index = row * cols + column. */
+ * dtype16, or NULL) are written.  cols % 4 == 0, cols <= 1024.
+ * Dropout of the FUSED kernels (this one, its adjoint, cir_attention_train_*; ABI v10): element (row, col) is dropped iff its 16 random bits
+ * are below round(p * 65536); the bits of the column pair (2j, 2j + 1) are the low / high half of
+ *   hash32((uint32)seed + (uint32)(seed >> 32) * 0x85EBCA6B + (uint32)row * 0x9E3779B9 + (uint32)(row >> 32) * 0xC2B2AE35  ^  j),
+ * hash32(x): x ^= x >> 16; x *= 0x7feb352d; x ^= x >> 15; x *= 0x846ca68b; x ^= x >> 16 - two 32-bit multiplies per pair instead of the three
+ * 64-bit ones per element of the stand-alone kernels' splitmix64 (which made the hash ~10x the MFMA time of an attention tile). */
 int cir_residual_layernorm_train(const float* t0, const float* t1, const float* residual, const float* gamma, const float* beta, float* pre,
                                  float* y32, void* y16, int64_t rows, int cols, float eps, float alpha, float p_drop, uint64_t seed, int dtype16,
                                  void* stream);

@@ -76,6 +76,60 @@ def test_bmm_split_k_weight_gradient(T):
     dw = torch.zeros((n * k,), device="cuda")
     T.colsum(part.view(nb, n * k), dw)
     torch.testing.assert_close(dw.view(n, k), dy.float().t() @ x.float(), atol=2e-3, rtol=1e-4)
+    # round 4: the chunks add their partial sums straight into ONE dW (stride-0 batch view, atomic accumulate), strided operands
+    wide = _r((rows, n + k + 8), 11, dtype=HF)
+    dy2, x2 = wide[:, :n], wide[:, n:n + k]
+    dw2 = torch.full((n, k), 3.0, device="cuda")
+    T.bmm(dy2.unflatten(0, (nb, rows // nb)), x2.unflatten(0, (nb, rows // nb)), True, False, out=dw2.unsqueeze(0).expand(nb, n, k), accumulate="atomic")
+    torch.testing.assert_close(dw2 - 3.0, dy2.float().t() @ x2.float(), atol=2e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [BF, HF], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("rows,n,k,splits", [(64, 128, 128, 0), (336, 256, 384, 0), (9232, 1536, 768, 0), (1024, 768, 128, 3), (40, 128, 256, 0),
+                                              (4096, 128, 128, 64)])
+def test_wgrad_kernel(T, dtype, rows, n, k, splits):
+    """cir_wgrad (LDS-DMA staging, transposing LDS reads, atomic split accumulation) against fp32 torch: dW += dy^T x with both operands
+    read as stored - row counts with and without a tail below 64 (577-token candidates: 9232 = 144 * 64 + 16), strided operand views
+    (column slices of wider buffers), explicit and automatic splits, accumulation into a non-zero dW."""
+    wide_y, wide_x = _r((rows, n + 128), 51, dtype=dtype), _r((rows, k + 256), 52, dtype=dtype)
+    dy, x = wide_y[:, 128:], wide_x[:, 128:128 + k]
+    dw = torch.full((n, k), 0.25, device="cuda")
+    T.wgrad(dy, x, dw, splits=splits)
+    ref = dy.float().t() @ x.float()
+    err = ((dw - 0.25) - ref).abs().max().item()
+    assert err < 2e-3 * max(1.0, ref.abs().max().item()), err
+    # integer-valued operands: every partial sum is exact in fp32, so the result does not depend on the (unordered) atomic additions
+    gi = torch.Generator().manual_seed(rows + n)
+    yi = torch.randint(-3, 4, (rows, n), generator=gi).to(dtype).cuda()
+    xi = torch.randint(-3, 4, (rows, k), generator=gi).to(dtype).cuda()
+    dwi = torch.zeros((n, k), device="cuda")
+    T.wgrad(yi, xi, dwi, splits=splits)
+    assert torch.equal(dwi, yi.float().t() @ xi.float())
+    with pytest.raises(RuntimeError):
+        T.wgrad(yi[:, :64], xi, torch.zeros((64, k), device="cuda"))              # N % 128
+
+
+@pytest.mark.parametrize("dtype", [BF, HF], ids=["bf16", "fp16"])
+def test_wgrad_grouped_layer_shapes(T, dtype):
+    """cir_wgrad_grouped on a scaled-down BertLayer's 13 weight gradients (+ 5 more: two launches): unequal row counts (the FFN's stacked rows
+    are split to the attention projections' length, a 9232-like count with a tail below 64), shared dy between two problems, exact
+    integer-valued operands (no dependence on the order of any atomic addition), accumulation into non-zero dW."""
+    r, d = 448, 128
+    gi = torch.Generator().manual_seed(7)
+    mk = lambda rows, cols: torch.randint(-3, 4, (rows, cols), generator=gi).to(dtype).cuda()
+    shapes = [(2 * r, d, 4 * d), (2 * r, 4 * d, d), (r, 3 * d, d), (r, 3 * d, d), (r, d, d), (r, d, d), (r, d, d), (r, d, d), (592, 2 * d, d), (592, 2 * d, d),
+              (r, d, 2 * d), (r, d, d), (r, d, d), (64, 128, 128), (40, 128, 128), (r, 2 * d, 3 * d), (r, d, d), (1024, 256, 128)]
+    probs, refs = [], []
+    shared = mk(r, d)
+    for i, (rows, n, k) in enumerate(shapes):
+        dy = shared if (rows, n) == (r, d) and i in (11, 12) else mk(rows, n)
+        x = mk(rows, k)
+        dw = torch.full((n, k), float(i), device="cuda")
+        probs.append((dy, x, dw))
+        refs.append(dy.float().t() @ x.float() + float(i))
+    T.wgrad_grouped(probs)
+    for (dy, x, dw), ref in zip(probs, refs):
+        assert torch.equal(dw, ref), (dy.shape, x.shape)
 
 
 @pytest.mark.parametrize("cols", [197, 900], ids=["row-in-registers", "long-row-loops"])
@@ -175,16 +229,28 @@ def test_colsum_embed_adamw(T):
 
 
 # ------------------------------------------------------------------------------------------------ fused training attention (round 4)
-def _keep_mask(seed: int, g: int, h: int, lq: int, lk: int, p: float) -> torch.Tensor:
-    """The dropout mask of cir_attention_train_fwd / _bwd regenerated on the host: splitmix64 of (seed, ((g*H+h)*Lq+q)*Lk+key) >= p."""
-    idx = np.arange(g * h * lq * lk, dtype=np.uint64)
+def _pair_keep(seed: int, rows: int, cols: int, p: float) -> torch.Tensor:
+    """The dropout mask of the FUSED training kernels regenerated on the host (include/cirrank.h, cir_residual_layernorm_train): element
+    (row, col) is kept iff the 16 bits of its column pair's hash32(row_key ^ (col >> 1)) - low half for even, high half for odd col - are
+    >= round(p * 65536)."""
+    m32 = np.uint64(0xFFFFFFFF)
+    row = np.arange(rows, dtype=np.uint64)
     with np.errstate(over="ignore"):
-        z = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (idx + np.uint64(1))
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
-    u = (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
-    return torch.from_numpy((u >= np.float32(p)).reshape(g, h, lq, lk))
+        rk = (np.uint64(seed & 0xFFFFFFFF) + np.uint64(seed >> 32) * np.uint64(0x85EBCA6B) + (row & m32) * np.uint64(0x9E3779B9)
+              + (row >> np.uint64(32)) * np.uint64(0xC2B2AE35)) & m32
+        x = rk[:, None] ^ (np.arange(cols, dtype=np.uint64)[None, :] >> np.uint64(1))
+        x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & m32
+        x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & m32
+        x ^= x >> np.uint64(16)
+    odd = (np.arange(cols) & 1).astype(bool)[None, :]
+    u16 = np.where(odd, x >> np.uint64(16), x & np.uint64(0xFFFF))
+    thr = int(np.float32(p) * np.float32(65536.0) + np.float32(0.5))
+    return torch.from_numpy(u16 >= np.uint64(thr))
+
+
+def _keep_mask(seed: int, g: int, h: int, lq: int, lk: int, p: float) -> torch.Tensor:
+    """cir_attention_train_fwd / _bwd: row = (g * H + h) * Lq + query, col = key."""
+    return _pair_keep(seed, g * h * lq, lk, p).view(g, h, lq, lk)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
@@ -273,10 +339,6 @@ def test_fused_training_attention_16bit_gradients(T):
 
 
 # ------------------------------------------------------------------------------------------------ fused row passes (round 4, train_fused.hip)
-def _keep_flat(seed: int, n: int, p: float) -> torch.Tensor:
-    return _keep_mask(seed, 1, 1, 1, n, p).view(-1)
-
-
 @pytest.mark.parametrize("dtype", [BF, HF], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("rows,cols,two,p", [(203, 768, False, 0.1), (64, 1024, True, 0.1), (7, 128, True, 0.0), (130, 132, False, 0.25)])
 def test_residual_layernorm_train_and_adjoint(T, dtype, rows, cols, two, p):
@@ -288,7 +350,7 @@ def test_residual_layernorm_train_and_adjoint(T, dtype, rows, cols, two, p):
     gam, bet = _r((cols,), 34) * 0.1 + 1.0, _r((cols,), 35)
     alpha, seed, eps = (0.5 if two else 1.0), 4242 + rows, 1e-12
     pre, y32, y16 = T.residual_layernorm_train(t0, t1, res, gam, bet, eps, dtype, alpha, p, seed)
-    keep = _keep_flat(seed, rows * cols, p).view(rows, cols).to(dev) if p > 0 else torch.ones((rows, cols), dtype=torch.bool, device=dev)
+    keep = _pair_keep(seed, rows, cols, p).to(dev) if p > 0 else torch.ones((rows, cols), dtype=torch.bool, device=dev)
     tr = (t0 + t1 if two else t0.clone()).requires_grad_(True)
     rr, gr, br = res.clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
     pre_ref = tr * alpha * keep / (1.0 - p) + rr

@@ -21,6 +21,22 @@ for rows, n, k in ((8192, 768, 768), (8192, 3072, 768), (8192, 768, 3072), (9232
         if rows % nb: continue
         us = timeit(lambda: T.bmm(dy.view(nb, rows // nb, n), x.view(nb, rows // nb, k), True, False, out_dtype=torch.float32))
         print(f"wgrad rows {rows} N {n} K {k} nb {nb:2d}: {us:8.1f} us  {2 * rows * n * k / us / 1e6:7.1f} TFLOP/s")
+# round 4: cir_wgrad (train_wgrad.hip) on the training step's weight-gradient shapes, over the split count
+for rows, n, k in ((8192, 768, 768), (8192, 2304, 768), (9232, 1536, 768), (8192, 768, 1536), (16384, 3072, 768), (16384, 768, 3072)):
+    dy = torch.randn(rows, n, device="cuda", dtype=dt); x = torch.randn(rows, k, device="cuda", dtype=dt)
+    dw = torch.zeros(n, k, device="cuda")
+    for sp in (0, 2, 4, 8, 12, 16, 24, 32):
+        us = timeit(lambda: T.wgrad(dy, x, dw, splits=sp))
+        print(f"cir_wgrad rows {rows} N {n} K {k} splits {sp:2d}: {us:8.1f} us  {2 * rows * n * k / us / 1e6:7.1f} TFLOP/s")
+# one BertLayer's 13 weight gradients of the training step (R = 8192 rows per branch, 16 x 577 candidate rows) in ONE grouped launch
+R, D = 8192, 768
+layer = [(2 * R, D, 4 * D), (2 * R, 4 * D, D)] + [(R, 3 * D, D)] * 2 + [(R, D, D)] * 6 + [(9232, 2 * D, D)] * 2 + [(R, D, 2 * D)]
+probs = [(torch.randn(rows, n, device="cuda", dtype=dt), torch.randn(rows, k, device="cuda", dtype=dt), torch.zeros(n, k, device="cuda")) for rows, n, k in layer]
+fl = sum(2 * rows * n * k for rows, n, k in layer)
+us = timeit(lambda: T.wgrad_grouped(probs))
+print(f"cir_wgrad_grouped, one layer (13 problems, {fl / 1e9:.0f} GFLOP): {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s")
+us = timeit(lambda: [T.wgrad(*p) for p in probs])
+print(f"the same 13 as single launches:                   {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s")
 b, h, l, n_tok, d = 16, 12, 32, 577, 768
 q = torch.randn(b * b * l, d, device="cuda", dtype=dt); kk = torch.randn(b * n_tok, d, device="cuda", dtype=dt)
 heads = lambda x, g, r: x.view(g, r, h, 64).permute(0, 2, 1, 3)
