@@ -418,10 +418,12 @@ def train_mode(args, m2, m1, dev, dt):
     gt = torch.arange(b, device=dev)
     sync = torch.cuda.synchronize
     legs = {"vit": 0.0, "z_t": 0.0, "fusion_forward": 0.0, "backward": 0.0, "adamw": 0.0}
+    host = dict(legs)
 
     def step(timed_legs=False):
         def mark(name, t0):
             if timed_legs:
+                host[name] += time.perf_counter() - t0                 # the Python calls returned: launches enqueued
                 sync(); legs[name] += time.perf_counter() - t0
             return time.perf_counter()
         t = time.perf_counter()
@@ -459,11 +461,11 @@ def train_mode(args, m2, m1, dev, dt):
         "ms_per_step": round(dt_s * 1e3, 2), "higher_is_better": True, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"batch {b} (B x B = {b * b} triplets), {l} caption tokens, {n_tok} image tokens ({args.image_size} px), ViT frozen, "
                                f"dropout 0.1, AdamW; fp32 residual stream"},
-        "legs_ms": {k: round(v * 1e3, 2) for k, v in legs.items()}, "loss": round(float(loss.detach()), 4),
+        "legs_ms": {k: round(v * 1e3, 2) for k, v in legs.items()}, "legs_host_enqueue_ms": {k: round(v * 1e3, 2) for k, v in host.items()}, "loss": round(float(loss.detach()), 4),
         "algorithmic_gflop_per_step": {"fusion_forward": round(gf, 1), "backward": round(gb, 1)},
         "roofline": {"bound": "mfma", "achieved": round((gf + gb) / fb_s / 1e3, 1), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                      "frac": round((gf + gb) / fb_s / 1e3 / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
-                     "note": "fusion forward + backward legs (synchronised) over their algorithmic flops; first-version kernels, see DESIGN section 9"},
+                     "note": "fusion forward + backward legs (synchronised) over their algorithmic flops; see DESIGN section 9"},
         "cpu_baseline": cpu}), flush=True)
 
 

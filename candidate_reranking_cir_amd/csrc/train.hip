@@ -41,6 +41,34 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* src, T* dst, in
     }
 }
 
+// ---- many transposes in one launch: matrix i (rows_i x cols_i, contiguous) at element offset off_i of src -> its transpose at the SAME
+// offset of dst.  table = 4 int64 per matrix: {offset, rows, cols, first 32 x 32 tile}; a block finds its matrix by binary search.
+// (The trainer's dgrad operands: every trained weight of the flat 16-bit parameter buffer, once per step.)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_multi_kernel(const T* src, T* dst, const int64_t* table, int count) {
+    __shared__ T tile[32][33];
+    int lo = 0, hi = count - 1;
+    const int64_t bid = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[4 * mid + 3] <= bid) lo = mid; else hi = mid - 1;
+    }
+    const int64_t off = table[4 * lo], t = bid - table[4 * lo + 3];
+    const int rows = (int)table[4 * lo + 1], cols = (int)table[4 * lo + 2];
+    const int tiles_c = (cols + 31) / 32;
+    const int r0 = (int)(t / tiles_c) * 32, c0 = (int)(t % tiles_c) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? src[off + (int64_t)r * cols + c] : static_cast<T>(0.f);
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) dst[off + (int64_t)c * rows + r] = tile[tx][i];
+    }
+}
+
 // ---- small batched matmul: C[b] = alpha * op(A[b]) * op(B[b]) (+ C[b]) ----------------------------------------------------
 // op(A) is (M, K): A stored (M, K) [ta = 0] or (K, M) [ta = 1]; op(B) is (K, N): B stored (K, N) [tb = 0] or (N, K) [tb = 1].
 // 16 x 16 output tile per 256-thread block, fp32 accumulate; inputs TI (16-bit or float), output TO.
@@ -573,6 +601,15 @@ extern "C" int cir_transpose16(const void* src, void* dst, int rows, int cols, i
     // (bf16 and fp16 are both 16-bit payloads: one instantiation moves either)
     hipLaunchKernelGGL((transpose_kernel<unsigned short>), grid, block, 0, s, reinterpret_cast<const unsigned short*>(src),
                        reinterpret_cast<unsigned short*>(dst), rows, cols, ld_src, ld_dst, s_src, s_dst);
+    CIR_LAUNCH_RESULT();
+}
+
+extern "C" int cir_transpose16_multi(const void* src, void* dst, const int64_t* table, int count, int64_t total_tiles, int dtype, void* stream) {
+    CIR_CHECK_PTR(src); CIR_CHECK_PTR(dst); CIR_CHECK_PTR(table);
+    if (count <= 0 || total_tiles <= 0 || total_tiles > 0x7fffffffLL) return CIR_EINVAL;
+    if (dtype != CIR_BF16 && dtype != CIR_F16) return CIR_EDTYPE;
+    hipLaunchKernelGGL((transpose_multi_kernel<unsigned short>), dim3((unsigned)total_tiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const unsigned short*>(src), reinterpret_cast<unsigned short*>(dst), table, count);
     CIR_LAUNCH_RESULT();
 }
 

@@ -66,6 +66,7 @@ SIGNATURES = {
     "cir_layernorm_bwd_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                         c_int, c_float, c_float, c_float, c_uint64, c_int, c_void_p]),
     "cir_rows16_colsum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "cir_transpose16_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "cir_wgrad_grouped": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "cir_wgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "cir_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),

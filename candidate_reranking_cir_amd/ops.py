@@ -47,7 +47,9 @@ def gemm_kernel_name(m: int, n: int, k: int, nb: int, has_residual: bool, act: i
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of torch's current stream on the current device (the C accessor: torch.cuda.current_stream().cuda_stream builds two
+    Python objects per call - measurable at ~800 launches per training step)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _need_cuda(*tensors):

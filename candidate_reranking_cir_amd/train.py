@@ -76,7 +76,7 @@ class _Slab:
             v = self._view(self.flat32, n)
             v.copy_(p.data)
             p.data = v
-        self.flat16 = self.gflat = None
+        self.flat16 = self.flat16t = self.gflat = self.plan = None
 
     def _view(self, flat: torch.Tensor, n: str) -> torch.Tensor:
         p = self.params[n]
@@ -87,22 +87,32 @@ class _Slab:
         return all(self.params[n].data_ptr() == base + 4 * self.off[n] for n in self.names)
 
     def begin_step(self):
-        self.flat16 = _cast(self.flat32, self.dtype)
+        """One cast launch refreshes the persistent 16-bit copy, one multi-transpose launch the dgrad operands (`plan`, built by the
+        trainer from its dense layers), one fill the fresh gradient buffer."""
+        if self.flat16 is None:
+            self.flat16 = torch.empty(self.flat32.shape, dtype=self.dtype, device=self.flat32.device)
+            self.flat16t = torch.zeros_like(self.flat16)
+        T.eltwise(self.flat32, T.MODE_SCALE, p_drop=1.0, out=self.flat16)
+        if self.plan is not None:
+            self.plan.run(self.flat16, self.flat16t)
         self.gflat = torch.zeros_like(self.flat32)
 
     def w32(self, n): return self._view(self.flat32, n)
     def w16(self, n): return self._view(self.flat16, n)
     def grad(self, n): return self._view(self.gflat, n)
 
-    def span(self, flat: torch.Tensor, names: List[str]) -> torch.Tensor:
-        """The slices of `names` as ONE tensor stacked along dim 0 (they must be adjacent in the buffer: `NlvrTrainer._order` lays
-        the q / k / v weights - and biases - of one attention out that way, so the three projections are one 2304-wide Linear)."""
+    def span_range(self, names: List[str]):
+        """(offset, rows, trailing shape) of the slices of `names` stacked along dim 0 (they must be adjacent in the buffer: `NlvrTrainer._order`
+        lays the q / k / v weights - and biases - of one attention out that way, so the three projections are one 2304-wide Linear)."""
         o = self.off[names[0]]
         rows = 0
         for n in names:
             assert self.off[n] == o + rows * (self.params[n].numel() // self.params[n].shape[0]), "group not adjacent in the slab"
             rows += self.params[n].shape[0]
-        tail = tuple(self.params[names[0]].shape[1:])
+        return o, rows, tuple(self.params[names[0]].shape[1:])
+
+    def span(self, flat: torch.Tensor, names: List[str]) -> torch.Tensor:
+        o, rows, tail = self.span_range(names)
         numel = rows
         for t in tail:
             numel *= t
@@ -110,18 +120,37 @@ class _Slab:
 
 
 class _Lin:
-    """One nn.Linear of the reference (weight (N, K), bias (N)): views of the slab's 16-bit weights / fp32 bias / gradient slices,
-    plus the transposed 16-bit weight copy the dgrad GEMM reads, made per step."""
+    """One nn.Linear of the reference (weight (N, K), bias (N)) - or several of one input stacked -: views of the slab's persistent 16-bit
+    weights, their transposed copy (the dgrad GEMM's operand; refreshed by the slab's one multi-transpose launch per step) and fp32 bias,
+    built ONCE; the gradient views follow the slab's per-step gradient buffer lazily."""
 
     def __init__(self, slab: _Slab, name, group: bool = False):
         names = list(name) if group else [name]                                     # a group: several Linears of one input, stacked
         has_bias = (names[0] + ".bias") in slab.off
-        ws, bs = [n + ".weight" for n in names], [n + ".bias" for n in names]
-        self.w16 = slab.span(slab.flat16, ws)                                       # (N, K): forward operand
-        self.w16t = T.transpose16(self.w16)                                         # (K, N): dgrad operand
-        self.bias = slab.span(slab.flat32, bs) if has_bias else None
-        self.dw = slab.span(slab.gflat, ws)
-        self.db = slab.span(slab.gflat, bs) if has_bias else None
+        self.slab = slab
+        self.ws, self.bs = [n + ".weight" for n in names], ([n + ".bias" for n in names] if has_bias else None)
+        self.w16 = slab.span(slab.flat16, self.ws)                                  # (N, K): forward operand
+        off, n, tail = slab.span_range(self.ws)
+        self.w16t = slab.flat16t[off:off + n * tail[0]].view(tail[0], n)            # (K, N): dgrad operand
+        self.transpose_entry = (off, n, tail[0])
+        self.bias = slab.span(slab.flat32, self.bs) if has_bias else None
+        self._g = None
+
+    def _grads(self):
+        g = self.slab.gflat
+        if self._g is not g:
+            self._g, self._dw = g, self.slab.span(g, self.ws)
+            self._db = self.slab.span(g, self.bs) if self.bs is not None else None
+
+    @property
+    def dw(self):
+        self._grads()
+        return self._dw
+
+    @property
+    def db(self):
+        self._grads()
+        return self._db
 
     def fwd(self, x16: torch.Tensor, out_dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         m, k = x16.shape
@@ -186,9 +215,24 @@ class _Lin:
 
 class _LN:
     def __init__(self, slab: _Slab, name: str, eps: float):
-        self.eps = eps
+        self.eps, self.slab, self.name = eps, slab, name
         self.g, self.b = slab.w32(name + ".weight"), slab.w32(name + ".bias")
-        self.dg, self.db = slab.grad(name + ".weight"), slab.grad(name + ".bias")
+        self._g = None
+
+    def _grads(self):
+        g = self.slab.gflat
+        if self._g is not g:
+            self._g, self._dg, self._db = g, self.slab.grad(self.name + ".weight"), self.slab.grad(self.name + ".bias")
+
+    @property
+    def dg(self):
+        self._grads()
+        return self._dg
+
+    @property
+    def db(self):
+        self._grads()
+        return self._db
 
     def fwd(self, pre: torch.Tensor, dtype: torch.dtype):
         return ops.layernorm(pre, self.g, self.b, self.eps, want32=True, dtype16=dtype, stream_dtype=torch.float32)
@@ -249,18 +293,29 @@ class NlvrTrainer:
         return out
 
     def _pack(self):
-        P = dict(self.model.named_parameters())
+        """Per step: refresh the 16-bit parameter copies and a zeroed gradient buffer (three launches).  The layer objects - views of the
+        persistent buffers - are built once and rebuilt only when the model was moved / re-cast."""
         slab = getattr(self, "slab", None)
         if slab is None or slab.dtype != self.dtype or not slab.valid():           # first step, or the model was moved / re-cast
+            P = dict(self.model.named_parameters())
             slab = self.slab = _Slab(P, self._order([n for n in P if self._trained(n)]), self.dtype)
+            slab.begin_step()                                                       # allocates the 16-bit buffers the views below slice
+            self._build_layers(slab)
         slab.begin_step()
+        e = self._EMB
+        self.dword, self.dpos = slab.grad(e + "word_embeddings.weight"), slab.grad(e + "position_embeddings.weight")
+
+    def _build_layers(self, slab: _Slab):
         g = self.geo
-        lin = lambda name: _Lin(slab, name)
-        grp = lambda names: _Lin(slab, names, group=True)
+        lins: List[_Lin] = []
+
+        def lin(name, group=False):
+            lins.append(_Lin(slab, name, group))
+            return lins[-1]
+        grp = lambda names: lin(names, True)
         ln = lambda name: _LN(slab, name, g.layer_norm_eps)
         e = self._EMB
         self.word, self.pos = slab.w32(e + "word_embeddings.weight"), slab.w32(e + "position_embeddings.weight")
-        self.dword, self.dpos = slab.grad(e + "word_embeddings.weight"), slab.grad(e + "position_embeddings.weight")
         self.ln_e = ln(e + "LayerNorm")
         self.layers: List[Dict] = []
         for i in range(g.num_hidden_layers):
@@ -280,6 +335,7 @@ class NlvrTrainer:
             ly["w1"], ly["w2"], ly["ln3"] = lin(p + "intermediate.dense"), lin(p + "output.dense"), ln(p + "output.LayerNorm")
             self.layers.append(ly)
         self.c0, self.c2 = lin("cls_head.0"), lin("cls_head.2")
+        slab.plan = T.TransposePlan([l.transpose_entry for l in lins], slab.flat32.device)
 
     def _site(self, *ids) -> int:
         s = self.seed * 1000003 + self.step_no * 7919

@@ -28,6 +28,24 @@ def transpose16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Te
     return out
 
 
+class TransposePlan:
+    """The table of cir_transpose16_multi for matrices (offset, rows, cols) of one flat 16-bit buffer, uploaded once."""
+
+    def __init__(self, entries, device):
+        rows, tile = [], 0
+        for off, r, c in entries:
+            rows.append([int(off), int(r), int(c), tile])
+            tile += ((r + 31) // 32) * ((c + 31) // 32)
+        self.count, self.tiles = len(rows), tile
+        self.table = torch.tensor(rows, dtype=torch.int64, device=device).contiguous()
+
+    def run(self, src: torch.Tensor, dst: torch.Tensor):
+        _need_cuda(src, dst)
+        assert src.dtype == dst.dtype and src.dtype in (torch.bfloat16, torch.float16) and src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
+        _lib.check(_lib.load().cir_transpose16_multi(src.data_ptr(), dst.data_ptr(), self.table.data_ptr(), self.count, self.tiles, _DT[src.dtype], _stream()),
+                   "cir_transpose16_multi")
+
+
 def bmm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False, out: Optional[torch.Tensor] = None,
         out_dtype: Optional[torch.dtype] = None, alpha: float = 1.0, accumulate=False) -> torch.Tensor:
     """out[z] = alpha * op(a[z]) @ op(b[z]) (+ out[z]); a, b, out are (B, ., .) or (B1, B2, ., .) views with unit last stride and
@@ -236,11 +254,13 @@ def gelu_bwd16(df: torch.Tensor, z: torch.Tensor, sums: Optional[torch.Tensor] =
 
 
 def eltwise(z: torch.Tensor, mode: int, dy: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, p_drop: float = 0.0,
-            seed: int = 0) -> torch.Tensor:
+            seed: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Elementwise modes of cir_eltwise on contiguous tensors (see the MODE_* constants)."""
-    _need_cuda(z, dy)
+    _need_cuda(z, dy, out)
     assert z.is_contiguous() and (dy is None or (dy.is_contiguous() and dy.dtype == torch.float32 and dy.numel() == z.numel()))
-    out = torch.empty(z.shape, dtype=out_dtype or z.dtype, device=z.device)
+    if out is None:
+        out = torch.empty(z.shape, dtype=out_dtype or z.dtype, device=z.device)
+    assert out.is_contiguous() and out.numel() == z.numel()
     _lib.check(_lib.load().cir_eltwise(z.data_ptr(), _DT[z.dtype], _ptr(dy), out.data_ptr(), _DT[out.dtype], z.numel(), mode, float(p_drop),
                                        int(seed) & (2 ** 63 - 1), _stream()), "cir_eltwise")
     return out

@@ -205,6 +205,10 @@ int cir_l2_normalize(const float* x, float* y, int64_t rows, int cols, void* str
 /* dst[b][c][r] = src[b][r][c], 16-bit elements (dtype CIR_BF16 / CIR_F16 names the payload only). */
 int cir_transpose16(const void* src, void* dst, int rows, int cols, int64_t ld_src, int64_t ld_dst, int batch, int64_t s_src, int64_t s_dst,
                     int dtype, void* stream);
+/* `count` transposes in one launch (ABI v10): matrix i - rows_i x cols_i, contiguous - at element offset off_i of src is written transposed at
+ * the same offset of dst.  table (DEVICE memory, 4 int64 per matrix): {off_i, rows_i, cols_i, index of its first 32 x 32 tile}; total_tiles =
+ * the sum of the tile counts.  The trainer transposes every trained weight of its flat 16-bit parameter buffer with it, once per step. */
+int cir_transpose16_multi(const void* src, void* dst, const int64_t* table, int count, int64_t total_tiles, int dtype, void* stream);
 /* C[z] = alpha * op(A[z]) * op(B[z]) (+ C[z] if accumulate): op(A) (M,K) from A stored (M,K) [trans_a 0] or (K,M) [1]; op(B) (K,N)
  * from B stored (K,N) [trans_b 0] or (N,K) [1].  Any extents, fp32 accumulate.  Two batch levels: z = z1 * nb2 + z2 with a stride per
  * level and operand (element units; 0 broadcasts), nb1 * nb2 <= 65535.  in_dtype CIR_BF16 / CIR_F16: MFMA kernel (64 x 64 tiles,

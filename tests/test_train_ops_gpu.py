@@ -406,3 +406,18 @@ def test_rows16_colsum_and_gelu_adjoint(T, dtype):
     torch.testing.assert_close(dz.float(), zr.grad, **tol)
     torch.testing.assert_close(sb, zr.grad.sum(0), atol=5e-2 if dtype == BF else 5e-3, rtol=1e-3)
     assert torch.equal(T.gelu_bwd16(a, z), dz)
+
+
+def test_transpose16_multi(T):
+    """cir_transpose16_multi: every matrix of a flat buffer transposed at its own offset in one launch (ragged extents, a 1-row matrix)."""
+    shapes = [(70, 33), (768, 128), (1, 40), (2304, 96), (32, 32)]
+    entries, off = [], 0
+    for r, c in shapes:
+        entries.append((off, r, c))
+        off += (r * c + 7) // 8 * 8
+    src = _r((off,), 61, dtype=HF)
+    dst = torch.zeros_like(src)
+    plan = T.TransposePlan(entries, src.device)
+    plan.run(src, dst)
+    for o, r, c in entries:
+        assert torch.equal(dst[o:o + r * c].view(c, r), src[o:o + r * c].view(r, c).t())
