@@ -13,6 +13,8 @@
 // with P = exp2(S * scale*log2e + mask*log2e - LSE2), Pd = dropout(P), dS = scale * P * (dropout'(dPd) - D), D = rowsum(dO * O).
 // Tensors are head views (group, head, row, 64) given by three element strides each; rows beyond an extent are clamped on load and
 // their probabilities forced to zero.  Dropout: element (row = (group * H + head) * Lq + query, col = key) of common.hpp's pair hash.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace cir {
@@ -109,16 +111,16 @@ __device__ __forceinline__ void store_f32(const f32x16 (&acc)[2], float* rowp /*
 
 // gradient store of a transposed accumulator (same element map) at element offset `off` of `base`: fp32 or the operand type
 template <typename T>
-__device__ __forceinline__ void store_grad(const f32x16 (&acc)[2], void* base, int64_t off, int grad16) {
-    if (!grad16) { store_f32(acc, reinterpret_cast<float*>(base) + off, 1.0f); return; }
+__device__ __forceinline__ void store_grad(const f32x16 (&acc)[2], void* base, int64_t off, int grad16, float mul) {
+    if (!grad16) { store_f32(acc, reinterpret_cast<float*>(base) + off, mul); return; }
     typedef __attribute__((ext_vector_type(4))) T t4;
     T* rowp = reinterpret_cast<T*>(base) + off;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
-            t4 o = {static_cast<T>(acc[dt][qd * 4 + 0]), static_cast<T>(acc[dt][qd * 4 + 1]), static_cast<T>(acc[dt][qd * 4 + 2]),
-                    static_cast<T>(acc[dt][qd * 4 + 3])};
+            t4 o = {static_cast<T>(acc[dt][qd * 4 + 0] * mul), static_cast<T>(acc[dt][qd * 4 + 1] * mul), static_cast<T>(acc[dt][qd * 4 + 2] * mul),
+                    static_cast<T>(acc[dt][qd * 4 + 3] * mul)};
             *reinterpret_cast<t4*>(rowp + dt * 32 + 8 * qd) = o;
         }
 }
@@ -226,20 +228,30 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const TAttnArgs a) {
 // the FORWARD used: a kept element's is its 16-bit dropout(P) value scaled back - D = rowsum(dO * O) = sum_j Pd16_ij dPd_ij was formed
 // with exactly those, so sum_j dS_ij = D (1 - sum_j P_ij) vanishes as the softmax Jacobian demands; with the unrounded fp32 p the row
 // sums of dS are off by the rounding of P and the (column-summed) query-bias gradients lose a factor 2-3 of accuracy.
+// Both kernels are VALU-bound (head dimension 64: 512 MFMA cycles per 32 x 32 tile against 16 score elements per lane), so the element
+// chain is kept minimal: x = s * sl + c with c = mask - LSE prepared per row / column (-inf for rows or keys past the extents: p = 0, no
+// `valid` selects), the softmax scale is applied ONCE to the dQ / dK accumulators at the store instead of to every dS element, and
+// dS / scale = Pd16 * dPd - P_f * D needs one multiply and one fma.
 struct Adj { float pd, ds; };
-template <typename T>
-__device__ __forceinline__ Adj adjoint(float s, float dp, float sl, float maskv, float lse, float dsum, bool valid, float scale, float keep,
-                                        bool kept) {
-    const float p = valid ? __builtin_amdgcn_exp2f(fmaf(s, sl, maskv) - lse) : 0.f;
+template <typename T, bool DROP>
+__device__ __forceinline__ Adj adjoint(float s, float dp, float sl, float c, float dsum, float keep, float ikeep, bool kept) {
+    const float p = __builtin_amdgcn_exp2f(fmaf(s, sl, c));
     Adj r;
-    r.pd = kept ? static_cast<float>(static_cast<T>(p * keep)) : 0.f;
-    const float pf = kept ? r.pd * (1.0f / keep) : p;
-    r.ds = pf * ((kept ? dp * keep : 0.f) - dsum) * scale;
+    if constexpr (DROP) {
+        r.pd = static_cast<float>(static_cast<T>(p * (kept ? keep : 0.f)));       // what the forward's P.V product consumed
+        const float pf = kept ? r.pd * ikeep : p;
+        r.ds = fmaf(r.pd, dp, -(pf * dsum));
+    } else {
+        r.pd = static_cast<float>(static_cast<T>(p));
+        r.ds = r.pd * (dp - dsum);
+    }
     return r;
 }
+// the 16 random bits of element (row key, column): column parity picks the half
+__device__ __forceinline__ bool kept16(uint32_t bits, uint32_t shift, uint32_t thr) { return __builtin_amdgcn_ubfe(bits, shift, 16) >= thr; }
 
 // ------------------------------------------------------------------------------------------------------------------ dQ (and D)
-template <typename T, bool MASKED>
+template <typename T, bool MASKED, bool DROP>
 __global__ __launch_bounds__(256) void tattn_bwd_dq_kernel(const TAttnArgs a) {
     using X8 = typename Elem<T>::x8;
     __shared__ __attribute__((aligned(16))) char smem[4 * 4096];
@@ -287,14 +299,14 @@ __global__ __launch_bounds__(256) void tattn_bwd_dq_kernel(const TAttnArgs a) {
         dsum += __shfl_xor(dsum, 32, 64);
         if (hh == 0 && q0 + r < a.Lq) a.dsum[gh * a.Lq + q0 + r] = dsum;
     }
-    const float lse = a.lse[gh * a.Lq + qrow];
+    const bool qvalid = q0 + r < a.Lq;
+    const float nlse = qvalid ? -a.lse[gh * a.Lq + qrow] : -INFINITY;     // a query row past Lq: p = 0 everywhere
     char* kl = smem + wave * 4096;
     int voff[2];
     tr_offsets(lane, voff);
     const float sl = a.scale * kLog2eT;
-    const float keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+    const float keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f, ikeep = 1.0f - a.p_drop;
     const uint32_t rkey = drop_row_key(a.seed, (uint64_t)(gh * a.Lq + qrow)), thr = drop_threshold(a.p_drop);
-    const bool qvalid = q0 + r < a.Lq;
 
     f32x16 dq[2];
 #pragma unroll
@@ -317,29 +329,40 @@ __global__ __launch_bounds__(256) void tattn_bwd_dq_kernel(const TAttnArgs a) {
             tile_load<T>(kb, a.k_sr, key0 + 32, a.Lk, lane, kr);
         }
         X8 dsf[2];
-        uint32_t bits = 0;
+        const bool edge = MASKED || key0 + 32 > a.Lk;              // only the last key tile can hold keys past Lk
+        auto elements = [&](auto edge_c) {
+            uint32_t bits = 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int key = key0 + acc_row(i, hh);
-            float maskv = 0.f;
-            if constexpr (MASKED) maskv = fmaxf(mp[min(key, a.Lk - 1)], -2.0e38f) * kLog2eT;
-            if (thr != 0 && (i & 1) == 0) bits = drop_bits(rkey, key);
-            const Adj ad = adjoint<T>(s[i], dp[i], sl, maskv, lse, dsum, qvalid && key < a.Lk, a.scale, keep, drop_kept(bits, key, thr));
-            dsf[i >> 3][i & 7] = static_cast<T>(ad.ds);
-        }
+            for (int i = 0; i < 16; ++i) {
+                const int key = key0 + acc_row(i, hh);
+                float c = nlse;
+                if constexpr (decltype(edge_c)::value) {
+                    if constexpr (MASKED) c = fmaf(fmaxf(mp[min(key, a.Lk - 1)], -2.0e38f), kLog2eT, nlse);
+                    c = key < a.Lk ? c : -INFINITY;
+                }
+                if (DROP && (i & 1) == 0) bits = drop_bits(rkey, key);
+                const Adj ad = adjoint<T, DROP>(s[i], dp[i], sl, c, dsum, keep, ikeep, DROP ? kept16(bits, (i & 1) * 16, thr) : true);
+                dsf[i >> 3][i & 7] = static_cast<T>(ad.ds);
+            }
+        };
+        if (edge) elements(std::true_type{}); else elements(std::false_type{});
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        tr_accumulate<T>(dq, kl, voff, dsf);                    // dQ^T[dh][q] += K^T[dh][key] dS^T[key][q]
+        tr_accumulate<T>(dq, kl, voff, dsf);                    // dQ^T[dh][q] += K^T[dh][key] (dS / scale)^T[key][q]
         __builtin_amdgcn_wave_barrier();
     }
-    if (qvalid) store_grad<T>(dq, a.dq, g * a.dq_sg + h * a.dq_sh + (int64_t)(q0 + r) * a.dq_sr + 4 * hh, a.grad16);
+    if (qvalid) store_grad<T>(dq, a.dq, g * a.dq_sg + h * a.dq_sh + (int64_t)(q0 + r) * a.dq_sr + 4 * hh, a.grad16, a.scale);
 }
 
 // ------------------------------------------------------------------------------------------------------------------ dK, dV
-template <typename T, bool MASKED>
+// Per wave and query tile the 32 rows' -LSE and D are staged through 256 bytes of LDS (one coalesced load per lane, prefetched a tile
+// ahead; eight ds_read_b128 hand every lane the values of its 16 accumulator rows) - per-element global gathers with clamped 64-bit
+// addresses were a fifth of this kernel's VALU work.  Keys past Lk need no masking here: a lane owns ONE key column of dK / dV, and the
+// columns of keys past the extent are simply not stored.
+template <typename T, bool MASKED, bool DROP>
 __global__ __launch_bounds__(256) void tattn_bwd_dkv_kernel(const TAttnArgs a) {
     using X8 = typename Elem<T>::x8;
-    __shared__ __attribute__((aligned(16))) char smem[4 * 2 * 4096];   // per wave: a Q tile and a dO tile
+    __shared__ __attribute__((aligned(16))) char smem[4 * (2 * 4096 + 256)];   // per wave: a Q tile, a dO tile, the rows' statistics
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
@@ -360,16 +383,22 @@ __global__ __launch_bounds__(256) void tattn_bwd_dkv_kernel(const TAttnArgs a) {
     frag_load<T>(reinterpret_cast<const T*>(a.v) + g * a.v_sg + h * a.v_sh + (int64_t)krow * a.v_sr + 8 * hh, vfb);
     float maskv = 0.f;
     if constexpr (MASKED) maskv = fmaxf(a.mask[g * a.Lk + krow], -2.0e38f) * kLog2eT;
-    char* ql = smem + wave * 8192;
+    char* ql = smem + wave * (2 * 4096 + 256);
     char* dl = ql + 4096;
+    float* stat = reinterpret_cast<float*>(dl + 4096);          // [0, 32): -LSE of the tile's rows, [32, 64): their D
     int voff[2];
     tr_offsets(lane, voff);
     const float sl = a.scale * kLog2eT;
-    const float keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
-    const float* lsep = a.lse + gh * a.Lq;
-    const float* dsp = a.dsum + gh * a.Lq;
+    const float keep = a.p_drop > 0.f ? 1.0f / (1.0f - a.p_drop) : 1.0f, ikeep = 1.0f - a.p_drop;
+    const float* stp = (hh == 0 ? a.lse : a.dsum) + gh * a.Lq;
+    auto stat_load = [&](int q0) -> float {
+        const int qi = q0 + r;
+        const float v = stp[min(qi, a.Lq - 1)];
+        return hh == 0 ? (qi < a.Lq ? -v : -INFINITY) : v;      // a query row past Lq: p = 0
+    };
     const uint32_t thr = drop_threshold(a.p_drop);
     const uint32_t rkey0 = drop_row_key(a.seed, (uint64_t)(gh * a.Lq + 4 * hh));    // + (query - 4 hh) * kDropWeyl: the rows of a tile are a Weyl step apart
+    const uint32_t kj = (uint32_t)krow >> 1, kshift = ((uint32_t)krow & 1u) * 16;
 
     f32x16 dk[2], dv[2];
 #pragma unroll
@@ -379,6 +408,7 @@ __global__ __launch_bounds__(256) void tattn_bwd_dkv_kernel(const TAttnArgs a) {
     frag_load<T>(dob + (int64_t)min(r, a.Lq - 1) * a.o_sr + 8 * hh, dofa);
     tile_load<T>(qb, a.q_sr, 0, a.Lq, lane, qr);
     tile_load<T>(dob, a.o_sr, 0, a.Lq, lane, dor);
+    float st = stat_load(0);
     for (int qt = 0; qt < a.nqt; ++qt) {
         const int q0 = qt * 32;
         f32x16 s, dp;
@@ -388,38 +418,41 @@ __global__ __launch_bounds__(256) void tattn_bwd_dkv_kernel(const TAttnArgs a) {
         for (int sx = 0; sx < 4; ++sx) { s = Elem<T>::mfma32(qfa[sx], kfb[sx], s); dp = Elem<T>::mfma32(dofa[sx], vfb[sx], dp); }   // rows = queries, column = my key
         tile_store<T>(ql, lane, qr);
         tile_store<T>(dl, lane, dor);
-        float lse_i[16], ds_i[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int qi = min(q0 + acc_row(i, hh), a.Lq - 1);
-            lse_i[i] = lsep[qi];
-            ds_i[i] = dsp[qi];
-        }
+        stat[lane] = st;
         if (qt + 1 < a.nqt) {
             frag_load<T>(qb + (int64_t)min(q0 + 32 + r, a.Lq - 1) * a.q_sr + 8 * hh, qfa);
             frag_load<T>(dob + (int64_t)min(q0 + 32 + r, a.Lq - 1) * a.o_sr + 8 * hh, dofa);
             tile_load<T>(qb, a.q_sr, q0 + 32, a.Lq, lane, qr);
             tile_load<T>(dob, a.o_sr, q0 + 32, a.Lq, lane, dor);
-        }
-        X8 pdf[2], dsf[2];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int qi = q0 + acc_row(i, hh);
-            // (rows past Lq carry p = 0: their mask bit is irrelevant, no clamp)
-            const uint32_t bits = thr != 0 ? drop_bits(rkey0 + (uint32_t)(q0 + (i & 3) + 8 * (i >> 2)) * kDropWeyl, (uint32_t)krow) : 0u;
-            const Adj ad = adjoint<T>(s[i], dp[i], sl, maskv, lse_i[i], ds_i[i], kvalid && qi < a.Lq, a.scale, keep, drop_kept(bits, (uint32_t)krow, thr));
-            pdf[i >> 3][i & 7] = static_cast<T>(ad.pd);
-            dsf[i >> 3][i & 7] = static_cast<T>(ad.ds);
+            st = stat_load(q0 + 32);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        float4 nl[4], dsv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                            // accumulator rows 8 j + 4 hh + (0..3)
+            nl[j] = *reinterpret_cast<const float4*>(stat + 8 * j + 4 * hh);
+            dsv[j] = *reinterpret_cast<const float4*>(stat + 32 + 8 * j + 4 * hh);
+        }
+        const uint32_t rkq = rkey0 + (uint32_t)q0 * kDropWeyl;
+        X8 pdf[2], dsf[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float nli = (i & 3) == 0 ? nl[i >> 2].x : (i & 3) == 1 ? nl[i >> 2].y : (i & 3) == 2 ? nl[i >> 2].z : nl[i >> 2].w;
+            const float dsi = (i & 3) == 0 ? dsv[i >> 2].x : (i & 3) == 1 ? dsv[i >> 2].y : (i & 3) == 2 ? dsv[i >> 2].z : dsv[i >> 2].w;
+            bool kept = true;
+            if constexpr (DROP) kept = kept16(hash32((rkq + (uint32_t)((i & 3) + 8 * (i >> 2)) * kDropWeyl) ^ kj), kshift, thr);
+            const Adj ad = adjoint<T, DROP>(s[i], dp[i], sl, MASKED ? maskv + nli : nli, dsi, keep, ikeep, kept);
+            pdf[i >> 3][i & 7] = static_cast<T>(ad.pd);
+            dsf[i >> 3][i & 7] = static_cast<T>(ad.ds);
+        }
         tr_accumulate<T>(dv, dl, voff, pdf);                    // dV^T[dh][key] += dO^T[dh][q] Pd[q][key]
-        tr_accumulate<T>(dk, ql, voff, dsf);                    // dK^T[dh][key] += Q^T[dh][q]  dS[q][key]
+        tr_accumulate<T>(dk, ql, voff, dsf);                    // dK^T[dh][key] += Q^T[dh][q]  (dS / scale)[q][key]
         __builtin_amdgcn_wave_barrier();
     }
     if (kvalid) {
-        store_grad<T>(dk, a.dk, g * a.dk_sg + h * a.dk_sh + (int64_t)key * a.dk_sr + 4 * hh, a.grad16);
-        store_grad<T>(dv, a.dv, g * a.dv_sg + h * a.dv_sh + (int64_t)key * a.dv_sr + 4 * hh, a.grad16);
+        store_grad<T>(dk, a.dk, g * a.dk_sg + h * a.dk_sh + (int64_t)key * a.dk_sr + 4 * hh, a.grad16, a.scale);
+        store_grad<T>(dv, a.dv, g * a.dv_sg + h * a.dv_sh + (int64_t)key * a.dv_sr + 4 * hh, a.grad16, 1.0f);
     }
 }
 
@@ -498,12 +531,13 @@ extern "C" int cir_attention_train_bwd(const void* q, int64_t q_sg, int64_t q_sh
     dim3 block(256);
     dim3 gq((unsigned)(((int64_t)G * H * a.nqt + 3) / 4)), gk((unsigned)(((int64_t)G * H * a.nkt + 3) / 4));
     // dQ first: it also writes D = rowsum(dO * O), which the dK / dV kernel reads (same stream: ordered)
-    if (dtype == CIR_BF16) {
-        if (mk) { hipLaunchKernelGGL((tattn_bwd_dq_kernel<__bf16, true>), gq, block, 0, s, a); hipLaunchKernelGGL((tattn_bwd_dkv_kernel<__bf16, true>), gk, block, 0, s, a); }
-        else { hipLaunchKernelGGL((tattn_bwd_dq_kernel<__bf16, false>), gq, block, 0, s, a); hipLaunchKernelGGL((tattn_bwd_dkv_kernel<__bf16, false>), gk, block, 0, s, a); }
-    } else {
-        if (mk) { hipLaunchKernelGGL((tattn_bwd_dq_kernel<_Float16, true>), gq, block, 0, s, a); hipLaunchKernelGGL((tattn_bwd_dkv_kernel<_Float16, true>), gk, block, 0, s, a); }
-        else { hipLaunchKernelGGL((tattn_bwd_dq_kernel<_Float16, false>), gq, block, 0, s, a); hipLaunchKernelGGL((tattn_bwd_dkv_kernel<_Float16, false>), gk, block, 0, s, a); }
-    }
+    const bool dr = p_drop > 0.f;
+#define CIR_TATTN_BWD(TT, MK, DR) do { hipLaunchKernelGGL((tattn_bwd_dq_kernel<TT, MK, DR>), gq, block, 0, s, a); \
+                                       hipLaunchKernelGGL((tattn_bwd_dkv_kernel<TT, MK, DR>), gk, block, 0, s, a); } while (0)
+#define CIR_TATTN_BWD_T(TT) do { if (mk) { if (dr) CIR_TATTN_BWD(TT, true, true); else CIR_TATTN_BWD(TT, true, false); } \
+                                 else { if (dr) CIR_TATTN_BWD(TT, false, true); else CIR_TATTN_BWD(TT, false, false); } } while (0)
+    if (dtype == CIR_BF16) CIR_TATTN_BWD_T(__bf16); else CIR_TATTN_BWD_T(_Float16);
+#undef CIR_TATTN_BWD_T
+#undef CIR_TATTN_BWD
     CIR_LAUNCH_RESULT();
 }
