@@ -252,7 +252,7 @@ __device__ __forceinline__ bool kept16(uint32_t bits, uint32_t shift, uint32_t t
 
 // ------------------------------------------------------------------------------------------------------------------ dQ (and D)
 template <typename T, bool MASKED, bool DROP>
-__global__ __launch_bounds__(256) void tattn_bwd_dq_kernel(const TAttnArgs a) {
+__global__ __launch_bounds__(256, 2) void tattn_bwd_dq_kernel(const TAttnArgs a) {
     using X8 = typename Elem<T>::x8;
     __shared__ __attribute__((aligned(16))) char smem[4 * 4096];
     const int lane = threadIdx.x & 63;
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void tattn_bwd_dq_kernel(const TAttnArgs a) {
 // addresses were a fifth of this kernel's VALU work.  Keys past Lk need no masking here: a lane owns ONE key column of dK / dV, and the
 // columns of keys past the extent are simply not stored.
 template <typename T, bool MASKED, bool DROP>
-__global__ __launch_bounds__(256) void tattn_bwd_dkv_kernel(const TAttnArgs a) {
+__global__ __launch_bounds__(256, 2) void tattn_bwd_dkv_kernel(const TAttnArgs a) {
     using X8 = typename Elem<T>::x8;
     __shared__ __attribute__((aligned(16))) char smem[4 * (2 * 4096 + 256)];   // per wave: a Q tile, a dO tile, the rows' statistics
     const int lane = threadIdx.x & 63;
