@@ -8,17 +8,18 @@ blip_stage2.py:65-99: row i's caption / z_t expanded to B rows against all B tar
 `NlvrTrainer` runs that forward with every intermediate the backward needs kept on the device, and the backward as an explicit
 reverse pass - no autograd graph over the kernels: each step of nlvr_encoder.BertLayer.forward (:414-476), BertSelfAttention
 (:140-222), BertSelfOutput (:248-264, incl. the averaging / merge_layer variants), BertIntermediate / BertOutput (:383-409),
-BertEmbeddings (:49-91) and cls_head (blip_stage2.py:50-54) has its hand-written adjoint below.  Arithmetic: dense layers on the
-MFMA GEMM (`ops.gemm`; dgrad over a transposed weight copy) or, where an extent misses its tile constraints, on `train_ops.bmm`
-(MFMA, any extents); weight gradients on `train_ops.bmm` reading dy and x as stored, split over row chunks; attention un-fused
-(scores, softmax + dropout, context: batched `bmm` over (group, head)) so that its adjoint is four batched matmuls and one row
-kernel; LayerNorm / GELU / dropout / embedding adjoints in `train_ops`.  Triplets are ordered candidate-major, so the
-cross-attention keys / values of a target image are projected once per step and their gradients sum over the B queries inside
-the dK / dV products.
-Precision: 16-bit MFMA operands (activations, weights, and the gradients fed to the GEMMs), fp32 accumulation, fp32 residual
-stream, fp32 LayerNorm inputs, fp32 weight gradients - the forward plan of DESIGN.md section 2 with an fp32 stream.
+BertEmbeddings (:49-91) and cls_head (blip_stage2.py:50-54) has its hand-written adjoint below.  Arithmetic:
+dense layers forward / dgrad on the MFMA GEMM (`ops.gemm`; dgrad over a transposed weight copy, the skip connection's fp32 gradient
+added in its epilogue); the 13 weight gradients of a layer in ONE grouped launch (`train_ops.wgrad_grouped`: dy and x read as stored,
+no row splits, no atomics); attention as one fused kernel with a log-sum-exp output and a recomputing adjoint whose dq | dk | dv come
+out as the 16-bit operand of the fused projection's backward; each dense -> dropout -> + residual -> LayerNorm block as one pass per
+direction (`residual_layernorm_train` / `layernorm_bwd_fused`, the latter also emitting the dense branch's 16-bit gradient and bias
+sums); GELU's adjoint with the bias sums in one 16-bit pass.  Triplets are ordered candidate-major, so the cross-attention keys /
+values of a target image are projected once per step and their gradients sum over the B queries inside the dK / dV kernel.
+Precision: 16-bit MFMA operands (activations, weights, and every gradient between two dense layers), fp32 accumulation, fp32 residual
+stream and its gradient, fp32 LayerNorm inputs, fp32 weight gradients.
 Dropout is counter-based (seed per site); with p = 0 the pass has no random state - reproducible up to the order of the fp32 atomic adds in
-the column sums / LayerNorm and embedding adjoints - and is what the reference-gradient fixture pins.
+the column sums / LayerNorm and embedding adjoints - and is what the reference-gradient fixtures pin.
 
 `fusion_train(model, ...)` wraps the pair as ONE `torch.autograd.Function`, so the reference's training step runs unchanged:
 `logits = model.img_txt_fusion(z_t, feats, captions)` in `.train()` mode, `loss = F.cross_entropy(logits, gt)`, `loss.backward()`
