@@ -185,7 +185,14 @@ class BLIP_NLVR(_EngineHost):
                                         cross_dtype=self.token_dtype))
             self._text_stale = False
             self._packed_epoch = _lib.PARAM_EPOCH[0]
-        elif text and (self._text_stale or (getattr(self, "_trainer", None) is not None and self._packed_epoch != _lib.PARAM_EPOCH[0])):
+        if self._engines is not None and (getattr(self, "_vit_stale", False) or (getattr(self, "_vit_trainer", None) is not None
+                                                                                 and getattr(self, "_vit_packed_epoch", None) != _lib.PARAM_EPOCH[0])):
+            # the ViT is being fine-tuned (train_vit.py): its packed engine follows the parameters the same way the text side's does
+            self._engines = (VitEngine(self.state_dict(), self.vit_geometry, self.token_dtype, self.device, stream_dtype=self.vit_stream_dtype),
+                             self._engines[1])
+            self._vit_stale = False
+            self._vit_packed_epoch = _lib.PARAM_EPOCH[0]
+        if text and self._engines is not None and (self._text_stale or (getattr(self, "_trainer", None) is not None and self._packed_epoch != _lib.PARAM_EPOCH[0])):
             # after training steps (the forward marks it; every cir_adamw_step launch moves lib.PARAM_EPOCH, so an eval call made
             # between backward() and step() cannot leave the engine on the pre-step weights): repack the two-branch encoder only (the ViT is frozen there),
             self._engines = (self._engines[0], NlvrEngine(self.state_dict(), self.bert_geometry, self.compute_dtype, self.device,
@@ -194,10 +201,16 @@ class BLIP_NLVR(_EngineHost):
             self._packed_epoch = _lib.PARAM_EPOCH[0]
         return self._engines
 
-    @torch.no_grad()
     def img_embed(self, image, train=True, atts=False):
-        """(B,3,H,W) -> (B, N, D) fp32 image tokens [+ ones (B, N) int64], blip_stage2.py:57-63."""
-        y32, _ = self.engines(text=False)[0].forward(image.to(self.device), want32=True)
+        """(B,3,H,W) -> (B, N, D) fp32 image tokens [+ ones (B, N) int64], blip_stage2.py:57-63.  In `.train()` mode with autograd enabled and
+        a trainable ViT (`--blip-img-tune`, stage2_train.py:87-92, 191-199) the tokens carry a graph: `train_vit.vit_train`, whose reverse
+        pass fills `.grad` of every visual_encoder parameter; otherwise (eval mode, torch.no_grad(), frozen ViT) the inference engine."""
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for n, p in self.named_parameters() if n.startswith("visual_encoder.")):
+            from .train_vit import vit_train
+            y32 = vit_train(self, image)
+        else:
+            with torch.no_grad():
+                y32, _ = self.engines(text=False)[0].forward(image.to(self.device), want32=True)
         if atts:
             return y32, torch.ones(y32.shape[:-1], dtype=torch.long, device=y32.device)
         return y32

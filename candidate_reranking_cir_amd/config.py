@@ -67,6 +67,8 @@ class VitGeometry:
     mlp_ratio: int = 4
     layer_norm_eps: float = 1e-6  # vit.py:142
     in_chans: int = 3
+    drop_path_rate: float = 0.1   # TRAINING mode only (train_vit.py): blip_stage2.py:37 builds the stage-II image encoder with 0.1; block i
+                                  # drops each sample's branch with probability linspace(0, rate, depth)[i] (vit.py:153, :98-109)
 
     @classmethod
     def named(cls, vit: str, image_size: int) -> "VitGeometry":

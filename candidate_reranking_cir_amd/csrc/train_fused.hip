@@ -243,9 +243,43 @@ __global__ __launch_bounds__(256) void rows16_colsum_kernel(const T* a, int64_t 
     }
 }
 
+// ---- out = a + s[row / rows_per_group] * b : a per-GROUP scale of a branch added to the stream (DropPath: timm's per-sample stochastic
+// depth, vit.py:98-109), or with a = NULL the scaled branch gradient written as the 16-bit operand of the adjoint products
+template <typename TO>
+__global__ __launch_bounds__(256) void rows_scale_add_kernel(const float* a, const float* b, const float* scale, TO* out, int64_t rows, int cols,
+                                                             int64_t rows_per_group) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= rows * cols) return;
+    const float sc = scale[(i / cols) / rows_per_group];
+    const float4 bv = *reinterpret_cast<const float4*>(b + i);
+    float r[4] = {bv.x * sc, bv.y * sc, bv.z * sc, bv.w * sc};
+    if (a != nullptr) {
+        const float4 av = *reinterpret_cast<const float4*>(a + i);
+        r[0] += av.x; r[1] += av.y; r[2] += av.z; r[3] += av.w;
+    }
+    if constexpr (sizeof(TO) == 4) *reinterpret_cast<float4*>(out + i) = make_float4(r[0], r[1], r[2], r[3]);
+    else store4<TO>(out + i, r);
+}
+
 }  // namespace cir
 
 using namespace cir;
+
+extern "C" int cir_rows_scale_add(const float* a, const float* b, const float* scale, void* out, int64_t rows, int cols, int64_t rows_per_group,
+                                  int out_dtype, void* stream) {
+    CIR_CHECK_PTR(b); CIR_CHECK_PTR(scale); CIR_CHECK_PTR(out);
+    if (rows <= 0 || cols <= 0 || rows_per_group <= 0) return CIR_EINVAL;
+    if (cols % 4 != 0) return CIR_ESHAPE;
+    if (!cir_aligned16(a) || !cir_aligned16(b) || (reinterpret_cast<uintptr_t>(out) & (out_dtype == CIR_F32 ? 15u : 7u))) return CIR_EALIGN;
+    const int64_t n4 = rows * cols / 4;
+    dim3 grid((unsigned)((n4 + 255) / 256)), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (out_dtype == CIR_F32) hipLaunchKernelGGL((rows_scale_add_kernel<float>), grid, block, 0, s, a, b, scale, reinterpret_cast<float*>(out), rows, cols, rows_per_group);
+    else if (out_dtype == CIR_BF16) hipLaunchKernelGGL((rows_scale_add_kernel<__bf16>), grid, block, 0, s, a, b, scale, reinterpret_cast<__bf16*>(out), rows, cols, rows_per_group);
+    else if (out_dtype == CIR_F16) hipLaunchKernelGGL((rows_scale_add_kernel<_Float16>), grid, block, 0, s, a, b, scale, reinterpret_cast<_Float16*>(out), rows, cols, rows_per_group);
+    else return CIR_EDTYPE;
+    CIR_LAUNCH_RESULT();
+}
 
 extern "C" int cir_residual_layernorm_train(const float* t0, const float* t1, const float* residual, const float* gamma, const float* beta, float* pre,
                                             float* y32, void* y16, int64_t rows, int cols, float eps, float alpha, float p_drop, uint64_t seed,

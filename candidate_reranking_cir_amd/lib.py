@@ -69,6 +69,7 @@ SIGNATURES = {
     "cir_transpose16_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "cir_wgrad_grouped": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "cir_wgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "cir_rows_scale_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_void_p]),
     "cir_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "cir_eltwise": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_uint64, c_void_p]),
     "cir_colsum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),

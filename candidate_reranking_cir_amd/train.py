@@ -130,17 +130,21 @@ class _Lin:
         has_bias = (names[0] + ".bias") in slab.off
         self.slab = slab
         self.ws, self.bs = [n + ".weight" for n in names], ([n + ".bias" for n in names] if has_bias else None)
-        self.w16 = slab.span(slab.flat16, self.ws)                                  # (N, K): forward operand
         off, n, tail = slab.span_range(self.ws)
-        self.w16t = slab.flat16t[off:off + n * tail[0]].view(tail[0], n)            # (K, N): dgrad operand
-        self.transpose_entry = (off, n, tail[0])
+        k = 1
+        for t in tail:                                                              # a conv kernel (N, C, p, p) is the (N, C p p) Linear over patches
+            k *= t
+        self.n, self.k, self.off_w = n, k, off
+        self.w16 = slab.flat16[off:off + n * k].view(n, k)                          # (N, K): forward operand
+        self.w16t = slab.flat16t[off:off + n * k].view(k, n)                        # (K, N): dgrad operand
+        self.transpose_entry = (off, n, k)
         self.bias = slab.span(slab.flat32, self.bs) if has_bias else None
         self._g = None
 
     def _grads(self):
         g = self.slab.gflat
         if self._g is not g:
-            self._g, self._dw = g, self.slab.span(g, self.ws)
+            self._g, self._dw = g, g[self.off_w:self.off_w + self.n * self.k].view(self.n, self.k)
             self._db = self.slab.span(g, self.bs) if self.bs is not None else None
 
     @property
@@ -153,12 +157,12 @@ class _Lin:
         self._grads()
         return self._db
 
-    def fwd(self, x16: torch.Tensor, out_dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def fwd(self, x16: torch.Tensor, out_dtype: torch.dtype, out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         m, k = x16.shape
         n = self.w16.shape[0]
         if _gemm_ok(m, n, k):
-            return ops.gemm(x16, self.w16, self.bias, out_dtype=out_dtype, out=out)
-        assert out is None
+            return ops.gemm(x16, self.w16, self.bias, residual=residual, out_dtype=out_dtype, out=out)
+        assert out is None and residual is None
         y = T.bmm(x16.unsqueeze(0), self.w16.unsqueeze(0), False, True, out_dtype=torch.float32)[0]
         if self.bias is not None:
             y = T.eltwise(y, T.MODE_ADD, self.bias.unsqueeze(0).expand(m, n).contiguous())
@@ -259,6 +263,8 @@ class NlvrTrainer:
         self.dtype = model.compute_dtype
         self.step_no = 0
         self._hd = self.geo.hidden_size // self.geo.num_attention_heads
+        self.need_dfeats = False          # blip_img_tune (stage2_train.py:183-199): also return the gradient of the target image tokens
+        self.dfeats = None
         self._scale = self._hd ** -0.5
 
     # ------------------------------------------------------------------------------------------------ parameters
@@ -489,6 +495,8 @@ class NlvrTrainer:
         dh[sv["cls_rows"]] = dhid[:, :d]
         dh[sv["cls_rows"] + r] = dhid[:, d:]
         ph, b_n = self.p_hidden, sv["b_n"]
+        dfeats = torch.empty((b_n * n, sv["cand16"].shape[1]), dtype=torch.float32, device=dev) if self.need_dfeats else None
+        dfeats_live = False
         for i in reversed(range(len(self.layers))):
             ly, s = self.layers[i], sv["layers"][i]
             w1, w2 = ly["w1"], ly["w2"]
@@ -519,7 +527,11 @@ class NlvrTrainer:
                 dckv16 = torch.empty((b_n * n, 2 * d), dtype=dt, device=dev)
                 self._attn_bwd(dc16, self._heads(cq, b_n, b_n * l), self._heads(ckv, b_n, n, 0, 2), self._heads(ckv, b_n, n, 1, 2), s["ca"][b],
                                self._heads(dcq16, b_n, b_n * l), self._heads(dckv16, b_n, n, 0, 2), self._heads(dckv16, b_n, n, 1, 2))
-                ly[f"ckv{b}"].bwd16(sv["cand16"], dckv16, need_dx=False, bias=True, queue=wq)  # image tokens are inputs: no gradient beyond the weights
+                if dfeats is None:                                                  # image tokens are inputs: no gradient beyond the weights
+                    ly[f"ckv{b}"].bwd16(sv["cand16"], dckv16, need_dx=False, bias=True, queue=wq)
+                else:                                                               # ViT fine-tuning: every layer and branch adds its share
+                    ly[f"ckv{b}"].bwd16(sv["cand16"], dckv16, bias=True, queue=wq, out=dfeats, residual=dfeats if dfeats_live else None)
+                    dfeats_live = True
                 da = ly[f"cq{b}"].bwd16(s["a16"][b], dcq16, residual=dpre2[b], bias=True, queue=wq)
                 o = ly[f"o{b}"]
                 dpre1, dt16 = ly[f"ln1{b}"].bwd_res(s["pre1"][b], da, dt, dbias=o.db, p_drop=ph, seed=self._site(i, b, 2))
@@ -535,6 +547,8 @@ class NlvrTrainer:
         de = dh[r:] if ph <= 0 else T.eltwise(dh[r:], T.MODE_DROPOUT, p_drop=ph, seed=self._site(9000))
         dpre_e = self.ln_e.bwd(sv["pre_e"], de)
         T.embed_bwd(sv["ids"].view(-1), dpre_e, self.dword, self.dpos, l)
+        # the loss-scaled gradient of the target tokens, unscaled for the ViT's own (separately scaled) reverse pass
+        self.dfeats = None if dfeats is None else (dfeats if self.grad_scale == 1.0 else T.eltwise(dfeats, T.MODE_SCALE, p_drop=1.0 / self.grad_scale))
         return self._collect()
 
     def _collect(self) -> Dict[str, torch.Tensor]:
@@ -548,6 +562,26 @@ class NlvrTrainer:
         return {n: slab.grad(n) for n in slab.names}
 
 
+def _install_grads(tr, grads: Dict[str, torch.Tensor]):
+    """Accumulate a trainer's gradients into `.grad` as autograd's AccumulateGrad would (a first gradient is the trainer's own slice of its
+    flat gradient buffer - no copy).  Gradient accumulation over micro-batches (stage2_train.py's grad_accumulation_step): when every .grad
+    is still a slice of the flat buffer a previous backward installed, ONE flat add folds it into the new buffer and .grad is re-pointed to
+    the new slices - so the optimizer keeps its one-launch flat path (per-tensor adds: ~570 launches, and AdamW falls back to 570 more)."""
+    slab = tr.slab
+    live = [(n, slab.params[n]) for n in slab.names if n in grads and slab.params[n].requires_grad]
+    prev = getattr(tr, "acc_gflat", None)
+    if (prev is not None and prev is not slab.gflat and prev.numel() == slab.gflat.numel()
+            and all(p.grad is not None and p.grad.data_ptr() == prev.data_ptr() + 4 * slab.off[n] and p.grad.is_contiguous() for n, p in live)):
+        slab.gflat = T.eltwise(slab.gflat, T.MODE_ADD, prev)
+        for n, p in live:
+            p.grad = slab.grad(n)
+    else:
+        for n, p in live:
+            gq = grads[n]
+            p.grad = gq if p.grad is None else T.eltwise(p.grad.contiguous(), T.MODE_ADD, gq.contiguous())
+    tr.acc_gflat = slab.gflat
+
+
 class _FusionTrainFn(torch.autograd.Function):
     """One autograd node around NlvrTrainer.forward / backward: `loss.backward()` of the reference's training step reaches
     the hand-written reverse pass through it.  `anchor` is a one-element leaf that only makes the node differentiable; the
@@ -557,6 +591,7 @@ class _FusionTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, trainer, z_t, feats, ids, mask):
         ctx.trainer = trainer
+        ctx.feats_shape = tuple(feats.shape)
         out = trainer.forward(z_t, feats, ids, mask)
         # The saved activations, the dropout site counter and the flat gradient buffer are single slots on the trainer: this
         # node may only be differentiated while they still belong to ITS forward, and only once.
@@ -576,34 +611,24 @@ class _FusionTrainFn(torch.autograd.Function):
                                "reverse pass keeps one gradient buffer per forward; run the forward again")
         tr.consumed = True
         grads = tr.backward(dlogits.contiguous().float())
-        slab = tr.slab
-        live = [(n, p) for n, p in tr.model.named_parameters() if n in grads and p.requires_grad]
-        # Gradient accumulation over micro-batches (stage2_train.py's grad_accumulation_step): when every .grad is still a slice of the
-        # flat buffer a previous backward installed, ONE flat add folds it into the new buffer and .grad is re-pointed to the new
-        # slices - so the optimizer keeps its one-launch flat path (per-tensor adds: ~570 launches, and AdamW falls back to 570 more)
-        prev = getattr(tr, "acc_gflat", None)
-        if (prev is not None and prev is not slab.gflat and prev.numel() == slab.gflat.numel()
-                and all(p.grad is not None and p.grad.data_ptr() == prev.data_ptr() + 4 * slab.off[n] and p.grad.is_contiguous() for n, p in live)):
-            slab.gflat = T.eltwise(slab.gflat, T.MODE_ADD, prev)
-            for n, p in live:
-                p.grad = slab.grad(n)
-        else:
-            for n, p in live:
-                gq = grads[n]
-                p.grad = gq if p.grad is None else T.eltwise(p.grad.contiguous(), T.MODE_ADD, gq.contiguous())
-        tr.acc_gflat = slab.gflat
-        return None, None, None, None, None, None
+        _install_grads(tr, grads)
+        dfeats = None if tr.dfeats is None else tr.dfeats.view(ctx.feats_shape)
+        tr.dfeats = None
+        return None, None, None, dfeats, None, None
 
 
 def fusion_train(model, z_t, feats, ids, mask, p_hidden: float = 0.1, p_attn: float = 0.1, seed: int = 0) -> torch.Tensor:
-    """(B, B) logits of `img_txt_fusion` in training mode, differentiable w.r.t. the model's text_encoder / cls_head parameters."""
-    if (torch.is_tensor(feats) and feats.requires_grad) or (torch.is_tensor(z_t) and z_t.requires_grad):
-        raise NotImplementedError("the image tokens / z_t require a gradient (blip_img_tune, stage2_train.py:183-199): the backward pass stops at "
-                                  "the two-branch encoder's inputs - compute them under torch.no_grad() as the reference's default does")
+    """(B, B) logits of `img_txt_fusion` in training mode, differentiable w.r.t. the model's text_encoder / cls_head parameters - and
+    w.r.t. the target image tokens when they require a gradient (blip_img_tune, stage2_train.py:191-199: the tokens then come from
+    `train_vit.vit_train`, whose reverse pass continues into the ViT)."""
+    if torch.is_tensor(z_t) and z_t.requires_grad:
+        raise NotImplementedError("z_t requires a gradient: the reference computes it from the frozen stage-I model under torch.no_grad() "
+                                  "(stage2_train.py:201-203); the backward pass stops at the two-branch encoder's z_t input")
     tr = getattr(model, "_trainer", None)
     if tr is None or (tr.p_hidden, tr.p_attn) != (float(p_hidden), float(p_attn)) or tr.dtype != model.compute_dtype:
         tr = model._trainer = NlvrTrainer(model, p_hidden, p_attn, seed)
         tr.anchor = torch.zeros((1,), device=z_t.device, requires_grad=True)
+    tr.need_dfeats = bool(torch.is_tensor(feats) and feats.requires_grad)
     return _FusionTrainFn.apply(tr.anchor, tr, z_t, feats, ids, mask)
 
 
@@ -620,7 +645,7 @@ class AdamW:
         self.lr, self.betas, self.eps, self.wd, self.t = lr, betas, eps, weight_decay, 0
         self.m: Dict[int, torch.Tensor] = {}
         self.v: Dict[int, torch.Tensor] = {}
-        self._flat = None                                     # (param storage ptr, m flat, v flat)
+        self._flats: Dict[int, tuple] = {}                    # param storage ptr -> (m flat, v flat)
 
     @staticmethod
     def _flat_range(tensors):
@@ -639,37 +664,51 @@ class AdamW:
         if not ps:
             return
         if self.model is not None:
-            tr = getattr(self.model, "_trainer", None)
-            if tr is not None and getattr(tr, "grads_finite", None) is not None and not bool(tr.grads_finite):
-                self.t -= 1                                   # non-finite fp16 gradients: skip this update like GradScaler.step would
-                self.skipped_steps = getattr(self, "skipped_steps", 0) + 1
-                return
+            for tr in (getattr(self.model, "_trainer", None), getattr(self.model, "_vit_trainer", None)):
+                if tr is not None and getattr(tr, "grads_finite", None) is not None and not bool(tr.grads_finite):
+                    self.t -= 1                               # non-finite fp16 gradients: skip this update like GradScaler.step would
+                    self.skipped_steps = getattr(self, "skipped_steps", 0) + 1
+                    return
             self.model._text_stale = True                     # the weights change HERE: the next eval / score call repacks
-        fp, fg = self._flat_range([p.data for p in ps]), self._flat_range([p.grad for p in ps])
-        if fp is not None and fg is not None and fp[1] == fg[1] and all(p.data_ptr() - fp[0] == p.grad.data_ptr() - fg[0] for p in ps):
-            n = fp[1]
-            if self._flat is None or self._flat[0] != fp[0]:
-                mf, vf = (torch.zeros((n,), dtype=torch.float32, device=ps[0].device) for _ in range(2))
-                for p in ps:                                  # carry over moments from per-tensor steps, then keep views
-                    o = (p.data_ptr() - fp[0]) // 4
-                    for store, flat in ((self.m, mf), (self.v, vf)):
-                        view = flat[o:o + p.numel()].view(p.shape)
-                        if id(p) in store:
-                            view.copy_(store[id(p)])
-                        store[id(p)] = view
-                self._flat = (fp[0], mf, vf)
-            base = ps[0].data.untyped_storage()
-            pflat = torch.empty(0, dtype=torch.float32, device=ps[0].device).set_(base, 0, (n,))
-            gflat = torch.empty(0, dtype=torch.float32, device=ps[0].device).set_(ps[0].grad.untyped_storage(), 0, (n,))
-            T.adamw_step(pflat, gflat, self._flat[1], self._flat[2], self.lr, self.betas, self.eps, self.wd, self.t)
-            return
+            if getattr(self.model, "_vit_trainer", None) is not None:
+                self.model._vit_stale = True
+        # one launch per FLAT STORAGE (the two-branch encoder's slab; the ViT's when it is fine-tuned), per tensor for what is left
+        groups: Dict[int, list] = {}
         for p in ps:
-            if id(p) not in self.m:
-                self.m[id(p)], self.v[id(p)] = torch.zeros_like(p, dtype=torch.float32), torch.zeros_like(p, dtype=torch.float32)
-            m, v = self.m[id(p)], self.v[id(p)]
-            if not (m.is_contiguous() and v.is_contiguous()):
-                m, v = self.m[id(p)], self.v[id(p)] = m.contiguous(), v.contiguous()
-            T.adamw_step(p.data, p.grad.contiguous(), m, v, self.lr, self.betas, self.eps, self.wd, self.t)
+            groups.setdefault(p.data.untyped_storage().data_ptr(), []).append(p)
+        for grp in groups.values():
+            if not self._step_flat(grp):
+                for p in grp:
+                    self._step_tensor(p)
+
+    def _step_flat(self, ps) -> bool:
+        fp, fg = self._flat_range([p.data for p in ps]), self._flat_range([p.grad for p in ps])
+        if not (fp is not None and fg is not None and fp[1] == fg[1] and all(p.data_ptr() - fp[0] == p.grad.data_ptr() - fg[0] for p in ps)):
+            return False
+        n = fp[1]
+        flat = self._flats.get(fp[0])
+        if flat is None:
+            mf, vf = (torch.zeros((n,), dtype=torch.float32, device=ps[0].device) for _ in range(2))
+            for p in ps:                                      # carry over moments from per-tensor steps, then keep views
+                o = (p.data_ptr() - fp[0]) // 4
+                for store, fl in ((self.m, mf), (self.v, vf)):
+                    view = fl[o:o + p.numel()].view(p.shape)
+                    if id(p) in store:
+                        view.copy_(store[id(p)])
+                    store[id(p)] = view
+            flat = self._flats[fp[0]] = (mf, vf)
+        pflat = torch.empty(0, dtype=torch.float32, device=ps[0].device).set_(ps[0].data.untyped_storage(), 0, (n,))
+        gflat = torch.empty(0, dtype=torch.float32, device=ps[0].device).set_(ps[0].grad.untyped_storage(), 0, (n,))
+        T.adamw_step(pflat, gflat, flat[0], flat[1], self.lr, self.betas, self.eps, self.wd, self.t)
+        return True
+
+    def _step_tensor(self, p):
+        if id(p) not in self.m:
+            self.m[id(p)], self.v[id(p)] = torch.zeros_like(p, dtype=torch.float32), torch.zeros_like(p, dtype=torch.float32)
+        m, v = self.m[id(p)], self.v[id(p)]
+        if not (m.is_contiguous() and v.is_contiguous()):
+            m, v = self.m[id(p)], self.v[id(p)] = m.contiguous(), v.contiguous()
+        T.adamw_step(p.data, p.grad.contiguous(), m, v, self.lr, self.betas, self.eps, self.wd, self.t)
 
     def zero_grad(self):
         for p in self.params:

@@ -253,6 +253,18 @@ def gelu_bwd16(df: torch.Tensor, z: torch.Tensor, sums: Optional[torch.Tensor] =
     return out
 
 
+def rows_scale_add(a: Optional[torch.Tensor], b: torch.Tensor, scale: torch.Tensor, rows_per_group: int, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """out = a + scale[row // rows_per_group] * b (a None: the scaled b alone) - fp32 (rows, cols) inputs, scale fp32 (groups); DropPath."""
+    _need_cuda(a, b, scale)
+    rows, cols = b.shape
+    assert b.dtype == scale.dtype == torch.float32 and b.is_contiguous() and scale.is_contiguous() and scale.numel() * rows_per_group == rows
+    assert a is None or (a.dtype == torch.float32 and a.shape == b.shape and a.is_contiguous())
+    out = torch.empty((rows, cols), dtype=out_dtype, device=b.device)
+    _lib.check(_lib.load().cir_rows_scale_add(_ptr(a), b.data_ptr(), scale.data_ptr(), out.data_ptr(), rows, cols, int(rows_per_group), _DT[out_dtype],
+                                              _stream()), "cir_rows_scale_add")
+    return out
+
+
 def eltwise(z: torch.Tensor, mode: int, dy: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, p_drop: float = 0.0,
             seed: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Elementwise modes of cir_eltwise on contiguous tensors (see the MODE_* constants)."""

@@ -288,6 +288,12 @@ int cir_layernorm_bwd_fused(const float* x, const float* gamma, const float* dy,
  * sums[c] += sum_r out[r][c] - BertIntermediate's adjoint (nlvr_encoder.py:383-396) with the bias gradient in the same pass. */
 int cir_rows16_colsum(const void* a, int64_t lda, const void* z, int64_t ldz, void* out, int64_t ldo, float* sums, int64_t rows, int cols, int mode,
                       int dtype, void* stream);
+/* out[r] = a[r] + scale[r / rows_per_group] * b[r] over rows of `cols` fp32 values (a may be NULL: out = scale * b); out fp32 or 16-bit
+ * (out_dtype).  DropPath - timm's per-sample stochastic depth around both branches of a ViT block (vit.py:98-109; blip_stage2.py:37 builds the
+ * stage-II image encoder with drop_path_rate 0.1) - in the ViT fine-tuning pass: the forward adds the sample-scaled branch to the stream, the
+ * backward writes the sample-scaled stream gradient as the 16-bit operand of the branch's adjoint products.  cols % 4 == 0. */
+int cir_rows_scale_add(const float* a, const float* b, const float* scale, void* out, int64_t rows, int cols, int64_t rows_per_group, int out_dtype,
+                       void* stream);
 /* mode 0: out = gelu(z) (erf form, ACT2FN['gelu']); 1: out = dy * gelu'(z); 2: relu(z); 3: dy * (z > 0); 4: dropout(z, p_drop, seed);
  * 5: z + dy; 6: p_drop * z (scale).  z in z_dtype (CIR_F32 / CIR_BF16 / CIR_F16), dy fp32, out in out_dtype. */
 int cir_eltwise(const void* z, int z_dtype, const float* dy, void* out, int out_dtype, int64_t n, int mode, float p_drop, uint64_t seed, void* stream);

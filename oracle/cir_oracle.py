@@ -78,8 +78,10 @@ def encoder_mask_additive(attention_mask: torch.Tensor) -> torch.Tensor:
 # ViT-B/16 (vit.py) + timm PatchEmbed
 # ----------------------------------------------------------------------------------------------
 def vit_forward(w: Weights, image: torch.Tensor, prefix: str = "visual_encoder.", n_heads: Optional[int] = None,
-                patch: int = 16, eps: float = 1e-6) -> torch.Tensor:
-    """VisionTransformer.forward, vit.py:180-194 (eval mode: dropout / DropPath are identity)."""
+                patch: int = 16, eps: float = 1e-6, branch_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """VisionTransformer.forward, vit.py:180-194 (eval mode: dropout / DropPath are identity).  `branch_scale` ((depth, 2, B), optional):
+    DropPath with GIVEN per-sample factors (0 = dropped, 1 / keep = kept; vit.py:98-109 with timm's DropPath) on the attention [.., 0, ..]
+    and MLP [.., 1, ..] branch of every block - the train-mode function for one fixed draw, differentiable like the rest."""
     pw = w[prefix + "patch_embed.proj.weight"]
     d = pw.shape[0]
     if n_heads is None:
@@ -101,10 +103,11 @@ def vit_forward(w: Weights, image: torch.Tensor, prefix: str = "visual_encoder."
         a = (q @ k.transpose(-2, -1)) * ((d // n_heads) ** -0.5)               # vit.py:75
         a = a.softmax(dim=-1)                                                  # vit.py:76
         y = (a @ v).transpose(1, 2).reshape(b, n, d)                           # vit.py:83
-        x = x + _lin(w, p + "attn.proj", y)                                    # vit.py:84, :108
+        y = _lin(w, p + "attn.proj", y)                                        # vit.py:84
+        x = x + (y if branch_scale is None else y * branch_scale[i, 0].view(b, 1, 1))      # vit.py:108
         y = _ln(w, p + "norm2", x, eps)
         y = _lin(w, p + "mlp.fc2", F.gelu(_lin(w, p + "mlp.fc1", y)))          # vit.py:35-41
-        x = x + y                                                              # vit.py:109
+        x = x + (y if branch_scale is None else y * branch_scale[i, 1].view(b, 1, 1))      # vit.py:109
     return _ln(w, prefix + "norm", x, eps)                                     # vit.py:192
 
 

@@ -213,3 +213,36 @@ def test_training_step_gradients(fixture):
     for key in z.files:
         if key.startswith("full__"):
             np.testing.assert_allclose(w[key[6:]].grad.numpy(), z[key], atol=1e-3 * np.abs(z[key]).max() + 1e-7 * gmax, err_msg=key)
+
+
+def test_training_step_gradients_with_vit_fine_tuning():
+    """`--blip-img-tune` (stage2_train.py:87-92, 191-199): the oracle's autograd through O.vit_forward + O.img_txt_fusion_train against ONE
+    step of the real reference with the image encoder trained (tests/golden/train_imgtune.npz, `oracle/make_golden.py train imgtune`):
+    target tokens, logits, loss, the SET of parameters with a gradient (572 text-side + 30 ViT), every gradient's norm and 64 samples."""
+    import json
+    import torch.nn.functional as F
+    from candidate_reranking_cir_amd import synthetic
+    z = H.load("train_imgtune.npz")
+    g, v = H.geometry(json.loads(str(z["bert_cfg"])), json.loads(str(z["vit_cfg"])))
+    sd2, _ = H.state_dicts(g, v, int(z["seed"]), str(z["profile"]))
+    torch.set_num_threads(8)
+    w = {k: t.clone().float() for k, t in sd2.items()}
+    keys = [k for k in w if k.startswith(("text_encoder.", "cls_head.", "visual_encoder.")) and w[k].is_floating_point()]
+    for k in keys:
+        w[k].requires_grad_(True)
+    feats = O.vit_forward(w, synthetic.scene_images(z["image_ids"].tolist(), v.image_size))
+    np.testing.assert_allclose(feats.detach().numpy(), z["feats"], atol=2e-4)
+    bsz = z["input_ids"].shape[0]
+    logits = O.img_txt_fusion_train(w, torch.from_numpy(z["z_t"]), feats, torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]))
+    loss = F.cross_entropy(logits, torch.arange(bsz))
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().numpy(), z["logits"], atol=2e-4)
+    assert abs(loss.item() - float(z["loss"])) < 1e-4
+    names = [str(n) for n in z["names"]]
+    assert sorted(names) == sorted(k for k in keys if w[k].grad is not None) and sum(n.startswith("visual_encoder.") for n in names) == 30
+    gmax = float(z["norms"].max())
+    for i, n in enumerate(names):
+        gq = w[n].grad.flatten()
+        assert abs(gq.double().norm().item() - float(z["norms"][i])) < 1e-3 * float(z["norms"][i]) + 1e-7 * gmax, n
+        got = gq[torch.from_numpy(H.grad_sample_index(gq.numel()))].numpy()
+        np.testing.assert_allclose(got, z["samples"][i], atol=1e-3 * float(z["norms"][i]) / np.sqrt(gq.numel()) * 8 + 1e-7 * gmax, err_msg=n)

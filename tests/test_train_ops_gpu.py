@@ -421,3 +421,16 @@ def test_transpose16_multi(T):
     plan.run(src, dst)
     for o, r, c in entries:
         assert torch.equal(dst[o:o + r * c].view(c, r), src[o:o + r * c].view(r, c).t())
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float32, HF, BF], ids=["f32", "fp16", "bf16"])
+def test_rows_scale_add(T, out_dtype):
+    """cir_rows_scale_add (DropPath): out = a + scale[row // rows_per_group] * b, and the scaled b alone as a 16-bit operand."""
+    groups, rpg, cols = 5, 17, 132
+    a, b = _r((groups * rpg, cols), 71), _r((groups * rpg, cols), 72)
+    sc = torch.tensor([0.0, 2.5, 1.0, 0.0, 1.25], device="cuda")
+    ref = a + sc.repeat_interleave(rpg)[:, None] * b
+    out = T.rows_scale_add(a, b, sc, rpg, out_dtype=out_dtype)
+    assert out.dtype == out_dtype and torch.equal(out, ref.to(out_dtype))
+    only = T.rows_scale_add(None, b, sc, rpg, out_dtype=out_dtype)
+    assert torch.equal(only, (sc.repeat_interleave(rpg)[:, None] * b).to(out_dtype))

@@ -1,0 +1,163 @@
+"""ViT fine-tuning inside the stage-II training step (`--blip-img-tune`, stage2_train.py:87-92, 191-199; candidate_reranking_cir_amd/
+train_vit.py) on a real MI355X: against ONE step of the real reference with the image encoder trained (tests/golden/train_imgtune.npz,
+DropPath and dropouts off), against torch autograd through the CPU oracle with DropPath ON (the trainer's own per-sample draw handed to
+the oracle), and the optimizer / engine bookkeeping around a fine-tuned ViT.  Tolerances follow tests/test_train_gpu.py: relative L2 per
+tensor, measured values printed with -s."""
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from candidate_reranking_cir_amd import synthetic
+from tests import helpers as H
+from tests.test_train_gpu import BF, HF, GOLDEN_REL, GOLDEN_REL_MEAN, GRAD_REL, GRAD_REL_MEAN, LOGIT_ABS, build
+
+pytestmark = pytest.mark.gpu
+FEATS_ABS = {BF: 6e-2, HF: 8e-3}          # image tokens (sigma ~1) against the reference's fp32 ones
+
+
+@pytest.fixture(scope="module")
+def cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda")
+
+
+def _setup(dtype):
+    z = H.load("train_imgtune.npz")
+    g, v = H.geometry(json.loads(str(z["bert_cfg"])), json.loads(str(z["vit_cfg"])))
+    m2, sd2 = build(g, v, int(z["seed"]), str(z["profile"]), dtype)
+    images = synthetic.scene_images(z["image_ids"].tolist(), v.image_size)
+    return z, g, v, m2, sd2, images
+
+
+@pytest.mark.parametrize("dtype", [BF, HF], ids=["bf16", "fp16"])
+def test_vit_fine_tuning_step_matches_reference(cuda, dtype):
+    z, g, v, m2, sd2, images = _setup(dtype)
+    assert v.drop_path_rate == 0.0 and g.hidden_dropout_prob == 0.0
+    bsz = z["input_ids"].shape[0]
+    m2.train()
+    feats = m2.img_embed(images.cuda())                                       # train mode + autograd + trainable ViT: carries a graph
+    assert feats.requires_grad and feats.dtype == torch.float32
+    e_f = np.abs(feats.detach().cpu().numpy() - z["feats"]).max()
+    caps = [str(c) for c in z["caps"]]
+    logits = m2.img_txt_fusion(torch.from_numpy(z["z_t"]).cuda(), feats.float(), caps, train=True)
+    loss = F.cross_entropy(logits, torch.arange(bsz, device=cuda))
+    loss.backward()
+    e_log = np.abs(logits.detach().cpu().numpy() - z["logits"]).max()
+    params = dict(m2.named_parameters())
+    names = [str(n) for n in z["names"]]
+    assert sorted(names) == sorted(n for n, p in params.items() if p.grad is not None), "set of parameters that received a gradient"
+    assert sum(n.startswith("visual_encoder.") for n in names) == 30
+    gmax = float(z["norms"].max())
+    worst, num, den = (0.0, ""), 0.0, 0.0
+    for i, n in enumerate(names):
+        gq = params[n].grad.detach().flatten()
+        ref_norm = float(z["norms"][i])
+        if ref_norm < 1e-6 * gmax:
+            assert gq.double().norm().item() < 1e-3 * gmax, n
+            continue
+        got = gq[torch.from_numpy(H.grad_sample_index(gq.numel())).cuda()].cpu().numpy()
+        e = max(float(np.sqrt(np.mean((got - z["samples"][i]) ** 2)) / (ref_norm / np.sqrt(gq.numel()))), abs(gq.double().norm().item() - ref_norm) / ref_norm)
+        worst = max(worst, (e, n))
+        num, den = num + e * ref_norm, den + ref_norm
+    print(f"\n[train_imgtune {dtype}] tokens {e_f:.3e}  logits {e_log:.3e}  loss {loss.item():.5f} vs {float(z['loss']):.5f}  worst grad rel {worst[0]:.3e} "
+          f"({worst[1]})  norm-weighted mean {num / den:.3e}")
+    assert e_f < FEATS_ABS[dtype] and e_log < 2 * LOGIT_ABS[dtype] and abs(loss.item() - float(z["loss"])) < 2 * LOGIT_ABS[dtype]
+    assert worst[0] < GOLDEN_REL[dtype] and num / den < GOLDEN_REL_MEAN[dtype]
+    # the backward arithmetic proper: autograd of the oracle (ViT included) on the ReLU piece this forward took, full tensors
+    from oracle import cir_oracle as O
+    w = {k: t.clone().float() for k, t in sd2.items()}
+    for k in names:
+        w[k].requires_grad_(True)
+    torch.set_num_threads(8)
+    o_logits = O.img_txt_fusion_train(w, torch.from_numpy(z["z_t"]), O.vit_forward(w, images), torch.from_numpy(z["input_ids"]),
+                                      torch.from_numpy(z["attention_mask"]), relu_mask=m2._trainer.head_mask().cpu())
+    F.cross_entropy(o_logits, torch.arange(bsz)).backward()
+    res = {}
+    for part in ("visual_encoder.", "text"):
+        w_e, tot, cnt = (0.0, ""), 0.0, 0
+        for n in names:
+            if n.startswith("visual_encoder.") != (part == "visual_encoder."):
+                continue
+            r = w[n].grad
+            if r.norm().item() < 1e-6 * gmax:
+                continue
+            e = ((params[n].grad.cpu() - r).norm() / r.norm()).item()
+            w_e = max(w_e, (e, n))
+            tot, cnt = tot + e, cnt + 1
+        res[part] = (w_e, tot / cnt)
+        print(f"[train_imgtune {dtype}] same ReLU piece, {part:15s} worst grad rel {w_e[0]:.3e} ({w_e[1]})  mean {tot / cnt:.3e}")
+    assert res["text"][0][0] < GRAD_REL[dtype] and res["text"][1] < GRAD_REL_MEAN[dtype]
+    assert res["visual_encoder."][0][0] < 1.5 * GRAD_REL[dtype] and res["visual_encoder."][1] < 2 * GRAD_REL_MEAN[dtype]   # a 2-block ViT behind 24 K|V projections
+    m2.eval()
+
+
+def test_drop_path_against_oracle_with_the_same_draw(cuda):
+    """DropPath at rate 0.6 (block 1 of 2 drops each sample's branches with probability 0.6): tokens and ViT gradients against the oracle's
+    autograd with the trainer's own per-sample factors; the draw is a function of (seed, step): reproducible, different from step to step."""
+    from candidate_reranking_cir_amd.train_vit import VitTrainer
+    from oracle import cir_oracle as O
+    z, g, v, m2, sd2, images = _setup(HF)
+    m2.vit_geometry.drop_path_rate = 0.6
+    m2.train()
+    b8 = torch.cat([images, images.flip(0)])                                   # 8 samples: enough for both outcomes
+    feats = m2.img_embed(b8.cuda())
+    tr = m2._vit_trainer
+    dp = tr.sv["dp"].cpu()
+    assert dp.shape == (2, 2, 8) and torch.all(dp[0] == 1.0) and set(np.round(dp[1].flatten().tolist(), 4)) == {0.0, 2.5}
+    gen = torch.Generator().manual_seed(3)
+    dfe = torch.randn(feats.shape, generator=gen) * 1e-3
+    feats.backward(dfe.cuda())
+    names = [n for n in sd2 if n.startswith("visual_encoder.")]
+    w = {k: t.clone().float() for k, t in sd2.items()}
+    for k in names:
+        w[k].requires_grad_(True)
+    ref = O.vit_forward(w, b8, branch_scale=dp)
+    assert (feats.detach().cpu() - ref.detach()).abs().max().item() < FEATS_ABS[HF]
+    (ref * dfe).sum().backward()
+    params = dict(m2.named_parameters())
+    worst = max((((params[n].grad.cpu() - w[n].grad).norm() / w[n].grad.norm()).item(), n) for n in names)
+    print(f"\n[drop path 0.6, fp16] worst ViT grad rel {worst[0]:.3e} ({worst[1]})")
+    assert worst[0] < GRAD_REL[HF]
+    # the same (seed, step) reproduces the draw; the next step draws again
+    t2 = VitTrainer(m2)
+    t2.forward(b8.cuda())
+    assert torch.equal(t2.sv["dp"].cpu(), dp)
+    t2.forward(b8.cuda())
+    assert not torch.equal(t2.sv["dp"].cpu(), dp)
+    m2.eval()
+
+
+def test_optimizer_and_engine_follow_a_fine_tuned_vit(cuda):
+    """AdamW takes its one-launch path on BOTH flat buffers (two-branch encoder, ViT); after the step the eval-mode `img_embed` (the packed
+    inference engine) runs on the UPDATED ViT: it equals the training forward at DropPath 0 on the new weights, not the old tokens."""
+    from candidate_reranking_cir_amd.train import AdamW
+    z, g, v, m2, sd2, images = _setup(HF)
+    bsz = z["input_ids"].shape[0]
+    m2.eval()
+    before = m2.img_embed(images.cuda()).clone()
+    m2.train()
+    opt = AdamW([p for p in m2.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.0, model=m2)
+    feats = m2.img_embed(images.cuda())
+    logits = m2.img_txt_fusion(torch.from_numpy(z["z_t"]).cuda(), feats, [str(c) for c in z["caps"]], train=True)
+    F.cross_entropy(logits, torch.arange(bsz, device=cuda)).backward()
+    opt.step()
+    assert len(opt._flats) == 2 and getattr(opt, "skipped_steps", 0) == 0
+    m2.eval()
+    after = m2.img_embed(images.cuda())
+    assert (after - before).abs().max().item() > 1e-2                       # lr 1e-3 on every ViT weight: the tokens moved
+    m2.train()
+    with torch.enable_grad():
+        again = m2.img_embed(images.cuda()).detach()
+    m2.eval()
+    assert (after - again).abs().max().item() < FEATS_ABS[HF]
+    # mini-batched embedding calls whose backward is all needed are refused loudly (one saved-activation slot)
+    m2.train()
+    f1 = m2.img_embed(images[:2].cuda())
+    f2 = m2.img_embed(images[2:].cuda())
+    with pytest.raises(RuntimeError, match="ONE call"):
+        (f1.sum() + f2.sum()).backward()
+    m2.eval()
