@@ -412,7 +412,7 @@ def train_mode(args, m2, m1, dev, dt):
     ids = torch.stack([synthetic.caption_ids(q, l) for q in range(b)])
     enc = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
     for n, p in m2.named_parameters():
-        p.requires_grad_(not n.startswith("visual_encoder."))           # blip_img_tune False (stage2_train.py:87-92)
+        p.requires_grad_(args.img_tune or not n.startswith("visual_encoder."))   # blip_img_tune (stage2_train.py:87-92)
     m2.train()
     opt = AdamW([p for p in m2.parameters() if p.requires_grad], lr=2e-5, weight_decay=0.05)
     gt = torch.arange(b, device=dev)
@@ -428,8 +428,13 @@ def train_mode(args, m2, m1, dev, dt):
             return time.perf_counter()
         t = time.perf_counter()
         with torch.no_grad():
-            rf, tf = m2.img_embed(ref).float(), m2.img_embed(tgt).float()
-            t = mark("vit", t)
+            rf = m2.img_embed(ref).float()
+            if not args.img_tune:
+                tf = m2.img_embed(tgt).float()
+        if args.img_tune:                                       # stage2_train.py:191-199: the target tokens carry a graph (the reference's
+            tf = m2.img_embed(tgt).float()                      # own second graph, over the reference images, is never differentiated)
+        t = mark("vit", t)
+        with torch.no_grad():
             z = m1.img_txt_fusion(rf, rf, enc, train=False, return_raw=True)
             t = mark("z_t", t)
         opt.zero_grad()
@@ -453,14 +458,18 @@ def train_mode(args, m2, m1, dev, dt):
     step(True)
     n_tok = (args.image_size // 16) ** 2 + 1
     gf, gb = train_gflop(b, l, n_tok)
+    if args.img_tune:                                       # the backward leg then also holds the ViT's reverse pass over the B target images:
+        d = 768                                             # 2 x its forward flops (dgrad + wgrad of qkv / proj / fc1 / fc2, the attention adjoint)
+        gb += 2 * b * 12 * (2 * n_tok * d * (3 * d + d + 8 * d) + 4 * n_tok * n_tok * d) / 1e9
     fb_s = legs["fusion_forward"] + legs["backward"]
     cpu = None if args.no_cpu_baseline else train_cpu_baseline(usable_cpus(), m2.state_dict(), l, n_tok)
     print(json.dumps({
         "metric": "stage-II training step, query-target pairs (B x B) forward+backward per second (stage2_train.py loop; not the headline metric)",
         "value": round(b * b / dt_s, 1), "unit": "triplets/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt_s * 1e3, 2), "higher_is_better": True, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"batch {b} (B x B = {b * b} triplets), {l} caption tokens, {n_tok} image tokens ({args.image_size} px), ViT frozen, "
-                               f"dropout 0.1, AdamW; fp32 residual stream"},
+        "config": {"workload": f"batch {b} (B x B = {b * b} triplets), {l} caption tokens, {n_tok} image tokens ({args.image_size} px), {'ViT fine-tuned' if args.img_tune else 'ViT frozen'}, "
+                               f"dropout 0.1, AdamW; fp32 residual stream" + ("; --blip-img-tune: DropPath 0.1, the image encoder's reverse pass is part of the backward leg and of its flops"
+                                                                            if args.img_tune else "")},
         "legs_ms": {k: round(v * 1e3, 2) for k, v in legs.items()}, "legs_host_enqueue_ms": {k: round(v * 1e3, 2) for k, v in host.items()}, "loss": round(float(loss.detach()), 4),
         "algorithmic_gflop_per_step": {"fusion_forward": round(gf, 1), "backward": round(gb, 1)},
         "roofline": {"bound": "mfma", "achieved": round((gf + gb) / fb_s / 1e3, 1), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
@@ -527,6 +536,8 @@ def main():
     ap.add_argument("--mode", default="pixels", choices=["pixels", "bank", "loop", "train"],
                     help="pixels: headline metric (every candidate encoded from pixels); bank: SURVEY 8(f)-1 real-dataset regime, "
                          "candidates drawn from a resident index bank with cached ViT tokens and cross-attention K/V")
+    ap.add_argument("--img-tune", action="store_true", help="train mode: fine-tune the ViT too (stage2_train.py --blip-img-tune): target tokens with a "
+                    "graph, the reverse pass continues through the image encoder, AdamW over both parameter buffers")
     ap.add_argument("--train-batch", type=int, default=16, help="train mode: B of the B x B training step (Instructions_*.md: --batch-size 16)")
     ap.add_argument("--index-size", type=int, default=2297, help="bank mode: number of index images (CIRR val: 2297)")
     args = ap.parse_args()

@@ -19,6 +19,7 @@ python bench.py --mode bank --steps 10 --warmup 3 > $O/bench_bank_mode.json 2>> 
 python bench.py --mode loop > $O/bench_loop_mode.json 2>> $O/err.txt
 python bench.py --mode train --image-size 384 --steps 10 --warmup 3 > $O/bench_train_mode.json 2>> $O/err.txt                    # stage2_train.py step, B = 16
 python bench.py --mode train --image-size 384 --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_train_mode_bf16.json 2>> $O/err.txt
+python bench.py --mode train --image-size 384 --img-tune --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_train_mode_img_tune.json 2>> $O/err.txt                # --blip-img-tune: ViT reverse pass + second AdamW buffer
 python bench.py --mode train --image-size 224 --train-batch 32 --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_train_mode_b32_224.json 2>> $O/err.txt
 Q=64 python tools/gemm_shapes.py $O/gemm_shapes.json > $O/gemm_shapes.txt 2>> $O/err.txt
 python tools/gemm_ab.py > $O/gemm_ab.txt 2>> $O/err.txt
