@@ -617,6 +617,14 @@ class _FusionTrainFn(torch.autograd.Function):
         return None, None, None, dfeats, None, None
 
 
+def cosine_lr_schedule(optimizer, epoch: int, max_epoch: int, init_lr: float, min_lr: float) -> float:
+    """utils.cosine_lr_schedule (utils.py:216-221): the per-epoch decay stage2_train.py:159 applies; works on `AdamW` below and on torch.optim."""
+    lr = (init_lr - min_lr) * 0.5 * (1.0 + math.cos(math.pi * epoch / max_epoch)) + min_lr
+    for group in optimizer.param_groups:
+        group["lr"] = lr
+    return lr
+
+
 def fusion_train(model, z_t, feats, ids, mask, p_hidden: float = 0.1, p_attn: float = 0.1, seed: int = 0) -> torch.Tensor:
     """(B, B) logits of `img_txt_fusion` in training mode, differentiable w.r.t. the model's text_encoder / cls_head parameters - and
     w.r.t. the target image tokens when they require a gradient (blip_img_tune, stage2_train.py:191-199: the tokens then come from
@@ -642,10 +650,21 @@ class AdamW:
         (without it the training forward marks it, which misses an eval call made between backward() and step())."""
         self.model = model
         self.params = [p for p in params if p.requires_grad]
-        self.lr, self.betas, self.eps, self.wd, self.t = lr, betas, eps, weight_decay, 0
+        self.betas, self.eps, self.wd, self.t = betas, eps, weight_decay, 0
+        # torch.optim's surface as far as the reference's loop uses it: utils.cosine_lr_schedule (utils.py:216-221, called once per epoch at
+        # stage2_train.py:159) writes `param_group['lr']`; one group, its 'lr' is what step() applies
+        self.param_groups = [{"params": self.params, "lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}]
         self.m: Dict[int, torch.Tensor] = {}
         self.v: Dict[int, torch.Tensor] = {}
         self._flats: Dict[int, tuple] = {}                    # param storage ptr -> (m flat, v flat)
+
+    @property
+    def lr(self) -> float:
+        return self.param_groups[0]["lr"]
+
+    @lr.setter
+    def lr(self, value: float):
+        self.param_groups[0]["lr"] = value
 
     @staticmethod
     def _flat_range(tensors):

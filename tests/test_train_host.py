@@ -58,3 +58,17 @@ def test_train_flop_model():
     per_branch = 6 * 2 * r * d * d + 16 * r * d * d + 4 * r * l * d + 4 * r * n * d + 4 * (b * n) * d * d
     want = 12 * 2 * per_branch + 6 * 4 * r * d * d + 2 * b * b * (2 * d * d + 2 * d)
     assert abs(fwd * 1e9 - want) < 1e-6 * want and 1.8 * fwd < bwd < 2.0 * fwd
+
+
+def test_cosine_lr_schedule_drives_adamw():
+    """utils.cosine_lr_schedule's contract (utils.py:216-221): writes param_group['lr']; train.AdamW applies that value."""
+    import math
+    import torch
+    from candidate_reranking_cir_amd.train import cosine_lr_schedule
+    opt = AdamW([torch.nn.Parameter(torch.zeros(4))], lr=2e-5)
+    assert opt.lr == 2e-5 and opt.param_groups[0]["lr"] == 2e-5
+    lr = cosine_lr_schedule(opt, 5, 50, 2e-5, 0.0)
+    assert lr == opt.lr == opt.param_groups[0]["lr"] and abs(lr - 1e-5 * (1 + math.cos(math.pi * 0.1))) < 1e-12
+    assert cosine_lr_schedule(opt, 50, 50, 2e-5, 1e-6) == 1e-6
+    ref = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(4))], lr=2e-5)
+    assert cosine_lr_schedule(ref, 5, 50, 2e-5, 0.0) == lr and ref.param_groups[0]["lr"] == lr
