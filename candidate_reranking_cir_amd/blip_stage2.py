@@ -206,6 +206,8 @@ class BLIP_NLVR(_EngineHost):
         a trainable ViT (`--blip-img-tune`, stage2_train.py:87-92, 191-199) the tokens carry a graph: `train_vit.vit_train`, whose reverse
         pass fills `.grad` of every visual_encoder parameter; otherwise (eval mode, torch.no_grad(), frozen ViT) the inference engine."""
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for n, p in self.named_parameters() if n.startswith("visual_encoder.")):
+            if self.device.type != "cuda":
+                raise RuntimeError("BLIP_NLVR runs on an MI355X only: move the model to 'cuda' (no CPU path)")
             from .train_vit import vit_train
             y32 = vit_train(self, image)
         else:

@@ -497,6 +497,8 @@ __device__ __forceinline__ float gelu_grad(float x) {
 }
 // mode 0: y = gelu(z); 1: dz = dy * gelu'(z); 2: y = relu(z); 3: dz = dy * (z > 0); 4: y = dropout(z) [dy unused]; 5: y = z + dy (add);
 // 6: y = p_drop * z (scale by the factor passed in p_drop)
+// (Tried in round 4: the logistic-fit GELU of the inference epilogue for 16-bit outputs - the 2R x 3072 pass went 58 -> 54 us, it is bound
+//  by its 200 MB of traffic, not by erff - at the price of moving train197's worst same-piece gradient 1.5e-2 -> 1.75e-2: dropped.)
 __device__ __forceinline__ float eltwise_op(float v, float d, int mode, float p_drop, float keep, uint64_t seed, int64_t i) {
     switch (mode) {
         case 0: return gelu_exact(v);
@@ -521,8 +523,10 @@ __global__ __launch_bounds__(256) void eltwise_kernel(const TZ* z, const float* 
             const float4 z4 = *reinterpret_cast<const float4*>(z + i0);
             v[0] = z4.x; v[1] = z4.y; v[2] = z4.z; v[3] = z4.w;
         } else {
+            typedef __attribute__((ext_vector_type(4))) TZ tz4;                // one 8-byte load (i0 is a multiple of 4, the base 16-byte aligned)
+            const tz4 z4 = *reinterpret_cast<const tz4*>(z + i0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = static_cast<float>(z[i0 + e]);
+            for (int e = 0; e < 4; ++e) v[e] = static_cast<float>(z4[e]);
         }
         if (use_dy) {
             const float4 d4 = *reinterpret_cast<const float4*>(dy + i0);

@@ -264,7 +264,7 @@ class NlvrTrainer:
         self.step_no = 0
         self._hd = self.geo.hidden_size // self.geo.num_attention_heads
         self.need_dfeats = False          # blip_img_tune (stage2_train.py:183-199): also return the gradient of the target image tokens
-        self.dfeats = None
+        self.dfeats = self.dfeats_scale = None
         self._scale = self._hd ** -0.5
 
     # ------------------------------------------------------------------------------------------------ parameters
@@ -549,6 +549,7 @@ class NlvrTrainer:
         T.embed_bwd(sv["ids"].view(-1), dpre_e, self.dword, self.dpos, l)
         # the loss-scaled gradient of the target tokens, unscaled for the ViT's own (separately scaled) reverse pass
         self.dfeats = None if dfeats is None else (dfeats if self.grad_scale == 1.0 else T.eltwise(dfeats, T.MODE_SCALE, p_drop=1.0 / self.grad_scale))
+        self.dfeats_scale = None if dfeats is None else self.grad_scale            # train_vit.VitTrainer.backward runs under the same scale
         return self._collect()
 
     def _collect(self) -> Dict[str, torch.Tensor]:
@@ -696,7 +697,7 @@ class AdamW:
         for p in ps:
             groups.setdefault(p.data.untyped_storage().data_ptr(), []).append(p)
         for grp in groups.values():
-            if not self._step_flat(grp):
+            if len(grp) < 2 or not self._step_flat(grp):
                 for p in grp:
                     self._step_tensor(p)
 

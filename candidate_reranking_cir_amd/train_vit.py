@@ -132,10 +132,18 @@ class VitTrainer:
         dev = dfeats.device
         g = dfeats.contiguous().float().view(bsz * n, d)
         # fp16 operands: run the (linear) pass on S * dfeats, S a power of two putting the largest entry near 512 (train.NlvrTrainer.backward)
+        # When the gradient comes out of the two-branch encoder's reverse pass (the normal case), that pass's scale is reused: its own
+        # internal gradients - of which dfeats is a 24-term sum - sat in fp16's range under it, and reading max|dfeats| back would make the
+        # host wait for the whole fusion backward before the first ViT launch.
         self.grad_scale = 1.0
         if dt == torch.float16:
-            amax = float(g.abs().max())
-            self.grad_scale = 2.0 ** round(math.log2(512.0 / amax)) if amax > 0 and math.isfinite(amax) else 1.0
+            hint = getattr(getattr(self.model, "_trainer", None), "dfeats_scale", None)
+            if hint is not None:
+                self.grad_scale = float(hint)
+                self.model._trainer.dfeats_scale = None
+            else:
+                amax = float(g.abs().max())
+                self.grad_scale = 2.0 ** round(math.log2(512.0 / amax)) if amax > 0 and math.isfinite(amax) else 1.0
             if self.grad_scale != 1.0:
                 g = T.eltwise(g, T.MODE_SCALE, p_drop=self.grad_scale)
         g = self.lnf.bwd(sv["xf"], g)

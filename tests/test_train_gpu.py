@@ -313,19 +313,37 @@ def test_flat_adamw_matches_torch_adamw(cuda):
     m.eval()
 
 
-def test_inputs_requiring_grad_are_refused(cuda):
-    """blip_img_tune (a gradient into the ViT / stage I) is not built: asking for it fails loudly instead of returning no gradient."""
-    zf, g, v, _, _ = H.tiny_setup()
-    m = build(g, v, int(zf["seed"]), str(zf["profile"]), BF)[0]
+def test_inputs_requiring_grad(cuda):
+    """z_t comes from the frozen stage-I model (stage2_train.py:201-203): asking for its gradient fails loudly instead of returning none.
+    The target tokens may require one (blip_img_tune: round 4; the ViT's own reverse pass is tests/test_train_vit_gpu.py): their gradient is
+    the sum of the K|V projections' dgrads over all layers and branches - checked against the oracle's autograd."""
+    from oracle import cir_oracle as O
+    zf, g, v, sd2, _ = H.tiny_setup()
+    m = build(g, v, int(zf["seed"]), str(zf["profile"]), HF)[0]
+    freeze_vit(m)
     m.train()
+    g_tr = m.bert_geometry
+    g_tr.hidden_dropout_prob = g_tr.attention_probs_dropout_prob = 0.0
     caps = [synthetic.caption_text(90, 4), synthetic.caption_text(91, 6)]
-    l = H.tokenize(caps)[0].shape[1]
-    z_t = torch.randn((2, l, g.hidden_size), device=cuda)
-    feats = torch.randn((2, 17, g.encoder_width), device=cuda, requires_grad=True)
-    with pytest.raises(NotImplementedError, match="blip_img_tune"):
-        m.img_txt_fusion(z_t, feats, caps)
+    ids, mask = H.tokenize(caps)
+    gen = torch.Generator().manual_seed(8)
+    z_t = torch.randn((2, ids.shape[1], g.hidden_size), generator=gen)
+    feats = torch.randn((2, 17, g.encoder_width), generator=gen)
+    with pytest.raises(NotImplementedError, match="z_t requires a gradient"):
+        m.img_txt_fusion(z_t.cuda().requires_grad_(True), feats.cuda(), caps)
+    f_dev = feats.cuda().requires_grad_(True)
+    logits = m.img_txt_fusion(z_t.cuda(), f_dev, caps)
+    F.cross_entropy(logits, torch.arange(2, device=cuda)).backward()
+    assert f_dev.grad is not None and f_dev.grad.shape == feats.shape
+    w = {k: t.clone().float() for k, t in sd2.items()}
+    f_ref = feats.clone().requires_grad_(True)
+    o = O.img_txt_fusion_train(w, z_t, f_ref, ids, mask, relu_mask=m._trainer.head_mask().cpu())
+    F.cross_entropy(o, torch.arange(2)).backward()
+    rel = ((f_dev.grad.cpu() - f_ref.grad).norm() / f_ref.grad.norm()).item()
+    print(f"\n[gradient of the target tokens, fp16, tiny geometry] relative error {rel:.3e}")
+    assert rel < GRAD_REL[HF]
     with torch.no_grad():                                       # no graph asked for: the inference path, whatever the mode
-        assert m.img_txt_fusion(z_t, feats, caps).shape == (2, 2)
+        assert m.img_txt_fusion(z_t.cuda(), feats.cuda(), caps).shape == (2, 2)
     m.eval()
 
 
