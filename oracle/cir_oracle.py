@@ -46,11 +46,12 @@ def _heads(x: torch.Tensor, n_heads: int) -> torch.Tensor:
     return x.view(b, t, n_heads, d // n_heads).transpose(1, 2)  # (b, h, t, dh)
 
 
-def _sdpa(q, k, v, add_mask: Optional[torch.Tensor], n_heads: int) -> torch.Tensor:
+def _sdpa(q, k, v, add_mask: Optional[torch.Tensor], n_heads: int, pdrop=None) -> torch.Tensor:
     """softmax(q k^T / sqrt(dh) + mask) v with heads merged back.
 
     nlvr_encoder.py:175 (scores), :193 (scale), :194-196 (mask), :199 (softmax), :213-217
-    (context + head merge); identical text in med.py:193-235.
+    (context + head merge); identical text in med.py:193-235.  `pdrop` (optional callable): the dropout on the attention probabilities
+    (nlvr_encoder.py:207) with a GIVEN mask - see `nlvr_forward`'s `drop`.
     """
     qh, kh, vh = _heads(q, n_heads), _heads(k, n_heads), _heads(v, n_heads)
     s = qh @ kh.transpose(-1, -2)
@@ -58,6 +59,8 @@ def _sdpa(q, k, v, add_mask: Optional[torch.Tensor], n_heads: int) -> torch.Tens
     if add_mask is not None:
         s = s + add_mask
     p = torch.softmax(s, dim=-1)
+    if pdrop is not None:
+        p = pdrop(p)
     ctx = p @ vh
     b, h, t, dh = ctx.shape
     return ctx.transpose(1, 2).reshape(b, t, h * dh)
@@ -168,7 +171,7 @@ def stage1_z_t(w: Weights, ref_tokens: torch.Tensor, input_ids: torch.Tensor, at
 # ----------------------------------------------------------------------------------------------
 def nlvr_forward(w: Weights, input_ids: torch.Tensor, attention_mask: torch.Tensor, z_t: torch.Tensor,
                  cand: torch.Tensor, cand_mask: Optional[torch.Tensor] = None, prefix: str = "text_encoder.",
-                 n_heads: Optional[int] = None, eps: float = 1e-12, taps: Optional[list] = None) -> torch.Tensor:
+                 n_heads: Optional[int] = None, eps: float = 1e-12, taps: Optional[list] = None, drop=None) -> torch.Tensor:
     """nlvr_encoder.BertModel.forward, nlvr_encoder.py:777-908 -> (K, 2*D).
 
     Branch 0 starts from z_t, branch 1 from the caption embeddings (:891-892).  Per layer
@@ -177,8 +180,14 @@ def nlvr_forward(w: Weights, input_ids: torch.Tensor, attention_mask: torch.Tens
     or by `merge_layer` on the concatenation for layers >= 6 (:252-256, no activation); the
     merged tensor is added to each branch's residual and normalised by LayerNormA / LayerNormB;
     the FFN uses shared weights on both branches (:469-476).
+
+    `drop` (optional callable (kind, layer, branch, tensor) -> tensor): the train-mode dropouts with GIVEN masks, at the reference's sites -
+    "emb" (BertEmbeddings, :90), "self_attn" / "cross_attn" (attention probabilities, :207), "self_out" (BertSelfOutput after the dense,
+    :250-264), "cross_out" (the same module behind the merge / average: ONE mask, branch index 2), "ffn_out" (BertOutput, :397-409).  With it
+    this is the training-mode function for one fixed draw - tests hand it the masks the HIP kernels regenerate from their counters.
     """
-    emb = bert_embeddings(w, input_ids, prefix, eps)
+    D = (lambda kind, layer, b, x: x) if drop is None else drop
+    emb = D("emb", -1, 1, bert_embeddings(w, input_ids, prefix, eps))
     assert z_t.shape == emb.shape, "left and right inputs shall be the same shape"  # :891
     d = emb.shape[-1]
     n_heads = n_heads or d // 64
@@ -192,23 +201,26 @@ def nlvr_forward(w: Weights, input_ids: torch.Tensor, attention_mask: torch.Tens
         att = []
         for b in (0, 1):
             s = f"{p}attention.self{b}."
-            ctx = _sdpa(_lin(w, s + "query", h[b]), _lin(w, s + "key", h[b]), _lin(w, s + "value", h[b]), smask, n_heads)
-            o = _lin(w, f"{p}attention.output.dense{b}", ctx) + h[b]
+            ctx = _sdpa(_lin(w, s + "query", h[b]), _lin(w, s + "key", h[b]), _lin(w, s + "value", h[b]), smask, n_heads,
+                        pdrop=None if drop is None else (lambda pr, i=i, b=b: D("self_attn", i, b, pr)))
+            o = D("self_out", i, b, _lin(w, f"{p}attention.output.dense{b}", ctx)) + h[b]
             att.append(_ln(w, p + "attention.output.LayerNorm" + "AB"[b], o, eps))
         dd = []
         for b in (0, 1):
             s = f"{p}crossattention.self{b}."
-            ctx = _sdpa(_lin(w, s + "query", att[b]), _lin(w, s + "key", cand), _lin(w, s + "value", cand), emask, n_heads)
+            ctx = _sdpa(_lin(w, s + "query", att[b]), _lin(w, s + "key", cand), _lin(w, s + "value", cand), emask, n_heads,
+                        pdrop=None if drop is None else (lambda pr, i=i, b=b: D("cross_attn", i, b, pr)))
             dd.append(_lin(w, f"{p}crossattention.output.dense{b}", ctx))
         mkey = p + "crossattention.output.merge_layer"
         if mkey + ".weight" in w:                                              # layers >= 6
             m = _lin(w, mkey, torch.cat(dd, dim=-1))
         else:                                                                  # layers < 6
             m = (dd[0] + dd[1]) / 2
+        m = D("cross_out", i, 2, m)
         x = [_ln(w, p + "crossattention.output.LayerNorm" + "AB"[b], m + att[b], eps) for b in (0, 1)]
         for b in (0, 1):
             f = F.gelu(_lin(w, p + "intermediate.dense", x[b]))
-            h[b] = _ln(w, p + "output.LayerNorm", _lin(w, p + "output.dense", f) + x[b], eps)
+            h[b] = _ln(w, p + "output.LayerNorm", D("ffn_out", i, b, _lin(w, p + "output.dense", f)) + x[b], eps)
         if taps is not None:
             taps.append((h[0][:, 0, :8].clone(), h[1][:, 0, :8].clone()))
     return torch.cat([h[0][:, 0, :], h[1][:, 0, :]], dim=-1)                   # :906-908
@@ -229,7 +241,8 @@ def img_txt_fusion_val(w: Weights, z_t: torch.Tensor, cand: torch.Tensor, input_
 
 
 def img_txt_fusion_train(w: Weights, z_t: torch.Tensor, feats: torch.Tensor, input_ids: torch.Tensor,
-                          attention_mask: torch.Tensor, enc_token_id: int = 30523, relu_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+                          attention_mask: torch.Tensor, enc_token_id: int = 30523, relu_mask: Optional[torch.Tensor] = None,
+                          drop=None) -> torch.Tensor:
     """BLIP_NLVR.img_txt_fusion, blip_stage2.py:65-99 -> (B, B): row i runs caption i / z_t[i] (expanded to B rows, :83-87)
     against all B target images, rows stacked (:94), cls_head, column 0 (:96-99).  Dropout-free (p = 0 or eval mode);
     differentiable: with `requires_grad` weights, torch autograd over this function is the gradient oracle of the training
@@ -239,13 +252,15 @@ def img_txt_fusion_train(w: Weights, z_t: torch.Tensor, feats: torch.Tensor, inp
     the linear piece the mask selects.  The gradient of the head is discontinuous where a pre-activation crosses zero, so a
     16-bit forward whose pre-activations differ by 1e-3 takes a different piece for a handful of the B*B*hidden entries (each
     flip moves that row's whole gradient by ~1/sqrt(hidden/2)); tests that check the BACKWARD arithmetic pass the mask of the
-    forward under test, tests that check the forward leave it out."""
+    forward under test, tests that check the forward leave it out.  `drop` (optional callable (kind, layer, branch, query row i, tensor)):
+    the train-mode dropouts with given masks (`nlvr_forward`), called once per site and query row - each call sees the B candidates of row i."""
     b = z_t.shape[0]
     ids = input_ids.clone()
     ids[:, 0] = enc_token_id                                                   # blip_stage2.py:71
     rows = []
     for i in range(b):
-        hid = nlvr_forward(w, ids[i:i + 1].expand(b, -1), attention_mask[i:i + 1].expand(b, -1), z_t[i:i + 1].expand(b, -1, -1), feats)
+        hid = nlvr_forward(w, ids[i:i + 1].expand(b, -1), attention_mask[i:i + 1].expand(b, -1), z_t[i:i + 1].expand(b, -1, -1), feats,
+                           drop=None if drop is None else (lambda kind, layer, br, x, i=i: drop(kind, layer, br, i, x)))
         y = F.linear(hid, w["cls_head.0.weight"], w["cls_head.0.bias"])
         y = F.relu(y) if relu_mask is None else y * relu_mask[i * b:(i + 1) * b].to(y.dtype)
         rows.append(F.linear(y, w["cls_head.2.weight"], w["cls_head.2.bias"])[:, 0])

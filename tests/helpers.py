@@ -97,3 +97,35 @@ class DuckCIRR(DuckFIQ):
         members.insert(self.ref_slot % 6, self.names[self.refs[i]])
         return (self.names[self.refs[i]], self.names[self.targets[i]], str(self.captions[i]), members,
                 self.K_sorted_index_names[i].tolist(), self.K_labels[i], self.K_group_labels[i])
+
+
+def pair_keep(seed: int, rows: int, cols: int, p: float) -> torch.Tensor:
+    """The dropout mask of the FUSED training kernels regenerated on the host (include/cirrank.h, cir_residual_layernorm_train): element
+    (row, col) is kept iff the 16 bits of its column pair's hash32(row_key ^ (col >> 1)) - low half for even, high half for odd col - are
+    >= round(p * 65536)."""
+    m32 = np.uint64(0xFFFFFFFF)
+    row = np.arange(rows, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        rk = (np.uint64(seed & 0xFFFFFFFF) + np.uint64(seed >> 32) * np.uint64(0x85EBCA6B) + (row & m32) * np.uint64(0x9E3779B9)
+              + (row >> np.uint64(32)) * np.uint64(0xC2B2AE35)) & m32
+        x = rk[:, None] ^ (np.arange(cols, dtype=np.uint64)[None, :] >> np.uint64(1))
+        x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & m32
+        x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & m32
+        x ^= x >> np.uint64(16)
+    odd = (np.arange(cols) & 1).astype(bool)[None, :]
+    u16 = np.where(odd, x >> np.uint64(16), x & np.uint64(0xFFFF))
+    thr = int(np.float32(p) * np.float32(65536.0) + np.float32(0.5))
+    return torch.from_numpy(u16 >= np.uint64(thr))
+
+
+def splitmix_keep(seed: int, n: int, p: float) -> torch.Tensor:
+    """The dropout mask of the STAND-ALONE operators (cir_eltwise mode 4, cir_softmax_dropout; train.hip uniform01): element i of a launch is
+    kept iff the top 24 bits of splitmix64(seed, i), as a fraction, are >= p."""
+    idx = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (idx + np.uint64(1))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return torch.from_numpy(u >= np.float32(p))

@@ -428,3 +428,85 @@ def test_gradient_accumulation_keeps_the_flat_path(cuda):
     assert AdamW._flat_range([p.grad for p in live]) is not None                 # still slices of one flat buffer
     opt.step()
     assert len(opt._flats) == 1                                                 # ... and the optimizer took the flat path
+
+
+@pytest.mark.parametrize("dtype", [BF, HF], ids=["bf16", "fp16"])
+def test_training_step_with_dropout_against_oracle_with_the_same_masks(cuda, dtype):
+    """Dropout ON (hidden 0.1, attention probabilities 0.1) end to end: the masks of every site - embeddings, both self-attention outputs,
+    the merged cross-attention output (ONE mask for both branches), the stacked FFN output, the self- and cross-attention probabilities of
+    every layer and branch - are regenerated on the HOST from the kernels' counters (tests/helpers.pair_keep, the seeds of
+    NlvrTrainer._site) and handed to the oracle (`drop=`): logits and every parameter gradient of the hand-written pass must match torch
+    autograd through the oracle with exactly that draw.  Catches any disagreement between a forward kernel's mask, its adjoint's
+    regenerated mask and the documented element numbering (row / column of each site, candidate-major triplets, stacked branches)."""
+    from oracle import cir_oracle as O
+    z = H.load("train768.npz")
+    cfg = dict(json.loads(str(z["bert_cfg"])), hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    g, v = H.geometry(cfg, json.loads(str(z["vit_cfg"])))
+    z_t_in, feats_in = _fixture_inputs(z)
+    bsz, l = z["input_ids"].shape
+    n, d, heads = feats_in.shape[1], g.hidden_size, g.num_attention_heads
+    m2, sd2 = build(g, v, int(z["seed"]), str(z["profile"]), dtype)
+    freeze_vit(m2)
+    m2.train()
+    caps = [str(c) for c in z["caps"]]
+    logits = m2.img_txt_fusion(z_t_in.cuda(), feats_in.cuda(), caps, train=True)
+    loss = F.cross_entropy(logits, torch.arange(bsz, device=cuda))
+    loss.backward()
+    tr = m2._trainer
+    assert tr.p_hidden == 0.1 and tr.p_attn == 0.1
+    r = bsz * bsz * l
+    cache = {}
+
+    def keep(kind, layer, b):
+        key = (kind, layer, b)
+        if key not in cache:
+            if kind == "emb":
+                cache[key] = H.splitmix_keep(tr._site(9000), r * d, 0.1).view(bsz, bsz, l, d)                 # [target j][query i]; cir_eltwise's generator
+            elif kind == "self_out":
+                cache[key] = H.pair_keep(tr._site(layer, b, 2), r, d, 0.1).view(bsz, bsz, l, d)
+            elif kind == "cross_out":
+                cache[key] = H.pair_keep(tr._site(layer, 2, 4), r, d, 0.1).view(bsz, bsz, l, d)
+            elif kind == "ffn_out":                                                                            # both branches stacked: 2R rows
+                cache[key] = H.pair_keep(tr._site(layer, 0, 5), 2 * r, d, 0.1).view(2, bsz, bsz, l, d)
+            elif kind == "self_attn":                                                                          # group = triplet j * B + i
+                cache[key] = H.pair_keep(tr._site(layer, b, 1), bsz * bsz * heads * l, l, 0.1).view(bsz, bsz, heads, l, l)
+            elif kind == "cross_attn":                                                                         # group = target j, rows = (query i, token)
+                cache[key] = H.pair_keep(tr._site(layer, b, 3), bsz * heads * bsz * l, n, 0.1).view(bsz, heads, bsz, l, n)
+        return cache[key]
+
+    def drop(kind, layer, b, qi, x):
+        k = keep(kind, layer, b)
+        if kind == "ffn_out":
+            mk = k[b][:, qi]
+        elif kind == "cross_attn":
+            mk = k[:, :, qi]
+        else:
+            mk = k[:, qi]
+        assert mk.shape == x.shape, (kind, mk.shape, x.shape)
+        return x * mk.to(x.dtype) / 0.9
+
+    names = [str(nm) for nm in z["names"]]
+    w = {k: t.clone().float() for k, t in sd2.items()}
+    for k in names:
+        w[k].requires_grad_(True)
+    torch.set_num_threads(8)
+    o_logits = O.img_txt_fusion_train(w, z_t_in, feats_in, torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]),
+                                      relu_mask=tr.head_mask().cpu(), drop=drop)
+    F.cross_entropy(o_logits, torch.arange(bsz)).backward()
+    e_log = (logits.detach().cpu() - o_logits.detach()).abs().max().item()
+    params = dict(m2.named_parameters())
+    gmax = max(w[nm].grad.norm().item() for nm in names)
+    w_e, tot, cnt = (0.0, ""), 0.0, 0
+    for nm in names:
+        ref = w[nm].grad
+        if ref.norm().item() < 1e-6 * gmax:
+            continue
+        e = ((params[nm].grad.cpu() - ref).norm() / ref.norm()).item()
+        w_e = max(w_e, (e, nm))
+        tot, cnt = tot + e, cnt + 1
+    kept = np.mean([keep("self_out", 0, 0).float().mean().item(), keep("cross_attn", 3, 1).float().mean().item()])
+    print(f"\n[dropout 0.1 / 0.1, {dtype}] logits vs oracle with the same masks {e_log:.3e}; worst grad rel {w_e[0]:.3e} ({w_e[1]})  mean {tot / cnt:.3e}; kept {kept:.3f}")
+    assert abs(kept - 0.9) < 0.02
+    assert e_log < 2 * LOGIT_ABS[dtype]
+    assert w_e[0] < 1.5 * GRAD_REL[dtype] and tot / cnt < 1.5 * GRAD_REL_MEAN[dtype]
+    m2.eval()

@@ -4,6 +4,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from tests import helpers as H
+
 pytestmark = pytest.mark.gpu
 BF, HF = torch.bfloat16, torch.float16
 
@@ -229,23 +231,7 @@ def test_colsum_embed_adamw(T):
 
 
 # ------------------------------------------------------------------------------------------------ fused training attention (round 4)
-def _pair_keep(seed: int, rows: int, cols: int, p: float) -> torch.Tensor:
-    """The dropout mask of the FUSED training kernels regenerated on the host (include/cirrank.h, cir_residual_layernorm_train): element
-    (row, col) is kept iff the 16 bits of its column pair's hash32(row_key ^ (col >> 1)) - low half for even, high half for odd col - are
-    >= round(p * 65536)."""
-    m32 = np.uint64(0xFFFFFFFF)
-    row = np.arange(rows, dtype=np.uint64)
-    with np.errstate(over="ignore"):
-        rk = (np.uint64(seed & 0xFFFFFFFF) + np.uint64(seed >> 32) * np.uint64(0x85EBCA6B) + (row & m32) * np.uint64(0x9E3779B9)
-              + (row >> np.uint64(32)) * np.uint64(0xC2B2AE35)) & m32
-        x = rk[:, None] ^ (np.arange(cols, dtype=np.uint64)[None, :] >> np.uint64(1))
-        x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & m32
-        x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & m32
-        x ^= x >> np.uint64(16)
-    odd = (np.arange(cols) & 1).astype(bool)[None, :]
-    u16 = np.where(odd, x >> np.uint64(16), x & np.uint64(0xFFFF))
-    thr = int(np.float32(p) * np.float32(65536.0) + np.float32(0.5))
-    return torch.from_numpy(u16 >= np.uint64(thr))
+_pair_keep = H.pair_keep
 
 
 def _keep_mask(seed: int, g: int, h: int, lq: int, lk: int, p: float) -> torch.Tensor:
