@@ -510,3 +510,40 @@ def test_training_step_with_dropout_against_oracle_with_the_same_masks(cuda, dty
     assert e_log < 2 * LOGIT_ABS[dtype]
     assert w_e[0] < 1.5 * GRAD_REL[dtype] and tot / cnt < 1.5 * GRAD_REL_MEAN[dtype]
     m2.eval()
+
+
+def test_benchmark_geometry_sub_batch_property(cuda):
+    """The training step at the BENCHMARK's geometry (B = 16 -> 256 triplets, 32 caption tokens, 577 image tokens, full med_config; the
+    reference fixtures stop at 64 triplets x 197 tokens): a size-independent property instead of a stored answer.  Triplet (i, j)'s logit
+    depends on query i and target j only, so (a) the B = 16 logits restricted to queries / targets < 8 equal the B = 8 run's - bit for bit:
+    rows are independent in every kernel and the GEMMs are tile-invariant - and (b) with dlogits supported on that block the B = 16
+    gradients equal the B = 8 run's up to the order of fp32 sums (zero rows contribute exact zeros; the loss scale is the same power of
+    two).  The two runs take different shapes through every product (8192 against 2048 rows, 16 against 8 stacked queries per target in the
+    cross-attention, different tile counts in the grouped weight gradients)."""
+    from candidate_reranking_cir_amd.train import NlvrTrainer
+    g, v = H.geometry(dict(H.FULL_BERT, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0), dict(image_size=384))
+    m2, _ = build(g, v, 23, "test", HF)
+    b, l, n, d = 16, 32, 577, g.hidden_size
+    gen = torch.Generator().manual_seed(77)
+    ids = torch.stack([synthetic.caption_ids(300 + q, l) for q in range(b)])
+    mask = torch.ones_like(ids)
+    mask[3, 20:] = 0; mask[9, 11:] = 0                                         # two ragged captions
+    z_t = torch.randn((b, l, d), generator=gen)
+    feats = torch.randn((b, n, d), generator=gen)
+    dl8 = torch.randn((8, 8), generator=gen)
+    dl16 = torch.zeros((b, b)); dl16[:8, :8] = dl8
+    t16, t8 = NlvrTrainer(m2, 0.0, 0.0), NlvrTrainer(m2, 0.0, 0.0)
+    lg16 = t16.forward(z_t.cuda(), feats.cuda(), ids.cuda(), mask.cuda()).clone()
+    g16 = {k: t.clone() for k, t in t16.backward(dl16.cuda()).items()}
+    lg8 = t8.forward(z_t[:8].cuda(), feats[:8].cuda(), ids[:8].cuda(), mask[:8].cuda())
+    g8 = t8.backward(dl8.cuda())
+    assert torch.isfinite(lg16).all() and lg16.std().item() > 1e-3
+    assert torch.equal(lg16[:8, :8], lg8), (lg16[:8, :8] - lg8).abs().max().item()
+    gmax = max(t.norm().item() for t in g8.values())
+    worst = (0.0, "")
+    for k, r8 in g8.items():
+        if r8.norm().item() < 1e-6 * gmax:
+            continue
+        worst = max(worst, (((g16[k] - r8).norm() / r8.norm()).item(), k))
+    print(f"\n[B = 16 x 577 tokens against its B = 8 sub-batch] logits bit-equal; worst gradient difference {worst[0]:.3e} ({worst[1]})")
+    assert worst[0] < 1e-4
