@@ -404,7 +404,9 @@ def train_mode(args, m2, m1, dev, dt):
     Reported separately from the headline metric; unit: triplets (B*B per step) forward+backward per second."""
     import torch.nn.functional as F
     from candidate_reranking_cir_amd import synthetic
-    from candidate_reranking_cir_amd.train import AdamW
+    from candidate_reranking_cir_amd.train import AdamW, _Lin2
+    if os.environ.get("CIR_TRAIN_PAIRS") == "0":            # A/B: the branch twins' dense layers as two launches instead of one batched GEMM
+        _Lin2.BATCHED = False
     b, l = args.train_batch, args.tokens
     gen = torch.Generator(device=dev).manual_seed(5)
     ref = torch.randn((b, 3, args.image_size, args.image_size), generator=gen, device=dev).to(dt)

@@ -218,6 +218,45 @@ class _Lin:
         return ops.gemm(dy16, self.w16t, None, residual=residual, out_dtype=dx_dtype, out=out)
 
 
+class _Lin2:
+    """The two branches' Linears of one kind (adjacent in the slab, `NlvrTrainer._order`): forward and dgrad of BOTH as one batched GEMM
+    (batch 2; measured on the 8192-row shapes of the step: 22 against 35 us for the 768 x 768 products, 60 against 88 us for the stacked
+    q|k|v dgrad - a 9.7-GFLOP product is mostly launch, prologue and epilogue).  Weight / bias gradients stay per branch (`.l[b]`)."""
+
+    def __init__(self, l0: _Lin, l1: _Lin):
+        slab, n, k = l0.slab, l0.n, l0.k
+        assert l1.n == n and l1.k == k and l1.off_w == l0.off_w + n * k, "branch twins not adjacent in the slab"
+        self.l = (l0, l1)
+        self.w16 = slab.flat16[l0.off_w:l0.off_w + 2 * n * k].view(2, n, k)
+        self.w16t = slab.flat16t[l0.off_w:l0.off_w + 2 * n * k].view(2, k, n)
+        ob = slab.off[l0.bs[0]]
+        assert slab.off[l1.bs[0]] == ob + n
+        self.bias = slab.flat32[ob:ob + 2 * n].view(2, n)
+
+    BATCHED = True        # False: the same products as two launches into the same tensors (A/B: tools/train_dbg.py, CIR_TRAIN_PAIRS=0)
+
+    def _gemm(self, a3, w3, bias, residual, out_dtype, out):
+        if self.BATCHED:
+            return ops.gemm(a3, w3, bias, residual=residual, out_dtype=out_dtype, out=out)
+        if out is None:
+            out = torch.empty((2, a3.shape[1], w3.shape[1]), dtype=out_dtype, device=a3.device)
+        for b in (0, 1):
+            ops.gemm(a3[b], w3[b], None if bias is None else bias[b], residual=None if residual is None else residual[b], out_dtype=out_dtype, out=out[b])
+        return out
+
+    def fwd(self, x3: torch.Tensor, out_dtype: torch.dtype, out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x3 (2, M, K) (a stride-0 batch dimension shares one input) -> (2, M, N)."""
+        return self._gemm(x3, self.w16, self.bias, residual, out_dtype, out)
+
+    def dgrad(self, dy3: torch.Tensor, dx_dtype: torch.dtype, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """dy3 (2, M, N) -> dx (2, M, K) = dy . W (+ residual) per branch."""
+        return self._gemm(dy3, self.w16t, None, residual, dx_dtype, out)
+
+    def wgrad(self, x3: torch.Tensor, dy3: torch.Tensor, queue: list, bias: bool = False):
+        for b in (0, 1):
+            self.l[b].bwd16(x3[b], dy3[b], need_dx=False, bias=bias, queue=queue)
+
+
 class _LN:
     def __init__(self, slab: _Slab, name: str, eps: float):
         self.eps, self.slab, self.name = eps, slab, name
@@ -279,23 +318,40 @@ class NlvrTrainer:
 
     @staticmethod
     def _order(names: List[str]) -> List[str]:
-        """Slab order: the weights of an attention's q, k, v (cross-attention: k, v) adjacent, then their biases - what `_Slab.span`
-        stacks into one Linear - and everything else in the model's own order."""
+        """Slab order: per layer the twin (branch 0 | branch 1) dense layers as adjacent groups - all weights of a group, then its biases - so
+        that (a) the q, k, v projections of one self-attention (k, v of one cross-attention) are ONE stacked Linear (`_Slab.span`) and (b) the
+        two branches' Linears of one kind sit a constant stride apart: one BATCHED GEMM serves both (`_Lin2`).  Everything else keeps the
+        model's own order."""
+        groups = {}
+        for n in names:
+            if not n.endswith(".weight"):
+                continue
+            stem = None
+            if ".attention.self0.query." in n:
+                stem, parts = n[:n.index("attention.self0.query.")], [f"attention.self{b}.{x}" for b in (0, 1) for x in ("query", "key", "value")]
+            elif ".crossattention.self0.key." in n:
+                stem, parts = n[:n.index("crossattention.self0.key.")], [f"crossattention.self{b}.{x}" for b in (0, 1) for x in ("key", "value")]
+            elif ".crossattention.self0.query." in n:
+                stem, parts = n[:n.index("crossattention.self0.query.")], [f"crossattention.self{b}.query" for b in (0, 1)]
+            elif ".attention.output.dense0." in n and ".crossattention." not in n:
+                stem, parts = n[:n.index("attention.output.dense0.")], [f"attention.output.dense{b}" for b in (0, 1)]
+            elif ".crossattention.output.dense0." in n:
+                stem, parts = n[:n.index("crossattention.output.dense0.")], [f"crossattention.output.dense{b}" for b in (0, 1)]
+            if stem is not None:
+                groups[n] = [stem + q + "." + y for y in ("weight", "bias") for q in parts]
+        grouped = {m for g in groups.values() for m in g}
         out, seen = [], set()
         for n in names:
             if n in seen:
                 continue
-            if n.endswith(".query.weight") and ".attention.self" in n:
-                stem = n[:-len("query.weight")]
-                grp = [stem + f"{x}.{y}" for y in ("weight", "bias") for x in ("query", "key", "value")]
-            elif n.endswith(".key.weight") and ".crossattention.self" in n:
-                stem = n[:-len("key.weight")]
-                grp = [stem + f"{x}.{y}" for y in ("weight", "bias") for x in ("key", "value")]
-            else:
-                grp = [n]
-            for m in grp:
-                if m not in seen:
+            if n in groups:
+                for m in groups[n]:
                     out.append(m); seen.add(m)
+            elif n not in grouped:
+                out.append(n); seen.add(n)
+        for n in names:                                                             # (a grouped name whose group head is missing: keep it)
+            if n not in seen:
+                out.append(n); seen.add(n)
         assert sorted(out) == sorted(names)
         return out
 
@@ -334,6 +390,8 @@ class NlvrTrainer:
                 ly[f"cq{b}"] = lin(p + f"crossattention.self{b}.query")
                 ly[f"ckv{b}"] = grp([p + f"crossattention.self{b}.{n}" for n in ("key", "value")])           # one 1536-wide Linear
                 ly[f"d{b}"] = lin(p + f"crossattention.output.dense{b}")
+            for kind in ("qkv", "o", "cq", "ckv", "d"):                                # the twins as one batched GEMM each
+                ly[kind] = _Lin2(ly[kind + "0"], ly[kind + "1"])
             for c, b in (("A", 0), ("B", 1)):
                 ly[f"ln1{b}"] = ln(p + f"attention.output.LayerNorm{c}")
                 ly[f"ln2{b}"] = ln(p + f"crossattention.output.LayerNorm{c}")
@@ -358,19 +416,17 @@ class NlvrTrainer:
         """(nb1 * rows, parts * D) projection(s) -> (nb1, H, rows, head_dim) view of the head slices of projection `part` (no copy)."""
         return x.view(nb1, rows, parts, self.geo.num_attention_heads, self._hd)[:, :, part].permute(0, 2, 1, 3)
 
-    def _attn_fwd(self, q4, k4, v4, mask, site):
+    def _attn_fwd(self, q4, k4, v4, mask, site, ctx, ctx32):
         """q4 (G, H, mq, hd), k4 / v4 (G, H, mk, hd) head views of 16-bit projections: G groups of mq query rows and mk key rows;
         mask (groups, mk) additive fp32, one row per mq * H score rows, or None.  Self-attention: a group is a triplet;
         cross-attention: a group is a CANDIDATE with the B queries scored against it stacked in mq = B * L rows - its keys /
         values exist once.  ONE kernel - scores, mask, softmax, dropout, P.V tile by tile in registers - and a log-sum-exp per row
         for the recomputing backward; no score / probability tensor is materialised (cir_attention_train_fwd; head dimension 64,
-        which config.BertGeometry enforces)."""
+        which config.BertGeometry enforces).  Writes the context into `ctx` (G*mq, D) 16-bit and its fp32 twin `ctx32` (the backward's
+        D = rowsum(dO * O), cirrank.h); returns what the adjoint needs."""
         nb1, h_n, mq, _ = q4.shape
-        d = self.geo.hidden_size
-        ctx = torch.empty((nb1 * mq, d), dtype=q4.dtype, device=q4.device)
-        ctx32 = torch.empty((nb1 * mq, d), dtype=torch.float32, device=q4.device)    # fp32 twin of the context: the backward's D = rowsum(dO * O) (cirrank.h)
         lse = T.attention_train_fwd(q4, k4, v4, mask, self._heads(ctx, nb1, mq), self._scale, self.p_attn, site, out32=self._heads(ctx32, nb1, mq))
-        return ctx, (lse, mask, site, ctx, ctx32)
+        return (lse, mask, site, ctx, ctx32)
 
     def _attn_bwd(self, dctx16, q4, k4, v4, saved, dq4, dk4, dv4):
         """dctx16 (G*mq, D) in the operand type -> dq4 / dk4 / dv4: head views (same type) of the buffer the fused projection's
@@ -406,36 +462,46 @@ class NlvrTrainer:
         sv["pre_e"] = pre_e
         e32, _ = self.ln_e.fwd(pre_e, dt)
         e32 = self._drop(e32, self._site(9000))
-        h32 = [ops.gather_rows(z_t.to(dev).float().contiguous().view(b_n, l * d), qi, f32).view(r, d), e32]
-        h16 = [_cast(x, dt) for x in h32]
+        # Both branches live in ONE (2, R, .) tensor per activation: the twin dense layers are then one batched GEMM each (`_Lin2`), and the
+        # shared FFN reads the same memory as its 2R stacked rows.
+        h32 = torch.empty((2, r, d), dtype=f32, device=dev)
+        h32[0].copy_(ops.gather_rows(z_t.to(dev).float().contiguous().view(b_n, l * d), qi, f32).view(r, d))
+        h32[1].copy_(e32)
+        h16 = _cast(h32, dt)
         cand16 = _cast(feats.to(dev).float().contiguous(), dt).view(b_n * n, -1)                          # (B*N, Dv): each target once
         sv["cand16"] = cand16
+        cand2 = cand16.unsqueeze(0).expand(2, b_n * n, cand16.shape[1])                                   # one input, two branches (batch stride 0)
         smask = ((1.0 - attention_mask.to(dev).float()) * -10000.0)[qi].contiguous()                      # (T, L), nlvr_encoder.py:773-774
+        smask2 = smask.repeat(2, 1)                                                                       # the same key masks for both branches' groups
         sv["layers"] = []
         for i, ly in enumerate(self.layers):
-            s = {"h16": h16, "qkv": [], "sa": [], "ctx": [], "pre1": [], "a16": [], "cq": [], "ckv": [], "ca": [], "c": []}
-            a32, dd = [], []
-            cat16 = None if ly["merge"] is None else torch.empty((r, 2 * d), dtype=dt, device=dev)
+            s = {"h16": h16}
+            qkv = ly["qkv"].fwd(h16, dt)                                              # (2, R, 3D): one batched GEMM for both branches
+            ctx = torch.empty((2, r, d), dtype=dt, device=dev)
+            ctx32 = torch.empty((2, r, d), dtype=f32, device=dev)                     # fp32 twin of the context: the backward's D = rowsum(dO * O)
+            # both branches' self-attentions in ONE launch: group = (branch, triplet) - 2T groups of 32 x 32 one-tile problems fill the
+            # chip better than T (3072 waves are 3 per SIMD), and the dropout rows of the two branches are distinct rows of one site
+            s["sa"] = self._attn_fwd(*(self._heads(qkv.view(2 * r, 3 * d), 2 * t_n, l, j, 3) for j in range(3)), smask2, self._site(i, 0, 1),
+                                     ctx.view(2 * r, d), ctx32.view(2 * r, d))
+            # BertSelfOutput (nlvr_encoder.py:399-409): LayerNorm(dropout(dense(ctx)) + h) - dropout, sum and LayerNorm in one pass per branch
+            t = ly["o"].fwd(ctx, f32)
+            pre1, a32, a16 = torch.empty((2, r, d), dtype=f32, device=dev), torch.empty((2, r, d), dtype=f32, device=dev), torch.empty((2, r, d), dtype=dt, device=dev)
             for b in (0, 1):
-                qkv = ly[f"qkv{b}"].fwd(h16[b], dt)                                   # (R, 3D)
-                ctx, sa = self._attn_fwd(*(self._heads(qkv, t_n, l, j, 3) for j in range(3)), smask, self._site(i, b, 1))
-                # BertSelfOutput (nlvr_encoder.py:399-409): LayerNorm(dropout(dense(ctx)) + h) - dropout, sum and LayerNorm in one pass
-                pre1, a, a16 = ly[f"ln1{b}"].fwd_res(ly[f"o{b}"].fwd(ctx, f32), None, h32[b], dt, 1.0, ph, self._site(i, b, 2))
-                cq = ly[f"cq{b}"].fwd(a16, dt)
-                ckv = ly[f"ckv{b}"].fwd(cand16, dt)                                   # (B*N, 2D): each target's keys | values, once
-                c, ca = self._attn_fwd(self._heads(cq, b_n, b_n * l), self._heads(ckv, b_n, n, 0, 2), self._heads(ckv, b_n, n, 1, 2), None,
-                                       self._site(i, b, 3))
-                if cat16 is None:
-                    dd.append(ly[f"d{b}"].fwd(c, f32))
-                else:                                                                # the merge layer's operand: written in place, 16-bit
-                    ly[f"d{b}"].fwd(c, dt, out=cat16[:, b * d:(b + 1) * d])
-                a32.append(a)
-                for key, val in (("qkv", qkv), ("sa", sa), ("ctx", ctx), ("pre1", pre1), ("a16", a16), ("cq", cq), ("ckv", ckv), ("ca", ca),
-                                 ("c", c)):
-                    s[key].append(val)
-            if cat16 is None:                                                       # layers < 6: average (nlvr_encoder.py:257-260)
+                ly[f"ln1{b}"].fwd_res(t[b], None, h32[b], dt, 1.0, ph, self._site(i, b, 2), pre=pre1[b], y32=a32[b], y16=a16[b])
+            cq = ly["cq"].fwd(a16, dt)
+            ckv = ly["ckv"].fwd(cand2, dt)                                            # (2, B*N, 2D): each target's keys | values, once per branch
+            c = torch.empty((2, r, d), dtype=dt, device=dev)
+            c32 = torch.empty((2, r, d), dtype=f32, device=dev)
+            # ... and both cross-attentions: group = (branch, target image), its B * L stacked query rows against the target's 577 keys
+            kv2 = ckv.view(2 * b_n * n, 2 * d)
+            s["ca"] = self._attn_fwd(self._heads(cq.view(2 * r, d), 2 * b_n, b_n * l), self._heads(kv2, 2 * b_n, n, 0, 2), self._heads(kv2, 2 * b_n, n, 1, 2),
+                                     None, self._site(i, 0, 3), c.view(2 * r, d), c32.view(2 * r, d))
+            if ly["merge"] is None:                                                 # layers < 6: average (nlvr_encoder.py:257-260)
+                dd = ly["d"].fwd(c, f32)
                 t0, t1, alpha = dd[0], dd[1], 0.5
-            else:                                                                   # layers >= 6: merge_layer(cat) (:252-256)
+            else:                                                                   # layers >= 6: merge_layer(cat) (:252-256): the operand is written
+                cat16 = torch.empty((r, 2 * d), dtype=dt, device=dev)               # in place, 16-bit, branch b into columns [bD, (b+1)D)
+                ly["d"].fwd(c, dt, out=cat16.view(r, 2, d).permute(1, 0, 2))
                 s["cat16"] = cat16
                 t0, t1, alpha = ly["merge"].fwd(cat16, f32), None, 1.0
             # BertSelfOutput of the cross-attention: m = dropout(average | merge) (ONE mask for both branches), LayerNormA / B (m + a_b).
@@ -449,9 +515,9 @@ class NlvrTrainer:
             z16 = ly["w1"].fwd(x16, dt)                                             # the dense output in the operand type, as autocast leaves it
             f16 = T.eltwise(z16, T.MODE_GELU, out_dtype=dt)
             pre3, hn, hn16 = ly["ln3"].fwd_res(ly["w2"].fwd(f16, f32), None, x32, dt, 1.0, ph, self._site(i, 0, 5))
-            s.update(pre2=pre2, x16=x16, z16=z16, f16=f16, pre3=pre3)
+            s.update(qkv=qkv, ctx=ctx, pre1=pre1, a16=a16, cq=cq, ckv=ckv, c=c, pre2=pre2, x16=x16, z16=z16, f16=f16, pre3=pre3)
             sv["layers"].append(s)
-            h32, h16 = [hn[:r], hn[r:]], [hn16[:r], hn16[r:]]
+            h32, h16 = hn.view(2, r, d), hn16.view(2, r, d)
         # cat(CLS_0, CLS_1) -> cls_head (nlvr_encoder.py:906-908, blip_stage2.py:50-54, 94-99)
         cls_rows = torch.arange(t_n, device=dev) * l
         hid16 = torch.cat([ops.gather_rows(h16[0], cls_rows, dt), ops.gather_rows(h16[1], cls_rows, dt)], dim=1).contiguous()
@@ -504,45 +570,51 @@ class NlvrTrainer:
             dpre3, do16 = ly["ln3"].bwd_res(s["pre3"], dh, dt, dbias=w2.db, p_drop=ph, seed=self._site(i, 0, 5))
             df16 = w2.bwd16(s["f16"], do16, dx_dtype=dt, queue=wq)
             dz16 = T.gelu_bwd16(df16, s["z16"], sums=w1.db)
-            dx = w1.bwd16(s["x16"], dz16, residual=dpre3, queue=wq)                           # (2R, D) fp32: FFN branch + skip
+            dx = w1.bwd16(s["x16"], dz16, residual=dpre3, queue=wq)                 # (2R, D) fp32: FFN branch + skip
             # the two LayerNorms over m + a_b: d m = dropout'(d pre2_0 + d pre2_1) comes out of the second one's kernel
             merge = ly["merge"]
-            dpre2 = [ly["ln20"].bwd_res(s["pre2"][:r], dx[:r], dt, want_dt=False)[0]]
+            dpre2 = torch.empty((2, r, d), dtype=torch.float32, device=dev)
+            ly["ln20"].bwd_res(s["pre2"][:r], dx[:r], dt, want_dt=False, dx=dpre2[0])
             if merge is None:                                                       # average: both output denses see 0.5 * d m
                 kw = dict(alpha=0.5, dbias=ly["d0"].db, dbias2=ly["d1"].db)
             else:
                 kw = dict(alpha=1.0, dbias=merge.db)
-            dp, dm16 = ly["ln21"].bwd_res(s["pre2"][r:], dx[r:], dt, t_add=dpre2[0], p_drop=ph, seed=self._site(i, 2, 4), **kw)
-            dpre2.append(dp)
+            _, dm16 = ly["ln21"].bwd_res(s["pre2"][r:], dx[r:], dt, t_add=dpre2[0], p_drop=ph, seed=self._site(i, 2, 4), dx=dpre2[1], **kw)
             if merge is None:
-                dd16 = [dm16, dm16]
+                dd16 = dm16.unsqueeze(0).expand(2, r, d)                            # one gradient, two branches (batch stride 0)
             else:
-                dcat16 = merge.bwd16(s["cat16"], dm16, dx_dtype=dt, queue=wq)                 # (R, 2D)
-                dd16 = [dcat16[:, :d], dcat16[:, d:]]
-            dh_in = torch.empty((2 * r, d), dtype=torch.float32, device=dev)
-            for b in (0, 1):
-                dc16 = ly[f"d{b}"].bwd16(s["c"][b], dd16[b], dx_dtype=dt, bias=merge is not None, queue=wq)
-                cq, ckv = s["cq"][b], s["ckv"][b]
-                dcq16 = torch.empty((r, d), dtype=dt, device=dev)
-                dckv16 = torch.empty((b_n * n, 2 * d), dtype=dt, device=dev)
-                self._attn_bwd(dc16, self._heads(cq, b_n, b_n * l), self._heads(ckv, b_n, n, 0, 2), self._heads(ckv, b_n, n, 1, 2), s["ca"][b],
-                               self._heads(dcq16, b_n, b_n * l), self._heads(dckv16, b_n, n, 0, 2), self._heads(dckv16, b_n, n, 1, 2))
-                if dfeats is None:                                                  # image tokens are inputs: no gradient beyond the weights
-                    ly[f"ckv{b}"].bwd16(sv["cand16"], dckv16, need_dx=False, bias=True, queue=wq)
-                else:                                                               # ViT fine-tuning: every layer and branch adds its share
-                    ly[f"ckv{b}"].bwd16(sv["cand16"], dckv16, bias=True, queue=wq, out=dfeats, residual=dfeats if dfeats_live else None)
+                dcat16 = merge.bwd16(s["cat16"], dm16, dx_dtype=dt, queue=wq)       # (R, 2D)
+                dd16 = dcat16.view(r, 2, d).permute(1, 0, 2)                        # branch b = columns [bD, (b+1)D)
+            ly["d"].wgrad(s["c"], dd16, wq, bias=merge is not None)
+            dc16 = ly["d"].dgrad(dd16, dt)                                          # (2, R, D): both branches' output-dense dgrads, one GEMM
+            cq, ckv = s["cq"], s["ckv"]
+            dcq16 = torch.empty((2, r, d), dtype=dt, device=dev)
+            dckv16 = torch.empty((2, b_n * n, 2 * d), dtype=dt, device=dev)
+            kv2, dkv2 = ckv.view(2 * b_n * n, 2 * d), dckv16.view(2 * b_n * n, 2 * d)
+            self._attn_bwd(dc16.view(2 * r, d), self._heads(cq.view(2 * r, d), 2 * b_n, b_n * l), self._heads(kv2, 2 * b_n, n, 0, 2),
+                           self._heads(kv2, 2 * b_n, n, 1, 2), s["ca"], self._heads(dcq16.view(2 * r, d), 2 * b_n, b_n * l),
+                           self._heads(dkv2, 2 * b_n, n, 0, 2), self._heads(dkv2, 2 * b_n, n, 1, 2))
+            cand2 = sv["cand16"].unsqueeze(0).expand(2, b_n * n, sv["cand16"].shape[1])
+            ly["ckv"].wgrad(cand2, dckv16, wq, bias=True)
+            if dfeats is not None:                                                  # ViT fine-tuning: every layer and branch adds its share
+                for b in (0, 1):                                                    # (image tokens are inputs otherwise: no gradient beyond the weights)
+                    ops.gemm(dckv16[b], ly[f"ckv{b}"].w16t, None, residual=dfeats if dfeats_live else None, out_dtype=torch.float32, out=dfeats)
                     dfeats_live = True
-                da = ly[f"cq{b}"].bwd16(s["a16"][b], dcq16, residual=dpre2[b], bias=True, queue=wq)
-                o = ly[f"o{b}"]
-                dpre1, dt16 = ly[f"ln1{b}"].bwd_res(s["pre1"][b], da, dt, dbias=o.db, p_drop=ph, seed=self._site(i, b, 2))
-                dctx16 = o.bwd16(s["ctx"][b], dt16, dx_dtype=dt, queue=wq)
-                qkv = s["qkv"][b]
-                dqkv16 = torch.empty((r, 3 * d), dtype=dt, device=dev)
-                self._attn_bwd(dctx16, *(self._heads(qkv, t_n, l, j, 3) for j in range(3)), s["sa"][b],
-                               *(self._heads(dqkv16, t_n, l, j, 3) for j in range(3)))
-                ly[f"qkv{b}"].bwd16(s["h16"][b], dqkv16, residual=dpre1, out=dh_in[b * r:(b + 1) * r], bias=True, queue=wq)
+            ly["cq"].wgrad(s["a16"], dcq16, wq, bias=True)
+            da = ly["cq"].dgrad(dcq16, torch.float32, residual=dpre2)               # (2, R, D) fp32: cross-attention query branch + skip
+            dpre1 = torch.empty((2, r, d), dtype=torch.float32, device=dev)
+            dt16 = torch.empty((2, r, d), dtype=dt, device=dev)
+            for b in (0, 1):
+                ly[f"ln1{b}"].bwd_res(s["pre1"][b], da[b], dt, dbias=ly[f"o{b}"].db, p_drop=ph, seed=self._site(i, b, 2), dx=dpre1[b], dt16=dt16[b])
+            ly["o"].wgrad(s["ctx"], dt16, wq)
+            dctx16 = ly["o"].dgrad(dt16, dt)
+            qkv = s["qkv"]
+            dqkv16 = torch.empty((2, r, 3 * d), dtype=dt, device=dev)
+            self._attn_bwd(dctx16.view(2 * r, d), *(self._heads(qkv.view(2 * r, 3 * d), 2 * t_n, l, j, 3) for j in range(3)), s["sa"],
+                           *(self._heads(dqkv16.view(2 * r, 3 * d), 2 * t_n, l, j, 3) for j in range(3)))
+            ly["qkv"].wgrad(s["h16"], dqkv16, wq, bias=True)
+            dh = ly["qkv"].dgrad(dqkv16, torch.float32, residual=dpre1).view(2 * r, d)      # both branches stacked, as the layer below's FFN saw them
             T.wgrad_grouped(wq)
-            dh = dh_in
         # branch 1 entered through BertEmbeddings; branch 0 is z_t (frozen stage I)
         de = dh[r:] if ph <= 0 else T.eltwise(dh[r:], T.MODE_DROPOUT, p_drop=ph, seed=self._site(9000))
         dpre_e = self.ln_e.bwd(sv["pre_e"], de)

@@ -216,17 +216,19 @@ def residual_layernorm_train(t0: torch.Tensor, t1: Optional[torch.Tensor], resid
 def layernorm_bwd_fused(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor, eps: float,
                         dtype16: torch.dtype, t_add: Optional[torch.Tensor] = None, dbias: Optional[torch.Tensor] = None,
                         dbias2: Optional[torch.Tensor] = None, alpha: float = 1.0, p_drop: float = 0.0, seed: int = 0, want_dx: bool = True,
-                        want_dt: bool = True, dx: Optional[torch.Tensor] = None):
+                        want_dt: bool = True, dx: Optional[torch.Tensor] = None, dt16: Optional[torch.Tensor] = None):
     """Adjoint of `residual_layernorm_train` (cir_layernorm_bwd_fused): x (the saved pre) / dy fp32 (rows, cols) -> (dx fp32: gradient of pre =
     of the residual; dt16: alpha * dropout'(dx + t_add) in `dtype16`, the dense branch's gradient, its column sums accumulated into dbias /
     dbias2).  dgamma / dbeta are accumulated."""
-    _need_cuda(x, gamma, dy, dgamma, dbeta, t_add, dbias, dbias2, dx)
+    _need_cuda(x, gamma, dy, dgamma, dbeta, t_add, dbias, dbias2, dx, dt16)
     rows, cols = x.shape
     for t in (x, dy, t_add, dx):
         assert t is None or (t.dtype == torch.float32 and t.shape == (rows, cols) and t.is_contiguous())
     if dx is None and want_dx:
         dx = torch.empty_like(x)
-    dt16 = torch.empty((rows, cols), dtype=dtype16, device=x.device) if want_dt else None
+    if dt16 is None and want_dt:
+        dt16 = torch.empty((rows, cols), dtype=dtype16, device=x.device)
+    assert dt16 is None or (dt16.dtype == dtype16 and dt16.shape == (rows, cols) and dt16.is_contiguous())
     _lib.check(_lib.load().cir_layernorm_bwd_fused(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), _ptr(dx), dgamma.data_ptr(), dbeta.data_ptr(),
                                                    _ptr(t_add), _ptr(dt16), _ptr(dbias), _ptr(dbias2), rows, cols, float(eps), float(alpha),
                                                    float(p_drop), int(seed) & (2 ** 63 - 1), _DT[dtype16], _stream()), "cir_layernorm_bwd_fused")

@@ -468,10 +468,10 @@ def test_training_step_with_dropout_against_oracle_with_the_same_masks(cuda, dty
                 cache[key] = H.pair_keep(tr._site(layer, 2, 4), r, d, 0.1).view(bsz, bsz, l, d)
             elif kind == "ffn_out":                                                                            # both branches stacked: 2R rows
                 cache[key] = H.pair_keep(tr._site(layer, 0, 5), 2 * r, d, 0.1).view(2, bsz, bsz, l, d)
-            elif kind == "self_attn":                                                                          # group = triplet j * B + i
-                cache[key] = H.pair_keep(tr._site(layer, b, 1), bsz * bsz * heads * l, l, 0.1).view(bsz, bsz, heads, l, l)
-            elif kind == "cross_attn":                                                                         # group = target j, rows = (query i, token)
-                cache[key] = H.pair_keep(tr._site(layer, b, 3), bsz * heads * bsz * l, n, 0.1).view(bsz, heads, bsz, l, n)
+            elif kind == "self_attn":                                                      # ONE site for both branches: group = (branch, triplet j * B + i)
+                cache[key] = H.pair_keep(tr._site(layer, 0, 1), 2 * bsz * bsz * heads * l, l, 0.1).view(2, bsz, bsz, heads, l, l)[b]
+            elif kind == "cross_attn":                                                     # group = (branch, target j), rows = (query i, token)
+                cache[key] = H.pair_keep(tr._site(layer, 0, 3), 2 * bsz * heads * bsz * l, n, 0.1).view(2, bsz, heads, bsz, l, n)[b]
         return cache[key]
 
     def drop(kind, layer, b, qi, x):

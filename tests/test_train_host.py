@@ -21,13 +21,17 @@ def test_trained_set_and_slab_order():
     assert sorted(order) == sorted(names) and len(set(order)) == len(order)
     pos = {n: i for i, n in enumerate(order)}
     for layer in (0, 6, 11):
-        for b in (0, 1):
-            s = f"text_encoder.encoder.layer.{layer}.attention.self{b}."
-            i = pos[s + "query.weight"]
-            assert [order[i + j] for j in range(6)] == [s + f"{x}.{y}" for y in ("weight", "bias") for x in ("query", "key", "value")]
-            c = f"text_encoder.encoder.layer.{layer}.crossattention.self{b}."
-            i = pos[c + "key.weight"]
-            assert [order[i + j] for j in range(4)] == [c + f"{x}.{y}" for y in ("weight", "bias") for x in ("key", "value")]
+        p = f"text_encoder.encoder.layer.{layer}."
+        # the q | k | v of branch 0, then of branch 1 (one stacked Linear each, the twins a constant stride apart), then the biases alike
+        i = pos[p + "attention.self0.query.weight"]
+        assert [order[i + j] for j in range(12)] == [p + f"attention.self{b}.{x}.{y}" for y in ("weight", "bias") for b in (0, 1) for x in ("query", "key", "value")]
+        i = pos[p + "crossattention.self0.key.weight"]
+        assert [order[i + j] for j in range(8)] == [p + f"crossattention.self{b}.{x}.{y}" for y in ("weight", "bias") for b in (0, 1) for x in ("key", "value")]
+        for stem in ("attention.output.dense", "crossattention.output.dense"):
+            i = pos[p + stem + "0.weight"]
+            assert [order[i + j] for j in range(4)] == [p + stem + f"{b}.{y}" for y in ("weight", "bias") for b in (0, 1)]
+        i = pos[p + "crossattention.self0.query.weight"]
+        assert [order[i + j] for j in range(4)] == [p + f"crossattention.self{b}.query.{y}" for y in ("weight", "bias") for b in (0, 1)]
     # every slice of a stacked group is a multiple of 8 elements: adjacency survives the slab's 8-element padding
     assert all(torch.Size(spec[n][0]).numel() % 8 == 0 for n in order if ".self" in n)
 
