@@ -39,8 +39,8 @@ def wrap(mod, name, key_fn):
     setattr(mod, name, timed)
 
 step(); step(); torch.cuda.synchronize()
-wrap(ops, "gemm", lambda a, w, *r, **kw: ("gemm", a.shape[-2], w.shape[-2], a.shape[-1], str(kw.get("out_dtype") or a.dtype)[6:], kw.get("residual") is not None,
-                                           2.0 * a.shape[-2] * w.shape[-2] * a.shape[-1]))
+wrap(ops, "gemm", lambda a, w, *r, **kw: ("gemm x%d" % (a.shape[0] if a.dim() == 3 else 1), a.shape[-2], w.shape[-2], a.shape[-1], str(kw.get("out_dtype") or a.dtype)[6:],
+                                           kw.get("residual") is not None, 2.0 * (a.shape[0] if a.dim() == 3 else 1) * a.shape[-2] * w.shape[-2] * a.shape[-1]))
 wrap(T, "wgrad_grouped", lambda probs: ("wgrad_grouped", len(probs), 0, 0, "float32", False, sum(2.0 * dy.shape[0] * dy.shape[1] * x.shape[1] for dy, x, _ in probs)))
 wrap(T, "attention_train_fwd", lambda q, k, *r, **kw: ("attn_fwd", q.shape[0] * q.shape[1], q.shape[2], k.shape[2], "", False, 4.0 * q.shape[0] * q.shape[1] * q.shape[2] * k.shape[2] * 64))
 wrap(T, "attention_train_bwd", lambda q, k, *r, **kw: ("attn_bwd", q.shape[0] * q.shape[1], q.shape[2], k.shape[2], "", False, 14.0 * q.shape[0] * q.shape[1] * q.shape[2] * k.shape[2] * 64))
