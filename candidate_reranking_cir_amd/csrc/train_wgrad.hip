@@ -172,7 +172,7 @@ extern "C" int cir_wgrad_grouped(const cir_wgrad_desc* d, int count, int in_dtyp
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (tiles_total > 0) {
         // Units of about equal length: a problem with k times the rows of the shortest one is split k ways (the FFN's 2R rows against
-        // the attention projections' R); everything is split further only when the whole group has fewer units than ~3 per CU.
+        // the attention projections' R); everything is split further until the group has ~9 units per CU (see `extra`).
         // Longest units first: the tail of the launch is then made of short ones.
         int order[kWgMaxProblems], n_act = 0;
         for (int i = 0; i < count; ++i) if (d[i].rows / 64 > 0) order[n_act++] = i;
@@ -181,7 +181,13 @@ extern "C" int cir_wgrad_grouped(const cir_wgrad_desc* d, int count, int in_dtyp
             const cir_wgrad_desc& q = d[order[j]];
             units_at_unit_len += (int64_t)(q.N / 128) * (q.K / 128) * ((q.rows / 64 + min_steps - 1) / min_steps);
         }
-        int64_t extra = (768 + units_at_unit_len - 1) / units_at_unit_len;     // further split factor for small groups
+        // further split factor: about 2300 units per launch.  Measured on one BertLayer's 13 products (1224 units of 128 steps unsplit):
+        // every unit halved (2448 units of 64 steps, every tile added by two workgroups' atomics) 546 us against 634 unsplit and 580 in
+        // thirds - the tail of a 2.4-round launch costs more than the second adder's atomic traffic
+        // (a launch that does not fill the chip on its own - a single product - keeps the smaller target: there the atomic traffic of
+        // every extra split outweighs the balance, tools/bmm_bench.py: 36 tiles are best at 8 splits, 108 at 4)
+        const int64_t target = units_at_unit_len >= 512 ? 2304 : 768;
+        int64_t extra = (target + units_at_unit_len - 1) / units_at_unit_len;
         if (extra > min_steps / 4) extra = min_steps / 4;
         if (extra < 1) extra = 1;
         const int64_t unit_len = (min_steps + extra - 1) / extra;
@@ -191,7 +197,8 @@ extern "C" int cir_wgrad_grouped(const cir_wgrad_desc* d, int count, int in_dtyp
             const cir_wgrad_desc& q = d[order[j]];
             WgradProblem& p = a.p[j];
             const int64_t steps = q.rows / 64;
-            int64_t sp = q.splits > 0 ? q.splits : (steps + unit_len - 1) / unit_len;
+            int64_t sp = q.splits > 0 ? q.splits : (steps + unit_len / 2) / unit_len;     // nearest: 144 steps against 64-step units are 2 x 72, not 3 x 48
+            if (sp < 1) sp = 1;
             if (sp > steps) sp = steps;
             p.dy = q.dy; p.ldy = q.ldy; p.x = q.x; p.ldx = q.ldx; p.dw = q.dw; p.ldw = q.ldw;
             p.tiles_k = q.K / 128; p.total_steps = (int)steps;

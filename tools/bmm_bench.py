@@ -35,6 +35,19 @@ probs = [(torch.randn(rows, n, device="cuda", dtype=dt), torch.randn(rows, k, de
 fl = sum(2 * rows * n * k for rows, n, k in layer)
 us = timeit(lambda: T.wgrad_grouped(probs))
 print(f"cir_wgrad_grouped, one layer (13 problems, {fl / 1e9:.0f} GFLOP): {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s")
+import ctypes
+from candidate_reranking_cir_amd import lib as L
+from candidate_reranking_cir_amd.ops import _DT, _stream
+def grouped_with(split_fn):
+    arr = (L.WgradDesc * len(probs))()
+    for dsc, (dy, x, dw) in zip(arr, probs):
+        rows, n = dy.shape; k = x.shape[1]
+        dsc.dy, dsc.ldy, dsc.x, dsc.ldx, dsc.dw, dsc.ldw, dsc.rows, dsc.N, dsc.K, dsc.splits = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0), rows, n, k, split_fn(rows)
+    return lambda: L.check(L.load().cir_wgrad_grouped(ctypes.addressof(arr), len(probs), _DT[dt], _stream()), "cir_wgrad_grouped")
+for name, fn in (("unsplit units (FFN halved: 1224 units of 128 steps)", lambda r: 1 if r <= 9232 else 2), ("every unit halved (2448 units)", lambda r: 2 if r <= 9232 else 4),
+                 ("in thirds (3672 units)", lambda r: 3 if r <= 9232 else 6)):
+    us = timeit(grouped_with(fn))
+    print(f"cir_wgrad_grouped, explicit splits - {name}: {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s")
 us = timeit(lambda: [T.wgrad(*p) for p in probs])
 print(f"the same 13 as single launches:                   {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s")
 b, h, l, n_tok, d = 16, 12, 32, 577, 768
