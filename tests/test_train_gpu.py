@@ -547,3 +547,33 @@ def test_benchmark_geometry_sub_batch_property(cuda):
         worst = max(worst, (((g16[k] - r8).norm() / r8.norm()).item(), k))
     print(f"\n[B = 16 x 577 tokens against its B = 8 sub-batch] logits bit-equal; worst gradient difference {worst[0]:.3e} ({worst[1]})")
     assert worst[0] < 1e-4
+
+
+def test_fp16_loop_at_benchmark_geometry(cuda):
+    """The library's default precision (fp16 operands, internal loss scale) through the reference's loop at the BENCHMARK's geometry
+    (B = 16 -> 256 triplets, 577 image tokens, full med_config, dropout 0.1 / 0.1): eight AdamW steps on one batch - no step is skipped for
+    non-finite gradients (the fp16 range holds under the internal scale, incl. the unscaled dS of the attention adjoint), every loss is
+    finite and the loss moves down."""
+    from candidate_reranking_cir_amd.train import AdamW
+    g, v = H.geometry(dict(H.FULL_BERT, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1), dict(image_size=384))
+    m2, _ = build(g, v, 29, "test", HF)
+    freeze_vit(m2)
+    b, l, n, d = 16, 32, 577, g.hidden_size
+    gen = torch.Generator().manual_seed(5)
+    caps = [synthetic.caption_text(400 + q, 6 + q % 9) for q in range(b)]
+    z_t = (torch.randn((b, max(len(synthetic.HashTokenizer()([c]).input_ids[0]) for c in caps), d), generator=gen)).cuda()
+    feats = torch.randn((b, n, d), generator=gen).cuda()
+    m2.train()
+    opt = AdamW([p for p in m2.parameters() if p.requires_grad], lr=2e-4, weight_decay=0.05, model=m2)
+    losses = []
+    for _ in range(8):
+        opt.zero_grad()
+        loss = F.cross_entropy(m2.img_txt_fusion(z_t, feats, caps), torch.arange(b, device=cuda))
+        loss.backward()
+        assert bool(m2._trainer.grads_finite)
+        opt.step()
+        losses.append(loss.item())
+    print(f"\n[fp16 loop, B = 16 x 577 tokens, dropout 0.1] losses {[round(x, 3) for x in losses]}; skipped {getattr(opt, 'skipped_steps', 0)}")
+    assert all(np.isfinite(losses)) and getattr(opt, "skipped_steps", 0) == 0
+    assert min(losses[-3:]) < losses[0] - 0.05               # random inputs, dropout noise at lr 2e-4: measured 2.780 -> 2.663
+    m2.eval()
