@@ -9,7 +9,7 @@
  * the stub a reference maintainer would add.
  *
  * Conventions
- *   - every pointer is a DEVICE pointer (tensor.data_ptr()); the caller owns all buffers; the
+ *   - every pointer is a DEVICE pointer (tensor.data_ptr()) - except cir_wgrad_grouped's descriptor array -; the caller owns all buffers; the
  *     library allocates nothing, never synchronises the device, and keeps no state besides the
  *     kernel-selection overrides of cir_set_tuning (default: none) and the cached CU count;
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
@@ -230,7 +230,10 @@ int cir_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, float* dw
 /* Up to 16 weight gradients in ONE launch: dw_i += dy_i^T x_i.  The 13 weight gradients of one two-branch BertLayer together have ~940 output
  * tiles - enough to fill the chip with every tile's row sum formed by one workgroup (plain adds, no atomics; a 768 x 768 weight alone has 36
  * tiles and needs an 8 .. 16-way row split whose atomic traffic costs as much as the product).  Units are balanced by splitting the longer row
- * counts (the FFN's stacked 2R rows) to the shortest one's length.  Same shape rules as cir_wgrad; splits 0 = automatic. */
+ * counts (the FFN's stacked 2R rows) to the shortest one's length - and, when the group fills the chip, halved once more (two workgroups' atomic
+ * adds per tile: measured faster than the tail of a 2.4-round launch).  Same shape rules as cir_wgrad; splits 0 = automatic.
+ * `problems` is a HOST array (the one exception to "every pointer is a device pointer": it is read during the call, its members dy / x / dw are
+ * device pointers); count <= 16 (CIR_ESHAPE beyond: call again). */
 typedef struct { const void* dy; int64_t ldy; const void* x; int64_t ldx; float* dw; int64_t ldw; int64_t rows; int N, K, splits; } cir_wgrad_desc;
 int cir_wgrad_grouped(const cir_wgrad_desc* problems, int count, int in_dtype, void* stream);
 /* P = softmax(S * scale + mask) per row (S fp32 (rows, cols); mask fp32 (cols) shared by each group of rows_per_mask rows, or
