@@ -129,3 +129,41 @@ def splitmix_keep(seed: int, n: int, p: float) -> torch.Tensor:
         z = z ^ (z >> np.uint64(31))
     u = (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
     return torch.from_numpy(u >= np.float32(p))
+
+
+def dropout_hooks(tr, bsz: int, l: int, n: int, d: int, heads: int, p: float):
+    """(drop, keep) for `oracle.cir_oracle.img_txt_fusion_train(drop=)`: the masks of every dropout site of the LAST forward of `tr`
+    (a train.NlvrTrainer), regenerated on the host from the kernels' counters - the seeds of `tr._site`, the element numbering of each site
+    (candidate-major triplets t = j * B + i, both branches stacked in the FFN and in the attention launches' groups)."""
+    r = bsz * bsz * l
+    cache = {}
+
+    def keep(kind, layer, b):
+        key = (kind, layer, b)
+        if key not in cache:
+            if kind == "emb":
+                cache[key] = splitmix_keep(tr._site(9000), r * d, p).view(bsz, bsz, l, d)                        # [target j][query i]; cir_eltwise's generator
+            elif kind == "self_out":
+                cache[key] = pair_keep(tr._site(layer, b, 2), r, d, p).view(bsz, bsz, l, d)
+            elif kind == "cross_out":
+                cache[key] = pair_keep(tr._site(layer, 2, 4), r, d, p).view(bsz, bsz, l, d)
+            elif kind == "ffn_out":                                                                            # both branches stacked: 2R rows
+                cache[key] = pair_keep(tr._site(layer, 0, 5), 2 * r, d, p).view(2, bsz, bsz, l, d)
+            elif kind == "self_attn":                                                      # ONE site for both branches: group = (branch, triplet j * B + i)
+                cache[key] = pair_keep(tr._site(layer, 0, 1), 2 * bsz * bsz * heads * l, l, p).view(2, bsz, bsz, heads, l, l)[b]
+            elif kind == "cross_attn":                                                     # group = (branch, target j), rows = (query i, token)
+                cache[key] = pair_keep(tr._site(layer, 0, 3), 2 * bsz * heads * bsz * l, n, p).view(2, bsz, heads, bsz, l, n)[b]
+        return cache[key]
+
+    def drop(kind, layer, b, qi, x):
+        k = keep(kind, layer, b)
+        if kind == "ffn_out":
+            mk = k[b][:, qi]
+        elif kind == "cross_attn":
+            mk = k[:, :, qi]
+        else:
+            mk = k[:, qi]
+        assert mk.shape == x.shape, (kind, mk.shape, x.shape)
+        return x * mk.to(x.dtype) / (1.0 - p)
+
+    return drop, keep

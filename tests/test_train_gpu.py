@@ -454,36 +454,7 @@ def test_training_step_with_dropout_against_oracle_with_the_same_masks(cuda, dty
     loss.backward()
     tr = m2._trainer
     assert tr.p_hidden == 0.1 and tr.p_attn == 0.1
-    r = bsz * bsz * l
-    cache = {}
-
-    def keep(kind, layer, b):
-        key = (kind, layer, b)
-        if key not in cache:
-            if kind == "emb":
-                cache[key] = H.splitmix_keep(tr._site(9000), r * d, 0.1).view(bsz, bsz, l, d)                 # [target j][query i]; cir_eltwise's generator
-            elif kind == "self_out":
-                cache[key] = H.pair_keep(tr._site(layer, b, 2), r, d, 0.1).view(bsz, bsz, l, d)
-            elif kind == "cross_out":
-                cache[key] = H.pair_keep(tr._site(layer, 2, 4), r, d, 0.1).view(bsz, bsz, l, d)
-            elif kind == "ffn_out":                                                                            # both branches stacked: 2R rows
-                cache[key] = H.pair_keep(tr._site(layer, 0, 5), 2 * r, d, 0.1).view(2, bsz, bsz, l, d)
-            elif kind == "self_attn":                                                      # ONE site for both branches: group = (branch, triplet j * B + i)
-                cache[key] = H.pair_keep(tr._site(layer, 0, 1), 2 * bsz * bsz * heads * l, l, 0.1).view(2, bsz, bsz, heads, l, l)[b]
-            elif kind == "cross_attn":                                                     # group = (branch, target j), rows = (query i, token)
-                cache[key] = H.pair_keep(tr._site(layer, 0, 3), 2 * bsz * heads * bsz * l, n, 0.1).view(2, bsz, heads, bsz, l, n)[b]
-        return cache[key]
-
-    def drop(kind, layer, b, qi, x):
-        k = keep(kind, layer, b)
-        if kind == "ffn_out":
-            mk = k[b][:, qi]
-        elif kind == "cross_attn":
-            mk = k[:, :, qi]
-        else:
-            mk = k[:, qi]
-        assert mk.shape == x.shape, (kind, mk.shape, x.shape)
-        return x * mk.to(x.dtype) / 0.9
+    drop, keep = H.dropout_hooks(tr, bsz, l, n, d, heads, 0.1)
 
     names = [str(nm) for nm in z["names"]]
     w = {k: t.clone().float() for k, t in sd2.items()}

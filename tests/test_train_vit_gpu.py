@@ -161,3 +161,52 @@ def test_optimizer_and_engine_follow_a_fine_tuned_vit(cuda):
     with pytest.raises(RuntimeError, match="ONE call"):
         (f1.sum() + f2.sum()).backward()
     m2.eval()
+
+
+def test_full_step_with_every_random_part_on_against_the_oracle(cuda):
+    """Everything stochastic at once - DropPath in the ViT (rate 0.6 so that both outcomes occur in 4 samples x 2 branches), hidden and
+    attention-probability dropout 0.1 in the two-branch encoder - in ONE training step with the image encoder trained: the DropPath
+    factors and all dropout masks of the step are regenerated on the host from the trainers' counters and handed to the oracle
+    (`branch_scale=`, `drop=`); logits and all 602 parameter gradients (text side, cls_head, ViT) must match torch autograd for that draw."""
+    from oracle import cir_oracle as O
+    z = H.load("train_imgtune.npz")
+    cfg = dict(json.loads(str(z["bert_cfg"])), hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    g, v = H.geometry(cfg, dict(json.loads(str(z["vit_cfg"])), drop_path_rate=0.6))
+    m2, sd2 = build(g, v, int(z["seed"]), str(z["profile"]), HF)
+    images = synthetic.scene_images(z["image_ids"].tolist(), v.image_size)
+    bsz, l = z["input_ids"].shape
+    m2.train()
+    feats = m2.img_embed(images.cuda())
+    caps = [str(c) for c in z["caps"]]
+    z_t = torch.from_numpy(z["z_t"])
+    logits = m2.img_txt_fusion(z_t.cuda(), feats, caps, train=True)
+    F.cross_entropy(logits, torch.arange(bsz, device=cuda)).backward()
+    tr, tv = m2._trainer, m2._vit_trainer
+    dp = tv.sv["dp"].cpu()
+    assert 0.0 in dp[1].flatten().tolist() and 2.5 in np.round(dp[1].flatten().tolist(), 4)
+    drop, _ = H.dropout_hooks(tr, bsz, l, feats.shape[1], g.hidden_size, g.num_attention_heads, 0.1)
+    names = [str(n) for n in z["names"]]
+    w = {k: t.clone().float() for k, t in sd2.items()}
+    for k in names:
+        w[k].requires_grad_(True)
+    torch.set_num_threads(8)
+    o_feats = O.vit_forward(w, images, branch_scale=dp)
+    o_logits = O.img_txt_fusion_train(w, z_t, o_feats, torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]),
+                                      relu_mask=tr.head_mask().cpu(), drop=drop)
+    F.cross_entropy(o_logits, torch.arange(bsz)).backward()
+    e_f = (feats.detach().cpu() - o_feats.detach()).abs().max().item()
+    e_log = (logits.detach().cpu() - o_logits.detach()).abs().max().item()
+    params = dict(m2.named_parameters())
+    gmax = max(w[n].grad.norm().item() for n in names)
+    worst = {"visual_encoder.": (0.0, ""), "text": (0.0, "")}
+    for n in names:
+        ref = w[n].grad
+        if ref.norm().item() < 1e-6 * gmax:
+            continue
+        part = "visual_encoder." if n.startswith("visual_encoder.") else "text"
+        worst[part] = max(worst[part], (((params[n].grad.cpu() - ref).norm() / ref.norm()).item(), n))
+    print(f"\n[DropPath 0.6 + dropout 0.1 / 0.1, fp16] tokens {e_f:.3e}  logits {e_log:.3e}  worst grad rel: ViT {worst['visual_encoder.'][0]:.3e} "
+          f"({worst['visual_encoder.'][1]}), text side {worst['text'][0]:.3e} ({worst['text'][1]})")
+    assert e_f < FEATS_ABS[HF] and e_log < 2 * LOGIT_ABS[HF]
+    assert worst["text"][0] < 1.5 * GRAD_REL[HF] and worst["visual_encoder."][0] < 1.5 * GRAD_REL[HF]
+    m2.eval()
