@@ -53,6 +53,12 @@ def canonical(name: str):
                 mm = re.search(short + r"I(DF16b|DF16_|Dh)Lb([01])E", name)
                 masked = ("<masked>" if (mm and mm.group(2) == "1") or ("true>" in name and not mm) else "<unmasked>")
             return f"cir::{short}{masked}"
+    for short in ("wgrad_kernel", "tattn_fwd_kernel", "tattn_bwd_dq_kernel", "tattn_bwd_dkv_kernel", "ln_bwd_fused_kernel", "res_ln_train_kernel",
+                  "rows16_colsum_kernel", "rows_scale_add_kernel", "bmm_mfma_kernel", "eltwise_kernel", "adamw_kernel", "transpose_multi_kernel",
+                  "layernorm_bwd_kernel", "colsum_kernel", "embed_bwd_kernel"):      # the training step's kernels (train*.hip)
+        if short in name:
+            mm = re.search(short + r"I(DF16b|DF16_|Dh)Lb([01])E", name) if short.startswith("tattn") else None
+            return f"cir::{short}" + (("<masked>" if mm.group(2) == "1" else "<unmasked>") if mm else "")
     return "cir::other"
 
 
@@ -83,8 +89,11 @@ def main():
             for ln in open(jf):
                 if ln.startswith('{"metric"'):
                     cfg = json.loads(ln)
-                    meta = {"residual_stream": cfg["config"]["residual_stream"], "queries": cfg["config"]["queries_per_step_per_gpu"],
-                            "k": cfg["config"]["k"], "subset": cfg["config"]["subset"], "image_size": cfg["config"]["image_size"], "dtype": cfg["dtype"]}
+                    if "queries_per_step_per_gpu" in cfg["config"]:
+                        meta = {"residual_stream": cfg["config"]["residual_stream"], "queries": cfg["config"]["queries_per_step_per_gpu"],
+                                "k": cfg["config"]["k"], "subset": cfg["config"]["subset"], "image_size": cfg["config"]["image_size"], "dtype": cfg["dtype"]}
+                    else:                                  # `--mode train` (or another secondary mode): keep its own workload string
+                        meta = {"workload": cfg["config"]["workload"], "dtype": cfg["dtype"]}
             break
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
