@@ -17,7 +17,14 @@ rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_B
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_fetch -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-precision-table > $OUT/${TAG}_pmc_fetch.json 2> $OUT/${TAG}_pmc_fetch.err
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_write -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-precision-table > $OUT/${TAG}_pmc_write.json 2> $OUT/${TAG}_pmc_write.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_train_stats -o run -- python3 $ROOT/bench.py --mode train --image-size 384 --steps 4 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_train_stats.json 2> $OUT/${TAG}_train_stats.err
+# the training step's kernels under the same three PMC passes (MFMA-pipe utilisation, fetched / written bytes per launch)
+for grp in "sq:SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
+  name=${grp%%:*}; ctr=${grp#*:}
+  rocprofv3 --kernel-trace --output-format csv --pmc $ctr -d $OUT/${TAG}_train_pmc_$name -o run -- python3 $ROOT/bench.py --mode train --image-size 384 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_train_pmc_$name.json 2> $OUT/${TAG}_train_pmc_$name.err
+done
 cd $ROOT
+find $OUT/${TAG}_train_pmc_sq $OUT/${TAG}_train_pmc_fetch $OUT/${TAG}_train_pmc_write -name "*kernel_trace.csv" -delete
+python3 tools/pmc_summary.py $OUT/${TAG}_train_pmc_summary.json $OUT/${TAG}_train_pmc_sq $OUT/${TAG}_train_pmc_fetch $OUT/${TAG}_train_pmc_write > $OUT/${TAG}_train_pmc_summary.txt 2>&1
 find $OUT/${TAG}_train_stats -name "*kernel_trace.csv" -delete
 python3 tools/kstats.py $OUT/${TAG}_train_stats 7 > $OUT/${TAG}_train_kstats.txt 2>&1      # 2 warm-up + 4 timed + 1 step with per-leg syncs
 # keep what travels back small: the per-dispatch kernel traces are not needed (the counter CSVs carry timestamps)
