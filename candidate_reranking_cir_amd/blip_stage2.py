@@ -91,6 +91,8 @@ class _EngineHost(nn.Module):
         Measured against the reference's fp32 outputs (profiles/r4_precision_modes.json): with fp16
         operands, fp32 storage of the text-side stream moves Kendall's tau on the outlier fixture 0.91 -> 0.94 and the exact
         positions on rank224 0.93 -> 0.96 for 3.6 % of the step; the ViT's stream is rank-neutral in fp16."""
+        if self.compute_dtype == torch.float32:
+            return torch.float32
         return self._stream_dtype if self._stream_dtype is not None else torch.float16
 
     def set_stream_dtype(self, dtype: Optional[torch.dtype], vit: Optional[torch.dtype] = "same"):
@@ -107,20 +109,24 @@ class _EngineHost(nn.Module):
 
     @property
     def vit_stream_dtype(self) -> torch.dtype:
+        if self.compute_dtype == torch.float32:
+            return torch.float32
         return self._vit_stream_dtype if self._vit_stream_dtype is not None else torch.float16
 
     def set_compute_dtype(self, dtype: torch.dtype, image_dtype: Optional[torch.dtype] = None):
         """Operand type of every MFMA product (bf16 or fp16; fp32 accumulate either way).  `image_dtype` gives the ViT and the
         image-facing cross-attention block of the text encoders their own operand type (engine.py, "MIXED")."""
         for d in (dtype, image_dtype):
-            if d not in (None, torch.bfloat16, torch.float16) or dtype is None:
-                raise ValueError("compute dtype must be torch.bfloat16 or torch.float16 (fp32 accumulate either way)")
+            if d not in (None, torch.bfloat16, torch.float16, torch.float32) or dtype is None:
+                raise ValueError("compute dtype must be torch.bfloat16, torch.float16 (fp32 accumulate either way) or torch.float32 (exact mode)")
+        if torch.float32 in (dtype, image_dtype) and not (dtype == torch.float32 and image_dtype in (None, torch.float32)):
+            raise ValueError("fp32 operands are all-or-nothing: use set_precision('exact')")
         self.compute_dtype = dtype
         self.image_dtype = None if image_dtype == dtype else image_dtype
         self._engines = None
         return self
 
-    PRECISIONS = ("bf16", "f16", "mixed")
+    PRECISIONS = ("bf16", "f16", "mixed", "exact")
 
     def set_precision(self, mode: str):
         """"bf16" / "f16": one operand type everywhere.  "mixed": bf16 operands for the ViT and the cross-attention block
@@ -129,6 +135,16 @@ class _EngineHost(nn.Module):
         (profiles/r4_precision_attribution_*.json)."""
         if mode not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {self.PRECISIONS}")
+        if mode == "exact":
+            # Round 5: the reference's own precision (validate_stage2.py:140-141, 288-289: model.float()) - fp32 weights, activations,
+            # attention operands and residual streams, every product on the f32-input MFMA (IEEE fmaf chains), erf GELU as written,
+            # the merge layers and the last layer's K / V projections un-folded.  The mode that holds the reference's rank order
+            # (north_star: "identical top-K rank order"), and the on-device referee for sizes the CPU reference cannot reach; ~1/9 of
+            # the default mode's throughput (DESIGN.md section 2).
+            self.set_compute_dtype(torch.float32)
+            return self.set_stream_dtype(torch.float32)
+        if self.compute_dtype == torch.float32:        # leaving exact mode: back to the automatic stream storage
+            self.set_stream_dtype(None)
         if mode == "mixed":
             return self.set_compute_dtype(torch.float16, torch.bfloat16)
         return self.set_compute_dtype(torch.bfloat16 if mode == "bf16" else torch.float16)
@@ -138,7 +154,7 @@ class _EngineHost(nn.Module):
         if self.image_dtype is not None:
             return "mixed" if (self.compute_dtype, self.image_dtype) == (torch.float16, torch.bfloat16) else \
                 f"{str(self.compute_dtype)[6:]}+{str(self.image_dtype)[6:]}"
-        return "bf16" if self.compute_dtype == torch.bfloat16 else "f16"
+        return {torch.bfloat16: "bf16", torch.float16: "f16", torch.float32: "exact"}[self.compute_dtype]
 
     @property
     def token_dtype(self) -> torch.dtype:
@@ -181,7 +197,7 @@ class BLIP_NLVR(_EngineHost):
                 raise RuntimeError("BLIP_NLVR runs on an MI355X only: move the model to 'cuda' (no CPU path)")
             sd = self.state_dict()
             self._engines = (VitEngine(sd, self.vit_geometry, self.token_dtype, dev, stream_dtype=self.vit_stream_dtype),
-                             NlvrEngine(sd, self.bert_geometry, self.compute_dtype, dev, fold_merge=self.fold_merge, stream_dtype=self.stream_dtype,
+                             NlvrEngine(sd, self.bert_geometry, self.compute_dtype, dev, fold_merge=self.fold_merge and self.compute_dtype != torch.float32, stream_dtype=self.stream_dtype,
                                         cross_dtype=self.token_dtype))
             self._text_stale = False
             self._packed_epoch = _lib.PARAM_EPOCH[0]
@@ -196,7 +212,7 @@ class BLIP_NLVR(_EngineHost):
             # after training steps (the forward marks it; every cir_adamw_step launch moves lib.PARAM_EPOCH, so an eval call made
             # between backward() and step() cannot leave the engine on the pre-step weights): repack the two-branch encoder only (the ViT is frozen there),
             self._engines = (self._engines[0], NlvrEngine(self.state_dict(), self.bert_geometry, self.compute_dtype, self.device,
-                                                          fold_merge=self.fold_merge, stream_dtype=self.stream_dtype, cross_dtype=self.token_dtype))
+                                                          fold_merge=self.fold_merge and self.compute_dtype != torch.float32, stream_dtype=self.stream_dtype, cross_dtype=self.token_dtype))
             self._text_stale = False           # and only when a caller needs it (`text`): img_embed between steps does not
             self._packed_epoch = _lib.PARAM_EPOCH[0]
         return self._engines

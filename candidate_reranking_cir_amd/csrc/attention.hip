@@ -46,24 +46,11 @@
 //     kernel must move: neither the softmax chain nor the DRAM access pattern is the bound; a workgroup's life is load 82 KB ->
 //     compute -> store with two or three workgroups per CU to overlap, and the time is their sum, not their maximum.
 
-#include "common.hpp"
+#include "attention_args.hpp"
 
 namespace cir {
 
-struct AttnArgs {
-    const void* q; int64_t q_s1, q_s0, q_rs;
-    const void* k; int64_t k_s1, k_s0, k_rs;
-    const void* v; int64_t v_s1, v_s0, v_rs;
-    const float* mask; int64_t m_s1, m_s0;
-    const int64_t* kv_index;   // optional: item b1 reads K/V of bank row kv_index[b1] (cross-query K/V cache)
-    void* out; int64_t o_s1, o_s0, o_rs;
-    int B0, H, Lq, Lk, nqt;
-    int64_t total;
-    float scale;
-};
-
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
-constexpr float kLog2e = 1.4426950408889634f;
 
 // Online-softmax state of one 32-query tile: lane = (query r, key/dh half hh).
 struct Softmax {
@@ -540,12 +527,13 @@ extern "C" int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t 
     using namespace cir;
     CIR_CHECK_PTR(q); CIR_CHECK_PTR(k); CIR_CHECK_PTR(v); CIR_CHECK_PTR(out);
     if (B1 <= 0 || B0 <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return CIR_EINVAL;
-    if (dtype != CIR_BF16 && dtype != CIR_F16) return CIR_EDTYPE;
+    if (dtype != CIR_BF16 && dtype != CIR_F16 && dtype != CIR_F32) return CIR_EDTYPE;
     const int64_t strides[] = {q_s1, q_s0, q_rs, k_s1, k_s0, k_rs, v_s1, v_s0, v_rs};
+    const int vec = dtype == CIR_F32 ? 4 : 8;       // elements per 16-byte load
     for (int64_t s : strides)
-        if (s % 8) return CIR_EALIGN;
+        if (s % vec) return CIR_EALIGN;
     if (o_s1 % 4 || o_s0 % 4 || o_rs % 4) return CIR_EALIGN;
-    if (!cir_aligned16(q) || !cir_aligned16(k) || !cir_aligned16(v) || (reinterpret_cast<uintptr_t>(out) & 7)) return CIR_EALIGN;
+    if (!cir_aligned16(q) || !cir_aligned16(k) || !cir_aligned16(v) || (reinterpret_cast<uintptr_t>(out) & (dtype == CIR_F32 ? 15 : 7))) return CIR_EALIGN;
     AttnArgs a;
     a.q = q; a.q_s1 = q_s1; a.q_s0 = q_s0; a.q_rs = q_rs;
     a.k = k; a.k_s1 = k_s1; a.k_s0 = k_s0; a.k_rs = k_rs;
@@ -557,6 +545,7 @@ extern "C" int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t 
     a.total = (int64_t)B1 * B0 * H * a.nqt;
     a.scale = scale;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == CIR_F32) return launch_attention_f32(a, s);      // "exact" mode: fp32 operands in both products (attention_f32.hip)
     const int lk_pad = (Lk + 31) & ~31;
     // K/V of a head are shared by its query tiles: stage them once per workgroup when there are several tiles
     // (up to 608 keys = 152 KiB of LDS: the 577-token ViT of the reference's 384-px scripts still fits one CU)

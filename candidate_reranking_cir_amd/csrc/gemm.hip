@@ -23,7 +23,30 @@
 namespace cir {
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int kTileBytes = BM * BK * 2;  // 16 KiB per operand tile
+constexpr int kTileBytes = BM * BK * 2;  // 16 KiB per operand tile: 128 rows of 128 bytes = 64 16-bit or 32 fp32 k-values per row
+
+// fp32 operands (the "exact" precision mode, round 5): the same tile image - a 128-byte row holds 32 fp32 k-values, a 16-byte
+// chunk 4 of them - on v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: a chain of IEEE fmaf's, 1/16 of the 16-bit MFMA rate,
+// 157.3 TFLOP/s peak).  Lane group g reads chunk g of a 64-byte k-group as before; the chunk's 4 values feed 4 MFMAs, the
+// s-th of which contracts k = {s, 4 + s, 8 + s, 12 + s} of the group (both operands use the same map, and a sum over k does
+// not care in which MFMA a k-value rides).  Accumulator layout = the 16x16x32 one, so staging, swizzle, W-row permutation
+// and epilogue are shared with the 16-bit instantiations.
+template <> struct Elem<float> {
+    using x8 = f32x4;     // one 16-byte fragment chunk
+};
+template <typename T> struct Tile {
+    static constexpr int kChunk = 16 / (int)sizeof(T);      // elements per 16-byte chunk
+    static constexpr int kBK = 128 / (int)sizeof(T);        // k-values per tile row
+};
+template <typename T>
+__device__ __forceinline__ void mma_frag(f32x4& acc, const typename Elem<T>::x8& w, const typename Elem<T>::x8& x) {
+    if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s], x[s], acc, 0, 0, 0);
+    } else {
+        acc = Elem<T>::mfma16(w, x, acc);
+    }
+}
 
 
 // OUT: 0 = C in the operand type T, 1 = fp32 C, 2 = fp16 C (the 16-bit residual stream).  The residual is fp32 for
@@ -63,17 +86,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
         const int lrow = (wave * 4 + j) * 8 + srow;           // LDS row 0..127
         int64_t gm = m0 + lrow;
         gm = gm < a.M ? gm : a.M - 1;                         // clamp the ragged M edge (stores are predicated)
-        a_src[j] = A + gm * a.lda + schunk * 8;
+        a_src[j] = A + gm * a.lda + schunk * Tile<T>::kChunk;
         // W rows are permuted so that lane group g of the accumulator owns 16 consecutive features
         const int perm = (lrow & 64) + ((lrow & 15) >> 2) * 16 + ((lrow >> 4) & 3) * 4 + (lrow & 3);
         int gn = n0 + perm;
         gn = gn < a.N ? gn : a.N - 1;
-        w_src[j] = W + (int64_t)gn * a.ldw + schunk * 8;
+        w_src[j] = W + (int64_t)gn * a.ldw + schunk * Tile<T>::kChunk;
     }
 
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * 2 * kTileBytes + wave * 4096;
-        const int koff = kt * BK;
+        const int koff = kt * Tile<T>::kBK;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             __builtin_amdgcn_global_load_lds((gptr_t)(a_src[j] + koff), (lptr_t)(base + j * 1024), 16, 0, 0);
@@ -113,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
     const int w_row_off = (wn * 64 + r15) * 128;
     const int swz = r15 & 7;
 
-    const int nk = a.K / BK;
+    const int nk = a.K / Tile<T>::kBK;
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         // The LDS-DMA pieces of tile kt must have landed before any wave reads them.  The wait is EXPLICIT: hipcc's wait-count
@@ -136,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = Elem<T>::mfma16(wf[ni], af[mi], acc[mi][ni]);
+                for (int ni = 0; ni < 4; ++ni) mma_frag<T>(acc[mi][ni], wf[ni], af[mi]);
         }
     }
 
@@ -153,7 +176,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs a) {
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) v[ni * 4 + jj] = acc[mi][ni][jj];
-        if (a.act == CIR_ACT_GELU) {
+        if (a.act == CIR_ACT_GELU && std::is_same<T, float>::value) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = 0.5f * v[q] * (1.0f + erff(v[q] * 0.70710678118654752f));   // ACT2FN['gelu'] / nn.GELU, as written
+        } else if (a.act == CIR_ACT_GELU) {
 #pragma unroll
             for (int q = 0; q < 16; q += 8) {      // the 256 x 256 kernel's packed evaluation: the same operations, the same bits
                 float w8[8];
@@ -215,6 +241,29 @@ extern "C" int cir_gemm_bias_act(const void* A, int64_t lda, int64_t strideA, co
     using namespace cir;
     CIR_CHECK_PTR(A); CIR_CHECK_PTR(W); CIR_CHECK_PTR(C);
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return CIR_EINVAL;
+    if (in_dtype == CIR_F32) {
+        // "exact" mode (ABI v11): fp32 operands, fp32 C, fp32 residual, exact-erf GELU - v_mfma_f32_16x16x4_f32 on the 128 x 128 tile
+        if (K % 32 != 0 || N % 16 != 0) return CIR_ESHAPE;
+        if (out_dtype != CIR_F32 || (residual && res_dtype != CIR_F32)) return CIR_EDTYPE;
+        if (act < CIR_ACT_NONE || act > CIR_ACT_RELU) return CIR_EINVAL;
+        if (!cir_aligned16(A) || !cir_aligned16(W) || !cir_aligned16(C) || lda % 4 || ldw % 4 || strideA % 4 || strideW % 4 || ldc % 4 || strideC % 4)
+            return CIR_EALIGN;
+        if (bias && (!cir_aligned16(bias) || strideBias % 4)) return CIR_EALIGN;
+        if (residual && (!cir_aligned16(residual) || ldr % 4 || strideR % 4)) return CIR_EALIGN;
+        GemmArgs a;
+        a.A = A; a.lda = lda; a.sA = strideA;
+        a.W = W; a.ldw = ldw; a.sW = strideW;
+        a.bias = bias; a.sBias = strideBias;
+        a.R = residual; a.ldr = ldr; a.sR = strideR;
+        a.C = C; a.ldc = ldc; a.sC = strideC;
+        a.M = M; a.N = N; a.K = K; a.batch = batch; a.act = act; a.group_w = 1; a.dbg = 0;
+        a.tiles_m = (int)((M + BM - 1) / BM);
+        a.tiles_n = (N + BN - 1) / BN;
+        const int64_t nblk = (int64_t)a.tiles_m * a.tiles_n * batch;
+        if (nblk > 0x7fffffff) return CIR_ESHAPE;
+        hipLaunchKernelGGL((gemm_kernel<float, 1>), dim3((unsigned)nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+        CIR_LAUNCH_RESULT();
+    }
     if (K % BK != 0 || N % 16 != 0) return CIR_ESHAPE;
     if (in_dtype != CIR_BF16 && in_dtype != CIR_F16) return CIR_EDTYPE;
     if (out_dtype != in_dtype && out_dtype != CIR_F32 && out_dtype != CIR_F16) return CIR_EDTYPE;

@@ -21,7 +21,12 @@ __global__ __launch_bounds__(256) void patchify_kernel(const TI* img, TO* out, i
     const TI* src = img + ((b * C + c) * H + (py * p + ky)) * (int64_t)Wd + px * p;
     TO* dst = out + ((b * gh + py) * gw + px) * (int64_t)(C * p * p) + (c * p + ky) * p;
     if (vec) {   // the ViT-B/16 case (p = 16, aligned rows): a 16-pixel segment = 32 (or 64) contiguous, aligned bytes
-        if constexpr (sizeof(TI) == 2) {   // same 16-bit type in and out: two 16-byte moves
+        if constexpr (sizeof(TO) == 4) {   // fp32 pixels -> fp32 patches ("exact" mode): four 16-byte moves
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            float4* d4 = reinterpret_cast<float4*>(dst);
+            const float4 a0 = s4[0], a1 = s4[1], a2 = s4[2], a3 = s4[3];
+            d4[0] = a0; d4[1] = a1; d4[2] = a2; d4[3] = a3;
+        } else if constexpr (sizeof(TI) == 2) {   // same 16-bit type in and out: two 16-byte moves
             const u32x4* s4 = reinterpret_cast<const u32x4*>(src);
             u32x4* d4 = reinterpret_cast<u32x4*>(dst);
             const u32x4 v0 = s4[0], v1 = s4[1];
@@ -267,12 +272,16 @@ extern "C" int cir_patchify(const void* image, int img_dtype, void* patches, int
     CIR_CHECK_PTR(image); CIR_CHECK_PTR(patches);
     if (B <= 0 || C <= 0 || H <= 0 || Wd <= 0 || patch <= 0) return CIR_EINVAL;
     if (H % patch || Wd % patch) return CIR_ESHAPE;
-    if (dtype16 != CIR_BF16 && dtype16 != CIR_F16) return CIR_EDTYPE;
+    if (dtype16 != CIR_BF16 && dtype16 != CIR_F16 && dtype16 != CIR_F32) return CIR_EDTYPE;
     if (img_dtype != CIR_F32 && img_dtype != dtype16) return CIR_EDTYPE;
     const int64_t total = (int64_t)B * C * H * (Wd / patch);
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int vec = patch == 16 && Wd % 16 == 0 && cir_aligned16(image) && cir_aligned16(patches);
+    if (dtype16 == CIR_F32) {   // "exact" mode: the patches stay fp32 (ABI v11)
+        hipLaunchKernelGGL((patchify_kernel<float, float>), grid, block, 0, s, (const float*)image, (float*)patches, B, C, H, Wd, patch, vec);
+        CIR_LAUNCH_RESULT();
+    }
     if (dtype16 == CIR_BF16) {
         if (img_dtype == CIR_F32) hipLaunchKernelGGL((patchify_kernel<float, __bf16>), grid, block, 0, s, (const float*)image, (__bf16*)patches, B, C, H, Wd, patch, vec);
         else hipLaunchKernelGGL((patchify_kernel<__bf16, __bf16>), grid, block, 0, s, (const __bf16*)image, (__bf16*)patches, B, C, H, Wd, patch, vec);

@@ -3,7 +3,8 @@
 Each engine packs a reference-layout fp32 state dict once (16-bit weight matrices, fused QKV /
 K|V concatenations, folded merge weights; fp32 biases and LayerNorm affines) and then issues a
 fixed sequence of libcirrank launches per forward.  Precision plan: GEMM operands and attention
-tiles are 16-bit (fp16 by default since round 4, or bf16); every accumulation, the softmax and the LayerNorm statistics are
+tiles are 16-bit (fp16 by default since round 4, or bf16; or fp32 - `dtype=torch.float32`, the "exact" mode of round 5: every tensor
+fp32 like the reference's, products on the f32-input MFMA, exact-erf GELU, no algebraic folds); every accumulation, the softmax and the LayerNorm statistics are
 fp32; the RESIDUAL STREAM (x + sublayer(x), and the LayerNorm outputs that feed one) is stored in
 `stream_dtype`: fp16 by default (sum formed in fp32, rounded to 11 bits) or fp32.
 
@@ -45,7 +46,7 @@ def _auto_stream(dtype: torch.dtype, stream_dtype: Optional[torch.dtype]) -> tor
 
 def _ln(x, gamma, beta, eps, dt, sdt, residual=None, need_stream=True):
     """LayerNorm -> (stream copy in `sdt` or None, operand copy in `dt`).  One tensor serves as both when dt == sdt."""
-    if dt == sdt and need_stream:
+    if (dt == sdt and need_stream) or dt == torch.float32:      # fp32 operands ("exact" mode): the fp32 stream copy IS the operand
         y, _ = ops.layernorm(x, gamma, beta, eps, residual=residual, want32=True, dtype16=None, stream_dtype=sdt)
         return y, y
     return ops.layernorm(x, gamma, beta, eps, residual=residual, want32=need_stream, dtype16=dt, stream_dtype=sdt)
@@ -98,7 +99,10 @@ class VitEngine:
             n_parts = -(-bsz // chunk)
             size = -(-bsz // n_parts)                                          # balanced chunks (no ragged tail)
             y16 = torch.empty((bsz, n, d), dtype=dt, device=image.device) if out16 is None else out16
-            y32 = (torch.empty((bsz, n, d), dtype=torch.float32, device=image.device) if out32 is None else out32) if want32 else None
+            if dt == torch.float32 and want32 and out32 is None:
+                y32 = y16                                                      # "exact" mode: one fp32 tensor is both results
+            else:
+                y32 = (torch.empty((bsz, n, d), dtype=torch.float32, device=image.device) if out32 is None else out32) if want32 else None
             for i in range(0, bsz, size):
                 self.forward(image[i:i + size], want32, chunk, out32=None if y32 is None else y32[i:i + size], out16=y16[i:i + size])
             return y32, y16
@@ -121,6 +125,13 @@ class VitEngine:
             _, xb = _ln(x, blk["g2"], blk["b2"], geo.layer_norm_eps, dt, sdt, need_stream=False)
             f = ops.gemm(xb, blk["w1"], blk["c1"], act=ops.ACT_GELU)           # vit.py:36-37
             ops.gemm(f, blk["w2"], blk["c2"], residual=x, out_dtype=sdt, out=x)  # vit.py:39, :109
+        if dt == torch.float32:                                                # "exact" mode: one fp32 token tensor serves both roles
+            o = out16 if out16 is not None else out32
+            y32, _ = ops.layernorm(x, self.gf, self.bf, geo.layer_norm_eps, want32=True, dtype16=None, stream_dtype=torch.float32,
+                                   out32=None if o is None else o.view(bsz * n, d))
+            if out16 is not None and out32 is not None and out32.data_ptr() != out16.data_ptr():
+                out32.copy_(out16)
+            return (y32.view(bsz, n, d) if want32 else None), y32.view(bsz, n, d)
         y32, y16 = ops.layernorm(x, self.gf, self.bf, geo.layer_norm_eps, want32=want32, dtype16=dt, stream_dtype=torch.float32,
                                  out32=None if (out32 is None or not want32) else out32.view(bsz * n, d),
                                  out16=None if out16 is None else out16.view(bsz * n, d))                                       # vit.py:192
@@ -221,7 +232,8 @@ class NlvrEngine:
         self.xdtype = xdt = cross_dtype or dtype   # operand type of the cross-attention block = type of the candidate tokens (module docstring)
         self.trim_last = True   # last layer: per-token work on the CLS rows only (results identical for the rows that are used)
         self.kv_chunk = 0       # candidates per K|V + cross-attention chunk (0 = all at once; attribute, for A/B runs)
-        self.fold_cls_kv = True  # last layer: fold the cross K / V projections out of the token side (False: K|V GEMM + attention)
+        self.fold_cls_kv = xdt != torch.float32  # last layer: fold the cross K / V projections out of the token side (False: K|V GEMM +
+                                                 # attention; the "exact" fp32 mode keeps the reference's order of operations)
         e = prefix + "embeddings."
         self.word, self.posemb = _f32(sd[e + "word_embeddings.weight"], device), _f32(sd[e + "position_embeddings.weight"], device)
         self.ge, self.be = _f32(sd[e + "LayerNorm.weight"], device), _f32(sd[e + "LayerNorm.bias"], device)

@@ -24,6 +24,8 @@ def gemm_kernel_name(m: int, n: int, k: int, nb: int, has_residual: bool, act: i
                      res_dtype=None) -> str:
     """Which kernel instantiation cir_gemm_bias_act launches for a shape (mirror of the dispatch in csrc/gemm.hip; for
     reporting only - the library decides).  `out_dtype`: torch dtype (or True / False = fp32 / operand type)."""
+    if in_dtype == torch.float32:
+        return "cir::gemm_kernel<float,1>"
     if isinstance(out_dtype, bool):
         out_dtype = torch.float32 if out_dtype else in_dtype
     t = "__bf16" if in_dtype == torch.bfloat16 else "_Float16"
@@ -64,8 +66,8 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          act: int = ACT_NONE, out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out = act(a @ w.T + bias) (+ residual).  a (M,K) or (B,M,K) 16-bit with contiguous rows (any
-    row stride); w (N,K) / (B,N,K); bias fp32 (N) / (B,N); out in a.dtype (operand copy), fp32 or fp16 (residual
+    """out = act(a @ w.T + bias) (+ residual).  a (M,K) or (B,M,K) 16-bit - or fp32 with fp32 w / residual / out: the "exact"
+    mode on the f32-input MFMA - with contiguous rows (any row stride); w (N,K) / (B,N,K); bias fp32 (N) / (B,N); out in a.dtype (operand copy), fp32 or fp16 (residual
     stream, also from bf16 operands); residual shaped like out: fp32 (out in a.dtype or fp32) or fp16 (with an fp16 out; the only
     residual an fp16 out from bf16 operands takes)."""
     _need_cuda(a, w, bias, residual, out)
@@ -77,6 +79,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     nb, m, k = a3.shape
     n = w3.shape[1]
     assert w3.shape[0] == nb and w3.shape[2] == k and a3.stride(2) == 1 and w3.stride(2) == 1
+    assert w3.dtype == a3.dtype, "operands of one type (16-bit, or fp32 for the exact mode)"
     out_dtype = out_dtype or a.dtype
     if out is None:
         out = torch.empty((nb, m, n) if batched else (m, n), dtype=out_dtype, device=a.device)
@@ -209,16 +212,20 @@ def embed_layernorm(ids: torch.Tensor, word: torch.Tensor, pos: torch.Tensor, ga
         raise IndexError(f"caption of {l} tokens exceeds the {pos.shape[0]}-row position-embedding table")
     ids = ids.contiguous()
     y32 = torch.empty((r, l, cols), dtype=stream_dtype, device=ids.device)
-    y16 = torch.empty((r, l, cols), dtype=dtype16, device=ids.device)
+    if dtype16 == torch.float32:       # "exact" mode: the fp32 stream copy is the operand
+        assert stream_dtype == torch.float32
+        y16 = None
+    else:
+        y16 = torch.empty((r, l, cols), dtype=dtype16, device=ids.device)
     code = _lib.load().cir_embed_layernorm(ids.data_ptr(), word.data_ptr(), pos.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                           y32.data_ptr(), _DT[stream_dtype], y16.data_ptr(), r * l, l, cols, word.shape[0], float(eps),
-                                           _DT[dtype16], _stream())
+                                           y32.data_ptr(), _DT[stream_dtype], _ptr(y16), r * l, l, cols, word.shape[0], float(eps),
+                                           CIR_F16 if y16 is None else _DT[dtype16], _stream())
     _lib.check(code, "cir_embed_layernorm")
-    return y32, y16
+    return y32, (y32 if y16 is None else y16)
 
 
 def patchify(image: torch.Tensor, patch: int, dtype16: torch.dtype = torch.bfloat16) -> torch.Tensor:
-    """(B,C,H,W) fp32 or 16-bit -> (B*gh*gw, C*patch*patch) 16-bit, column order (c, ky, kx)."""
+    """(B,C,H,W) fp32 or 16-bit -> (B*gh*gw, C*patch*patch) 16-bit (fp32 with dtype16 = torch.float32), column order (c, ky, kx)."""
     _need_cuda(image)
     image = image.contiguous()
     b, c, h, w = image.shape
@@ -243,6 +250,8 @@ def vit_assemble(proj: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, batch
 def small_linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     """(M,K) 16-bit @ (N<=8, K)^T + bias -> (M,N) fp32."""
     _need_cuda(x, w, bias)
+    if x.dtype == torch.float32:       # "exact" mode: the fp32 dot-product kernel
+        return linear_f32(x, w, bias)
     m, k = x.shape
     n = w.shape[0]
     assert x.stride(1) == 1 and w.is_contiguous()

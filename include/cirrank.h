@@ -16,7 +16,10 @@
  *     work is enqueued on it and nowhere else;
  *   - leading dimensions / strides are in ELEMENTS of the tensor they describe;
  *   - dtype codes: CIR_BF16 / CIR_F16 for 16-bit activations and weights (fp32 accumulate
- *     everywhere), CIR_F32 for fp32 tensors; the RESIDUAL STREAM (every x + sublayer(x) and the
+ *     everywhere), CIR_F32 for fp32 tensors - and, since ABI v11, as the OPERAND type of cir_gemm_bias_act, cir_attention
+ *     and cir_patchify: the "exact" precision mode, every tensor fp32 like the reference's (validate_stage2.py:140-141:
+ *     model.float()), products on the f32-input MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32: IEEE fmaf chains, 157.3 TFLOP/s
+ *     peak = 1/16 of the 16-bit rate); the RESIDUAL STREAM (every x + sublayer(x) and the
  *     LayerNorm outputs that feed one) is either fp32 or fp16 ("stream dtype": CIR_F32 / CIR_F16),
  *     independently of the operand type - sums are formed in fp32 and rounded on the store (a GEMM with an fp16
  *     residual rounds its result to the stream type before the residual joins it: two roundings there);
@@ -33,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CIR_ABI_VERSION 10
+#define CIR_ABI_VERSION 11
 
 enum { CIR_BF16 = 0, CIR_F16 = 1, CIR_F32 = 2 };
 enum { CIR_ACT_NONE = 0, CIR_ACT_GELU = 1, CIR_ACT_RELU = 2 };
@@ -70,6 +73,9 @@ int cir_set_tuning(int knob, int value);
  *   bf16 operands).  res_dtype: CIR_F32 (with a C in the operand type or fp32) or CIR_F16 (only with an fp16 C; an fp16 C
  *   from bf16 operands takes ONLY an fp16 residual - CIR_EDTYPE otherwise).  C may alias residual.
  *   Requirements: K % 64 == 0, N % 16 == 0, 16-byte aligned rows.
+ *   in_dtype CIR_F32 (ABI v11, "exact" mode): A, W, residual and C all fp32 (out_dtype and res_dtype must be CIR_F32), K % 32 == 0,
+ *   one fmaf chain per output starting at the bias (K ascending within each group of 16, see csrc/gemm.hip), GELU evaluated as
+ *   written in the reference: 0.5 x (1 + erf(x / sqrt 2)) with erff.
  *   Rounding: one rounding of the fp32 result to the type of C - except an fp16 residual-stream C WITH a residual, which
  *   rounds A*W^T + bias to fp16 first, adds the residual in fp32 and rounds again.  Both tile sizes (128 x 128, persistent
  *   256 x 256; picked from M*N*batch) start their accumulators at the bias, walk K in the same order and share the epilogue
@@ -106,7 +112,8 @@ int cir_layernorm(const void* x, int x_dtype, int64_t strideX, const void* resid
  *   fp32 key mask (Lk) per item at mask + b1*m_s1 + b0*m_s0, or NULL.  kv_index (B1 int64, or NULL):
  *   item b1 reads its K/V from row kv_index[b1] of k / v instead of row b1 - the candidates of a
  *   query are then attended straight out of a per-image K/V bank (the cross-query reuse of
- *   SURVEY section 8(f)-1) with no gather copy.  16-bit in/out, fp32 softmax.  Replaces BertSelfAttention.forward (nlvr_encoder.py:140-222, med.py:158-240: the
+ *   SURVEY section 8(f)-1) with no gather copy.  16-bit in/out, fp32 softmax - or, dtype CIR_F32 (ABI v11), fp32 q / k / v / out
+ *   with fp32 operands in both products (csrc/attention_f32.hip).  Replaces BertSelfAttention.forward (nlvr_encoder.py:140-222, med.py:158-240: the
  *   transpose_for_scores / matmul / scale / mask / softmax / matmul / merge-heads sequence) and
  *   Attention.forward's core (vit.py:73-83).
  */
@@ -143,7 +150,7 @@ int cir_embed_layernorm(const int64_t* ids, const float* word, const float* pos,
 /*
  * timm PatchEmbed's im2col (vit.py:182; Conv2d k=p s=p == GEMM over flattened patches):
  *   patches[(b*gh+py)*gw+px][c*p*p + ky*p + kx] = image[b][c][py*p+ky][px*p+kx]
- *   image fp32 or 16-bit (img_dtype), patches 16-bit (dtype16).
+ *   image fp32 or 16-bit (img_dtype), patches 16-bit (dtype16) - or fp32 from an fp32 image (dtype16 = CIR_F32, ABI v11).
  */
 int cir_patchify(const void* image, int img_dtype, void* patches, int dtype16,
                  int B, int C, int H, int Wd, int patch, void* stream);

@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_symbol():
     cdll = lib.load()
     for name in _declared():
         assert hasattr(cdll, name), name
-    assert cdll.cir_version() == 10
+    assert cdll.cir_version() == 11
     assert b"aligned" in cdll.cir_strerror(-3)
 
 
@@ -92,7 +92,7 @@ def test_argument_validation_happens_before_any_launch():
     assert c.cir_attention(*bad) == EINVAL
     bad = list(att); bad[1] = 60
     assert c.cir_attention(*bad) == EALIGN
-    bad = list(att); bad[26] = F32
+    bad = list(att); bad[26] = 7                  # (CIR_F32 is a valid operand type since ABI v11: the exact mode)
     assert c.cir_attention(*bad) == EDTYPE
     assert c.cir_topk_desc(P, P, 1, 9000, None) == ESHAPE and c.cir_topk_desc(None, P, 1, 8, None) == EINVAL
     clsx = c.cir_cls_cross_attention
