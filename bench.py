@@ -141,6 +141,49 @@ def cpu_baseline(threads: int, per_query: int = 105):
                       % (reps, n_img, t_vit, n_q, t_s1, n_fq, k, t_fuse, per_query)}
 
 
+def rank_fidelity_block(scored, scored_x, active, k, ns, exact_ms, n_cand, recs_x):
+    """This run's logits against the EXACT mode's on the same step (same pixels, ids, weights): per scored query the fraction of
+    sorted top-K positions that hold the same candidate, Kendall's tau, the top-10 overlap and top-1 agreement; likewise for the
+    5-member subsets.  The exact mode is fp32 on the f32-input MFMA and is pinned to the reference's own outputs (logits 2e-6, sorted
+    order identical on 1599 of 1600 positions: tests/test_exact_gpu.py) - the on-device referee at sizes the CPU reference cannot reach."""
+    import numpy as np
+    from scipy.stats import kendalltau
+    a, b = scored.float().cpu().numpy(), scored_x.float().cpu().numpy()
+    rows, sub_rows, o = [], [], 0
+    for act in active:
+        if act:
+            rows.append((a[o:o + k], b[o:o + k])); o += k
+        if ns:
+            sub_rows.append((a[o:o + ns], b[o:o + ns])); o += ns
+
+    def stats(pairs, top):
+        ex, tau, ov, t1 = [], [], [], []
+        for x, y in pairs:
+            ox, oy = np.argsort(-x, kind="stable"), np.argsort(-y, kind="stable")
+            ex.append(float((ox == oy).mean())); tau.append(float(kendalltau(x, y).statistic))
+            ov.append(len(set(ox[:top]) & set(oy[:top])) / float(top)); t1.append(float(ox[0] == oy[0]))
+        return ex, tau, ov, t1
+    out = {"referee": "this step in set_precision('exact') - fp32 tensors, f32-input MFMA, pinned to the reference's own outputs by tests/test_exact_gpu.py",
+           "max_abs_dlogit": round(float(np.abs(a - b).max()), 6), "logit_sigma_per_query": None}
+    if rows:
+        ex, tau, ov, t1 = stats(rows, min(10, k))
+        out.update({"queries": len(rows), "positions": len(rows) * k, "exact_positions": round(float(np.mean(ex)), 4),
+                    "kendall_tau": round(float(np.mean(tau)), 5), "kendall_tau_worst_query": round(float(np.min(tau)), 5),
+                    "top10_overlap": round(float(np.mean(ov)), 4), "top1_agree": round(float(np.mean(t1)), 4),
+                    "logit_sigma_per_query": round(float(np.mean([y.std() for _, y in rows])), 5),
+                    "median_adjacent_gap": round(float(np.median(np.concatenate([np.diff(np.sort(y)) for _, y in rows]))), 7)})
+    if sub_rows:
+        ex, tau, ov, t1 = stats(sub_rows, min(3, ns))
+        out["subset"] = {"queries": len(sub_rows), "exact_positions": round(float(np.mean(ex)), 4), "kendall_tau": round(float(np.mean(tau)), 5),
+                         "top3_overlap": round(float(np.mean(ov)), 4), "top1_agree": round(float(np.mean(t1)), 4)}
+    gf = sum(r[0] for r in recs_x); gms = sum(r[1].elapsed_time(r[2]) for r in recs_x)
+    out["exact_mode"] = {"triplets_per_s": round(n_cand / (exact_ms * 1e-3), 1), "ms_per_step": round(exact_ms, 1),
+                         "gemm_kernel": "cir::gemm_kernel<float,1> (v_mfma_f32_16x16x4_f32)", "gemm_tflops": round(gf / (gms * 1e-3) / 1e12, 1),
+                         "gemm_frac_of_f32_mfma_peak": round(gf / (gms * 1e-3) / 1e12 / PEAK_TFLOPS["exact"], 4), "f32_mfma_peak_tflops": PEAK_TFLOPS["exact"],
+                         "gemm_share_of_step": round(gms / exact_ms, 3)}
+    return out
+
+
 def device_info():
     """What the box reports about the GPU (print the clocks rocminfo reports and state the peak used)."""
     import re
@@ -537,6 +580,7 @@ def main():
                          "sums are formed in fp32 either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-precision-table", action="store_true", help="skip the short re-runs at the other operand / stream precisions")
+    ap.add_argument("--no-rank-fidelity", action="store_true", help="skip the exact-mode (fp32) re-run of the step that referees the run's rank order")
     ap.add_argument("--loop-queries", type=int, default=512, help="loop mode: queries of the synthetic split (CIRR val: 4181)")
     ap.add_argument("--query-batch", type=int, default=16, help="loop mode: queries per stage-II batch")
     ap.add_argument("--index-batch", type=int, default=256, help="loop mode: images per extract_index_features batch")
@@ -549,7 +593,8 @@ def main():
     ap.add_argument("--index-size", type=int, default=2297, help="bank mode: number of index images (CIRR val: 2297)")
     args = ap.parse_args()
 
-    torch.set_num_threads(min(16, usable_cpus()))   # the box shows every host core but grants a cgroup quota: the default pool thrashes
+    # the box shows every host core but grants a cgroup quota: the default pool thrashes; N ranks of one node share that quota
+    torch.set_num_threads(min(16, max(1, usable_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: this process becomes the launcher.  It has not touched the GPU (no HIP
         # call precedes this line) and never does; it starts one CHILD per GPU and relays rank 0's line - nothing is exec'ed.
@@ -674,6 +719,8 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    if os.environ.get("CIR_BENCH_FAIL_RANK") == str(rank):              # test hook (tests/test_bench_gpu.py): this rank dies before the
+        sys.exit(3)                                                     # exchange - its peers block in the collective, the launcher must end them
     exchange()                                                          # warm the communicator too
     fence()
     with ClockSampler(dev_index) as clocks:
@@ -724,6 +771,26 @@ def main():
     attn_flop = sum(r[0] for r in arecs)
     attn_ms = sum(r[1].elapsed_time(r[2]) for r in arecs)
     t1 = time.perf_counter(); step(); torch.cuda.synchronize(); step_ms = (time.perf_counter() - t1) * 1e3
+
+    # ---- rank fidelity of THIS run against the exact (fp32) mode on the same step: thousands of sorted positions ---------
+    fidelity = None
+    if world == 1 and not args.no_rank_fidelity and args.dtype != "exact":
+        ref_scored = step().clone()
+        apply_precision(m2, "exact", "auto"); apply_precision(m1, "exact", "auto")
+        images_x = images.float()                                      # the same (16-bit-rounded) pixel values, as fp32 tensors
+        def xstep():
+            toks = m2.img_embed16(images_x)
+            z = m1.z_t(toks[:q_n], ids, mask)
+            return m2.score(z.last_hidden_state, ids, mask, toks[q_n:], qidx)
+        xstep(); torch.cuda.synchronize()
+        ops.PROFILE_GEMM = []
+        tx = time.perf_counter(); scored_x = xstep(); torch.cuda.synchronize(); exact_ms = (time.perf_counter() - tx) * 1e3
+        recs_x, ops.PROFILE_GEMM = ops.PROFILE_GEMM, None
+        fidelity = rank_fidelity_block(ref_scored, scored_x, active, k, ns, exact_ms, n_cand, recs_x)
+        del images_x, scored_x
+        apply_precision(m2, args.dtype, args.stream_dtype); apply_precision(m1, args.dtype, args.stream_dtype)
+        m2.engines(); m1.engines()
+        torch.cuda.empty_cache()
 
     # ---- the speed / precision trade in the same record: 3 timed steps at each other (operand, stream) precision ---------
     precision = None
@@ -807,6 +874,8 @@ def main():
         }
         if collective is not None:
             line["collective"] = collective
+        if fidelity is not None:
+            line["rank_fidelity"] = fidelity
         if precision is not None:
             line["precision_table"] = precision
         if world == 1 and not args.no_cpu_baseline:

@@ -718,10 +718,14 @@ class AdamW:
     When the parameters and their gradients are the trainer's flat buffers (the normal case after `fusion_train`), one launch
     updates all of them; otherwise one launch per tensor."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, model=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, model=None, check_finite=None):
         """`model`: the BLIP_NLVR whose parameters these are - its packed inference engine is marked stale by every step()
-        (without it the training forward marks it, which misses an eval call made between backward() and step())."""
+        (without it the training forward marks it, which misses an eval call made between backward() and step()).
+        `check_finite`: test the gradients step() is about to apply for inf / NaN and skip the update then (GradScaler.step's found_inf,
+        stage2_train.py:215-218; one reduction over the flat gradient buffer + one host read).  None = automatic: always, unless `model`
+        is given and its trainers run bf16 operands (whose pass cannot overflow: no loss scale)."""
         self.model = model
+        self.check_finite = check_finite
         self.params = [p for p in params if p.requires_grad]
         self.betas, self.eps, self.wd, self.t = betas, eps, weight_decay, 0
         # torch.optim's surface as far as the reference's loop uses it: utils.cosine_lr_schedule (utils.py:216-221, called once per epoch at
@@ -755,12 +759,22 @@ class AdamW:
         ps = [p for p in self.params if p.grad is not None]
         if not ps:
             return
+        # Non-finite gradients (an fp16 intermediate above 65504 -> inf -> NaN in the weight gradients): skip this update like
+        # GradScaler.step would.  The test runs on the buffers this call APPLIES - .grad as it is now, i.e. after any accumulation over
+        # micro-batches (an overflowed earlier micro-batch followed by a finite one stays non-finite in the sum) - and does not depend on
+        # `model=` (round-4 advisor findings: the per-backward flag of the trainer saw only the last micro-batch and only with model=).
+        need = self.check_finite
+        trainers = [] if self.model is None else [tr for tr in (getattr(self.model, "_trainer", None), getattr(self.model, "_vit_trainer", None)) if tr is not None]
+        if need is None:
+            need = self.model is None or not trainers or any(getattr(tr, "dtype", None) == torch.float16 for tr in trainers)
+        bad = any(getattr(tr, "grads_finite", None) is not None and not bool(tr.grads_finite) for tr in trainers)   # (a flag a test / caller set)
+        if need and not bad:
+            bad = not self._grads_finite(ps)
+        if bad:
+            self.t -= 1
+            self.skipped_steps = getattr(self, "skipped_steps", 0) + 1
+            return
         if self.model is not None:
-            for tr in (getattr(self.model, "_trainer", None), getattr(self.model, "_vit_trainer", None)):
-                if tr is not None and getattr(tr, "grads_finite", None) is not None and not bool(tr.grads_finite):
-                    self.t -= 1                               # non-finite fp16 gradients: skip this update like GradScaler.step would
-                    self.skipped_steps = getattr(self, "skipped_steps", 0) + 1
-                    return
             self.model._text_stale = True                     # the weights change HERE: the next eval / score call repacks
             if getattr(self.model, "_vit_trainer", None) is not None:
                 self.model._vit_stale = True
@@ -772,6 +786,21 @@ class AdamW:
             if len(grp) < 2 or not self._step_flat(grp):
                 for p in grp:
                     self._step_tensor(p)
+
+    def _grads_finite(self, ps) -> bool:
+        """All gradients about to be applied are finite: one reduction per flat gradient storage (per tensor otherwise), ONE host read."""
+        groups: Dict[int, list] = {}
+        for p in ps:
+            groups.setdefault(p.grad.untyped_storage().data_ptr(), []).append(p)
+        flags = []
+        for grp in groups.values():
+            fr = self._flat_range([p.grad for p in grp]) if len(grp) > 1 else None
+            if fr is not None:
+                flat = torch.empty(0, dtype=torch.float32, device=grp[0].grad.device).set_(grp[0].grad.untyped_storage(), 0, (fr[1],))
+                flags.append(torch.isfinite(flat).all())
+            else:
+                flags += [torch.isfinite(p.grad).all() for p in grp]
+        return bool(torch.stack(flags).all())
 
     def _step_flat(self, ps) -> bool:
         fp, fg = self._flat_range([p.data for p in ps]), self._flat_range([p.grad for p in ps])

@@ -20,6 +20,7 @@ from typing import Dict, List
 
 import torch
 
+from . import lib as _lib
 from . import ops, train_ops as T
 from .train import _Lin, _LN, _Slab, _cast, _install_grads
 
@@ -97,7 +98,10 @@ class VitTrainer:
         x = ops.vit_assemble(self.pe.fwd(patches, f32), self.cls, self.pos, bsz).view(bsz * n, d)      # vit.py:184-187, fp32 stream
         self.step_no += 1
         dp, dp_rates = self._drop_path_scales(bsz, x.device)
-        self.sv = sv = {"patches": patches, "bsz": bsz, "blocks": [], "dp": dp, "dp_rates": dp_rates}
+        # What the reverse pass needs travels WITH THE CALL (the autograd node keeps it), not on the trainer: the reference embeds the
+        # reference and the target images in `blip_bs` mini-batches, every call with a graph (stage2_train.py:191-199) - several calls
+        # are live at once, and each backward must find its own activations and its own DropPath draw (round-4 advisor finding).
+        sv = {"patches": patches, "bsz": bsz, "blocks": [], "dp": dp, "dp_rates": dp_rates, "epoch": _lib.PARAM_EPOCH[0]}
         heads = lambda t, j: self._heads(t, bsz, n, j)
 
         def branch(lin, a16, res, i, j):
@@ -121,14 +125,26 @@ class VitTrainer:
             x = x2
         sv["xf"] = x
         y32, _ = self.lnf.fwd(x, dt)                                                 # vit.py:192
-        return y32.view(bsz, n, d)
+        self.sv = sv                                                                 # (the latest call's state: tests / tools read it)
+        return y32.view(bsz, n, d), sv
 
     # ------------------------------------------------------------------------------------------------ backward
     @torch.no_grad()
-    def backward(self, dfeats: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """dfeats (B, N, D) fp32 -> {parameter name: fp32 gradient} for every visual_encoder.* parameter."""
-        sv, geo, dt = self.sv, self.geo, self.dtype
-        bsz, d, n = sv["bsz"], geo.width, geo.num_tokens
+    def backward(self, dfeats: torch.Tensor, sv: Dict = None) -> Dict[str, torch.Tensor]:
+        """dfeats (B, N, D) fp32 -> {parameter name: fp32 gradient} for every visual_encoder.* parameter, from the saved state `sv` of
+        the forward call being differentiated (default: the latest call's).  Every backward writes a FRESH flat gradient buffer
+        (`train._install_grads` folds it into .grad with one flat add), so the mini-batches of one step - and their loss scales - do
+        not meet inside a buffer."""
+        sv = self.sv if sv is None else sv
+        geo, dt = self.geo, self.dtype
+        if sv["epoch"] != _lib.PARAM_EPOCH[0]:
+            raise RuntimeError("img_embed (train mode): the parameters were updated (optimizer step) between this forward and its backward - "
+                               "the reverse pass would run on other weights than the forward did")
+        slab = self.slab
+        slab.gflat = torch.zeros_like(slab.flat32)
+        d = geo.width
+        self.dcls, self.dpos = slab.grad(_P + "cls_token").view(d), slab.grad(_P + "pos_embed").view(-1, d)
+        bsz, n = sv["bsz"], geo.num_tokens
         dev = dfeats.device
         g = dfeats.contiguous().float().view(bsz * n, d)
         # fp16 operands: run the (linear) pass on S * dfeats, S a power of two putting the largest entry near 512 (train.NlvrTrainer.backward)
@@ -178,7 +194,6 @@ class VitTrainer:
         T.colsum(g3[:, 0], self.dcls)
         dproj16 = _cast(g3[:, 1:].contiguous().view(bsz * (n - 1), d), dt)
         self.pe.bwd16(sv["patches"], dproj16, need_dx=False, bias=True)             # pixels are inputs
-        slab = self.slab
         if self.grad_scale != 1.0:
             slab.gflat = T.eltwise(slab.gflat, T.MODE_SCALE, p_drop=1.0 / self.grad_scale)
         self.grads_finite = torch.isfinite(slab.gflat).all() if dt == torch.float16 else None
@@ -186,27 +201,24 @@ class VitTrainer:
 
 
 class _VitTrainFn(torch.autograd.Function):
-    """One autograd node around VitTrainer.forward / backward (see train._FusionTrainFn: same single-slot rules)."""
+    """One autograd node around VitTrainer.forward / backward.  The node owns the saved state of ITS call, so any number of calls
+    may be live between forward and backward - the reference's loop embeds reference and target images in `blip_bs` mini-batches,
+    each with a graph (stage2_train.py:191-199); calls whose output never receives a gradient (the reference images: z_t is formed
+    under no_grad) simply drop their state with their output.  A second backward through one call raises (its state is released)."""
 
     @staticmethod
     def forward(ctx, anchor, trainer, image):
         ctx.trainer = trainer
-        out = trainer.forward(image)
-        trainer.generation = ctx.generation = getattr(trainer, "generation", 0) + 1
-        trainer.consumed = False
+        out, ctx.sv = trainer.forward(image)
         return out
 
     @staticmethod
     def backward(ctx, dfeats):
-        tr = ctx.trainer
-        if tr.generation != ctx.generation:
-            raise RuntimeError("img_embed (train mode, ViT fine-tuning): another training-mode img_embed ran before this one's backward - the saved "
-                               "activations belong to the later call.  Embed all images that need a gradient in ONE call (torch.cat the "
-                               "mini-batches), and the others under torch.no_grad()")
-        if tr.consumed:
+        tr, sv = ctx.trainer, ctx.sv
+        if sv is None:
             raise RuntimeError("img_embed (train mode): second backward through the same forward; run the forward again")
-        tr.consumed = True
-        _install_grads(tr, tr.backward(dfeats))
+        ctx.sv = None
+        _install_grads(tr, tr.backward(dfeats, sv))
         return None, None, None
 
 

@@ -27,6 +27,8 @@ and `.weights`, so fixtures hold only seeds, small input checksums and the refer
                   reference's recall tuples for those labels (`make_golden.py rank`, ~4 minutes).
   outlier224.npz  the benchmark geometry with OUTLIER-channel weights (residual stream 1e2..1e3 in three channels) through the
                   reference's generate_cirr_val_predictions at K=100 (+5): what pins the fp16 residual stream (`make_golden.py outlier`).
+  rank224_wide.npz / outlier224_wide.npz  the two rank fixtures regrown to >= 16 scored queries per case (`make_golden.py wide rank`,
+                  `make_golden.py wide outlier`; round 5).
   vitl_tiny.npz   the reference's ViT-large encoder (depth 24, width 1024, 16 heads) at 64 px (`make_golden.py vitl`).
   bxb224.npz      training-mode surface `BLIP_NLVR.img_txt_fusion` (blip_stage2.py:65-99) in eval mode: B=4 ragged
                   captions (padding='longest' -> real masks) -> (B,B) logits (`make_golden.py rank`).
@@ -482,6 +484,122 @@ def outlier_goldens(R, ref_val, full_bert):
           f"range [{lg[:2].min():.3f}, {lg[:2].max():.3f}], sorted gaps median {np.median(np.diff(np.sort(lg[0]))):.2e}")
 
 
+def wide_goldens(R, ref_val, full_bert, which):
+    """tests/golden/rank224_wide.npz / outlier224_wide.npz (round 5): the rank fixtures regrown to >= 16 SCORED queries per case, so
+    that one candidate is 0.006 of a top-10 statistic instead of 0.05 (rank224 has 4 / 2 / 3 scored queries, outlier224 has 2) and the
+    exact-position / tau / top-10 floors of the 16-bit modes - and the exact mode's identity with the reference - are measured on
+    1600 / 3200 / 800 sorted positions.  Same models, banks and construction as rank_goldens / outlier_goldens (their files are left
+    untouched: dozens of asserted numbers hang on them); the reference's own generate_*_val_predictions / compute_*_val_metrics
+    on the final datasets are the fixture.  `make_golden.py wide rank` ~8 minutes, `make_golden.py wide outlier` ~2 minutes of CPU."""
+    margin = 4 * RANK_TOL
+    saved = (ref_val.generate_fiq_val_predictions, ref_val.generate_cirr_val_predictions)
+    if which == "rank":
+        m2, m1, g, v = build_reference_models(R, full_bert, dict(image_size=224, width=768, depth=12, num_heads=12), seed=21, profile="test")
+        n_index = 256
+        names = ["img%04d" % i for i in range(n_index)]
+        with torch.no_grad():
+            bank = torch.cat([m2.img_embed(synthetic.scene_images(range(i, i + 32), 224)) for i in range(0, n_index, 32)])
+        rng = np.random.RandomState(131)
+        out = dict(seed=21, profile="test", n_index=n_index, tol_unit=RANK_TOL, bank_sum=bank.double().sum().item())
+        cases = (("c100", 17, 100, (0, 1, 2, 3, 4, 6, 8, 9, None, 12, 20, 28, 40, 49, 55, 70, 90)),
+                 ("c200", 16, 200, (0, 2, 4, 6, 9, 11, 20, 30, 45, 49, 51, 70, 100, 120, 150, 190)))
+        for tag, n_q, k, want in cases:
+            refs = rng.randint(0, n_index, n_q)
+            cand = np.stack([rng.permutation(n_index)[:k] for _ in range(n_q)])
+            groups = np.stack([np.array([j for j in rng.permutation(n_index) if j != refs[q] and j not in cand[q]][:5]) for q in range(n_q)])
+            caps = [synthetic.caption_text(2700 + 13 * k + q, 30) for q in range(n_q)]
+            ds = FakeCIRR(names, refs, cand[:, 0], caps, cand, np.ones((n_q, k), dtype=bool), groups)
+            logits, glogits, *_ = ref_val.generate_cirr_val_predictions(m2, m1, ds, names, bank)
+            logits, glogits = logits.numpy(), glogits.numpy()
+            labels = np.zeros((n_q, k), dtype=bool)
+            targets = np.zeros(n_q, dtype=np.int64)
+            for q in range(n_q):
+                slot = q % 5
+                if want[q] is None:                                     # skipped row: target outside the top-K
+                    targets[q] = groups[q][_pick_robust(glogits[q], 1, margin, (1, 2, 3))]
+                    continue
+                ci = _pick_robust(logits[q], want[q], margin, (1, 5, 10, 50),
+                                  also=lambda i: _robust(glogits[q], logits[q][i], slot, margin, (1, 2, 3)))
+                labels[q, ci] = True
+                targets[q] = cand[q, ci]
+                groups[q, slot] = cand[q, ci]
+            ds = FakeCIRR(names, refs, targets, caps, cand, labels, groups)
+            logits2, glogits2, _, tnames, gnames = ref_val.generate_cirr_val_predictions(m2, m1, ds, names, bank)
+            l2, g2 = logits2.numpy(), glogits2.numpy()
+            for q in range(n_q):
+                gi = int(np.where(groups[q] == targets[q])[0][0])
+                assert _robust(g2[q], g2[q][gi], gi, margin, (1, 2, 3))
+                if labels[q].any():
+                    ci = int(labels[q].argmax())
+                    assert _robust(l2[q], l2[q][ci], ci, margin, (1, 5, 10, 50)) and abs(l2[q][ci] - g2[q][gi]) < 1e-5
+                    assert np.array_equal(l2[q], logits[q])             # a query's logits do not depend on the labels of the dataset
+                else:
+                    assert np.all(l2[q] == np.float32(-99999.99))
+            ref_val.generate_cirr_val_predictions = lambda *a, **kw: (logits2, glogits2, None, tnames, gnames)
+            try:
+                metrics = ref_val.compute_cirr_val_metrics(ds, None, None, None, None)
+            finally:
+                ref_val.generate_cirr_val_predictions = saved[1]
+            out.update({f"{tag}_refs": refs, f"{tag}_cand": cand, f"{tag}_groups": groups, f"{tag}_caps": np.array(caps),
+                        f"{tag}_labels": labels, f"{tag}_targets": targets,
+                        f"{tag}_logits": l2, f"{tag}_group_logits": g2, f"{tag}_metrics": np.array(metrics)})
+            gaps = np.concatenate([np.diff(np.sort(l2[q])) for q in range(n_q) if labels[q].any()])
+            print(f"rank224_wide {tag}: {int(labels.any(1).sum())} scored queries, metrics {np.round(metrics, 2)}, logit std {l2[labels.any(1)].std():.4f}, "
+                  f"adjacent gaps: min {gaps.min():.2e} median {np.median(gaps):.2e}, below 1e-5: {int((gaps < 1e-5).sum())} of {len(gaps)}")
+        n_q, k = 16, 50
+        refs = rng.randint(0, n_index, n_q)
+        cand = np.stack([rng.permutation(n_index)[:k] for _ in range(n_q)])
+        fcaps = [(synthetic.caption_text(2900 + q, 14) + ".", "  " + synthetic.caption_text(2950 + q, 15) + "?") for q in range(n_q)]
+        ds = FakeFIQ(names, refs, cand[:, 0], fcaps, cand, np.ones((n_q, k), dtype=bool))
+        logits, _ = ref_val.generate_fiq_val_predictions(m2, m1, ds, names, bank)
+        labels = np.zeros((n_q, k), dtype=bool)
+        for q, want in enumerate((0, 1, 2, 4, 6, 8, 9, 11, 15, 20, 25, 30, 35, 40, 45, 48)):
+            labels[q, _pick_robust(logits.numpy()[q], want, margin, (10, 50))] = True
+        ds = FakeFIQ(names, refs, cand[np.arange(n_q), labels.argmax(1)], fcaps, cand, labels)
+        ref_val.generate_fiq_val_predictions = lambda *a, **kw: (logits, None)
+        try:
+            fmetrics = ref_val.compute_fiq_val_metrics(ds, None, None, None, None)
+        finally:
+            ref_val.generate_fiq_val_predictions = saved[0]
+        out.update(f50_refs=refs, f50_cand=cand, f50_caps=np.array(fcaps), f50_labels=labels, f50_logits=logits.numpy(), f50_metrics=np.array(fmetrics))
+        print(f"rank224_wide f50: metrics {np.round(fmetrics, 2)}  logit std {logits.numpy().std():.4f}")
+        np.savez_compressed(os.path.join(OUT, "rank224_wide.npz"), **out)
+        return
+    # ---- outlier-channel weights: 17 queries at K = 100 (+5), one of them skipped ------------------------------------------------
+    m2, m1, g, v = build_reference_models(R, full_bert, dict(image_size=224, width=768, depth=12, num_heads=12), seed=33, profile="outlier")
+    n_index, n_q, k = 128, 17, 100
+    names = ["img%04d" % i for i in range(n_index)]
+    with torch.no_grad():
+        bank = torch.cat([m2.img_embed(synthetic.scene_images(range(i, i + 32), 224)) for i in range(0, n_index, 32)])
+    rng = np.random.RandomState(141)
+    refs = rng.randint(0, n_index, n_q)
+    cand = np.stack([rng.permutation(n_index)[:k] for _ in range(n_q)])
+    groups = np.stack([np.array([j for j in rng.permutation(n_index) if j != refs[q] and j not in cand[q]][:5]) for q in range(n_q)])
+    caps = [synthetic.caption_text(3700 + q, 30) for q in range(n_q)]
+    labels = np.zeros((n_q, k), dtype=bool)
+    targets = np.zeros(n_q, dtype=np.int64)
+    skip_q = 11
+    for q in range(n_q):
+        if q == skip_q:                                                # no positive in its top-K -> skipped row; target is a subset member only
+            targets[q] = groups[q, 1]
+            continue
+        ci = (7 * q + 3) % k
+        labels[q, ci] = True
+        targets[q] = cand[q, ci]
+        groups[q, q % 5] = cand[q, ci]
+    ds = FakeCIRR(names, refs, targets, caps, cand, labels, groups)
+    logits, glogits, *_ = ref_val.generate_cirr_val_predictions(m2, m1, ds, names, bank)
+    lg, gl = logits.numpy(), glogits.numpy()
+    active = labels.any(1)
+    assert np.all(lg[skip_q] == np.float32(-99999.99)) and np.isfinite(lg[active]).all()
+    gaps = np.concatenate([np.diff(np.sort(lg[q])) for q in range(n_q) if active[q]])
+    np.savez_compressed(os.path.join(OUT, "outlier224_wide.npz"), seed=33, profile="outlier", n_index=n_index, refs=refs, cand=cand,
+                        groups=groups, caps=np.array(caps), labels=labels, targets=targets, logits=lg, group_logits=gl,
+                        bank_sum=bank.double().sum().item())
+    print(f"outlier224_wide: {int(active.sum())} scored queries, logits std {lg[active].std():.4f}, adjacent gaps: min {gaps.min():.2e} "
+          f"median {np.median(gaps):.2e}, below 2e-5: {int((gaps < 2e-5).sum())} of {len(gaps)}")
+
+
 def vitl_goldens(R):
     """tests/golden/vitl_tiny.npz: the reference's ViT-LARGE encoder (blip.py:203-209: depth 24, width 1024, 16 heads) at
     64 px (17 tokens) on four seeded images - token slices, sums and the per-block CLS taps of the reference's own
@@ -684,6 +802,14 @@ def main():
         _install_torchvision_stub()
         _, ref_val = _import_reference_scripts()
         return tiny_goldens(R, ref_val)
+    if len(sys.argv) > 2 and sys.argv[1] == "wide":     # only the >= 16-query rank fixtures (round 5): wide rank | wide outlier
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        R = ref_shim.load_reference_modules()
+        _install_torchvision_stub()
+        _, ref_val = _import_reference_scripts()
+        full_bert = json.load(open(os.path.join(ref_shim.REFERENCE_ROOT, "configs", "med_config.json")))
+        return wide_goldens(R, ref_val, full_bert, sys.argv[2])
     if len(sys.argv) > 1 and sys.argv[1] == "rank":     # only the rank-order / B x B fixtures
         torch.manual_seed(0)
         torch.set_num_threads(8)

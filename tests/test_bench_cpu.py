@@ -68,4 +68,10 @@ def test_precision_flags_map_to_model_settings():
         b.apply_precision(m, dtype, stream)
         assert (m.precision, m.compute_dtype, m.image_dtype, b.stream_name(m)) == (prec, cdt, idt, sname)
         assert m.token_dtype == (idt or cdt)
-    assert set(b.PRECISION_NOTE) == {"f16", "bf16", "mixed"} == set(b.PEAK_TFLOPS)
+    # the exact mode (round 5): fp32 everywhere, whatever --stream-dtype says; leaving it restores the automatic streams
+    b.apply_precision(m, "exact", "f16")
+    assert (m.precision, m.compute_dtype, m.image_dtype, m.stream_dtype, m.vit_stream_dtype, m.token_dtype) == \
+        ("exact", torch.float32, None, torch.float32, torch.float32, torch.float32) and b.stream_name(m) == "f32"
+    b.apply_precision(m, "f16", "auto")
+    assert (m.precision, m.stream_dtype, m.vit_stream_dtype) == ("f16", torch.float16, torch.float16)
+    assert set(b.PRECISION_NOTE) == {"f16", "bf16", "mixed", "exact"} == set(b.PEAK_TFLOPS) and b.PEAK_TFLOPS["exact"] == 157.3

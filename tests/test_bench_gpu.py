@@ -36,6 +36,12 @@ def test_single_rank_contract_line():
     assert rf["kernel"].startswith("cir::gemm") and "traffic" in rf and rf["all_gemm_kernels"]["launches_per_step"] > 100
     assert d["config"]["subset"] == 5 and d["config"]["triplets_per_step_rank0"] == 2 * 105
     assert d["executed_gflop_per_triplet"] > 0 and d["device"]["compute_units"] == 256
+    # round 5: the step re-run in the exact (fp32) mode referees this run's rank order
+    fid = d["rank_fidelity"]
+    assert fid["queries"] == 2 and fid["positions"] == 200 and 0.0 < fid["exact_positions"] <= 1.0 and fid["kendall_tau"] > 0.9
+    assert fid["max_abs_dlogit"] < 0.02 and fid["subset"]["queries"] == 2
+    ex = fid["exact_mode"]
+    assert ex["triplets_per_s"] > 100 and 0.3 < ex["gemm_frac_of_f32_mfma_peak"] < 1.0 and ex["f32_mfma_peak_tflops"] == 157.3
 
 
 @pytest.mark.parametrize("launcher", ["self", "torchrun"])
@@ -64,6 +70,34 @@ def test_two_rank_dry_run_on_one_gpu(launcher):
     assert r.stdout.count('{"metric"') == 1          # rank 0 alone prints the line
     c = d["collective"]
     assert c["ranks"] == 2 and c["own_block_bit_identical"] and c["checksum_equal_on_all_ranks"] and len(c["per_rank_triplets_per_step"]) == 2
+
+
+def test_eight_rank_dry_run_and_a_dying_rank():
+    """SURVEY 8(e) at the rank count BASELINE configs[3] / [4] name, as far as ONE GPU allows: `python bench.py --gpus 8` starts its own
+    eight ranks (all pinned to device 0, gloo instead of RCCL - which refuses two ranks per device), every rank scores its block of
+    the 16 queries, ONE all-gather of scores + indices closes the timed region; then the same launch with a rank that dies before the
+    exchange: its peers block in the collective and the launcher must end them and return non-zero (bench.launch_ranks: 20-s window)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import time
+    env = dict(os.environ, CIR_BENCH_BACKEND="gloo", CIR_BENCH_DEVICE="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--queries", "2", "--skip-rate", "0.2",
+           "--no-precision-table"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    c = d["collective"]
+    assert d["n_gpus"] == 8 and c["ranks"] == 8 and len(c["per_rank_triplets_per_step"]) == 8 and r.stdout.count('{"metric"') == 1
+    assert c["own_block_bit_identical"] and c["checksum_equal_on_all_ranks"]
+    assert sum(c["per_rank_triplets_per_step"]) > 0 and max(c["per_rank_triplets_per_step"]) - min(c["per_rank_triplets_per_step"]) <= 100   # balanced_order: blocks differ by <= 1 scored query
+    assert "rank_fidelity" not in d and "cpu_baseline" not in d                 # single-rank blocks only
+    t0 = time.time()
+    cmd2 = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "1", "--queries", "2", "--no-precision-table"]
+    r = subprocess.run(cmd2, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(env, CIR_BENCH_FAIL_RANK="1"))
+    assert r.returncode != 0 and '{"metric"' not in r.stdout and "a rank exited with code 3" in r.stderr, (r.returncode, r.stderr[-1500:])
+    print(f"\n[dying rank] launcher returned {r.returncode} after {time.time() - t0:.0f} s")
 
 
 def test_bank_mode_line():

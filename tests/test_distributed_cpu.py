@@ -61,6 +61,61 @@ def test_two_rank_gather_equals_single_process(n_q, use_balance):
         np.testing.assert_array_equal(idx, expect_idx)
 
 
+def _fast_scores(rows, k, active, gain=1.0):
+    """Vectorised stand-in scorer (depends only on (query, candidate)); skipped queries give the fill row."""
+    q = torch.as_tensor(list(rows), dtype=torch.float32)[:, None]
+    out = torch.sin(torch.arange(k, dtype=torch.float32)[None, :] * 0.37 + q) * gain
+    act = torch.as_tensor([bool(active[r]) for r in rows])
+    out[~act] = D.SKIP_FILL
+    return out
+
+
+# BASELINE configs[2] / [3] / [4] shapes and the degenerate "fewer queries than ranks" case: (queries, widths)
+EIGHT_RANK_CASES = [(4181, (100, 5)), (6016, (100,)), (512, (200, 5)), (5, (100, 5))]
+
+
+def _worker8(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        got = []
+        for n_q, widths in EIGHT_RANK_CASES:
+            active = (np.random.RandomState(n_q).rand(n_q) > 0.17).tolist()
+            order = D.balanced_order(active)
+            lo, hi, per = D.shard_bounds(n_q, rank, world)
+            mine = sum(active[q] for q in order[lo:hi])
+            if len(widths) == 1:
+                full, idx = D.sharded_scores(lambda rows: _fast_scores(rows, widths[0], active), n_q, widths[0], torch.device("cpu"), order, with_indices=True)
+                parts = (full,)
+            else:
+                parts, idx = D.sharded_scores(lambda rows: (_fast_scores(rows, widths[0], active), _fast_scores(rows, widths[1], active, 2.0)),
+                                              n_q, widths, torch.device("cpu"), order, with_indices=True)
+            # every rank checks the whole matrix itself (returning 8 x 6016 x 105 floats through a manager would dominate the test)
+            ok = True
+            for p, (w, gain) in zip(parts, zip(widths, (1.0, 2.0))):
+                ok &= bool(torch.equal(p, _fast_scores(range(n_q), w, active, gain)))
+            ok &= bool(torch.equal(idx, torch.argsort(parts[0], dim=-1, descending=True, stable=True)))
+            got.append((ok, mine, hi - lo, per))
+        ret[rank] = got
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_gather_on_the_benchmark_configs():
+    """SURVEY 8(e) at the rank count it names: EIGHT gloo processes, the query counts of BASELINE configs[2] (CIRR val, 4181 x (100 + 5)),
+    configs[3] (FashionIQ, 6016 x 100), configs[4] (512 x (200 + 5)) and 5 queries on 8 ranks (three ranks own nothing), balanced
+    order + indices: every rank ends with the single-process matrices bit for bit, blocks differ by at most 2 scored queries."""
+    world = 8
+    ret = mp.Manager().dict()
+    mp.spawn(_worker8, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for ci, (n_q, widths) in enumerate(EIGHT_RANK_CASES):
+        loads = [ret[r][ci][1] for r in range(world)]
+        assert all(ret[r][ci][0] for r in range(world)), (n_q, widths)
+        assert sum(ret[r][ci][2] for r in range(world)) == n_q and max(loads) - min(loads) <= 2, (n_q, loads)
+        assert len({ret[r][ci][3] for r in range(world)}) == 1            # one padded block length: equal-sized contributions
+
+
 def test_empty_and_tiny_query_sets_single_process():
     """No queries at all (an empty split) and fewer queries than ranks are valid inputs."""
     import torch

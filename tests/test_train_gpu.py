@@ -430,6 +430,40 @@ def test_gradient_accumulation_keeps_the_flat_path(cuda):
     assert len(opt._flats) == 1                                                 # ... and the optimizer took the flat path
 
 
+def test_overflowed_micro_batch_is_not_forgotten_by_accumulation(cuda):
+    """Round-4 advisor finding: with gradient accumulation an overflowed FIRST micro-batch followed by a finite second one left the
+    trainer's per-backward flag True and AdamW.step wrote NaN into every parameter - and an optimizer built WITHOUT `model=` (bench.py,
+    most tests) never looked at the flag at all.  step() now tests the accumulated buffer it applies (GradScaler.unscale_ checks .grad)."""
+    from candidate_reranking_cir_amd.train import AdamW
+    zf, g, v, _, _ = H.tiny_setup()
+    m = build(g, v, int(zf["seed"]), str(zf["profile"]), HF)[0]
+    freeze_vit(m)
+    m.train()
+    caps = [synthetic.caption_text(90 + i, n) for i, n in enumerate((4, 8, 6))]
+    rng = torch.Generator().manual_seed(9)
+    l = H.tokenize(caps)[0].shape[1]
+    z_t = torch.randn((3, l, g.hidden_size), generator=rng).cuda()
+    feats = torch.randn((3, 17, g.encoder_width), generator=rng).cuda()
+    gt = torch.arange(3, device=cuda)
+    ps = [p for p in m.parameters() if p.requires_grad]
+    for with_model in (False, True):
+        opt = AdamW(ps, lr=1e-2, weight_decay=0.0, model=m if with_model else None)
+        opt.zero_grad()
+        (F.cross_entropy(m.img_txt_fusion(z_t, feats, caps), gt) / 2).backward()
+        live = [p for p in ps if p.grad is not None]
+        live[5].grad.view(-1)[3] = float("inf")                                  # what an overflowed intermediate leaves in the first micro-batch
+        (F.cross_entropy(m.img_txt_fusion(z_t.flip(0), feats, caps), gt) / 2).backward()
+        assert bool(m._trainer.grads_finite)                                     # the second pass alone was finite ...
+        assert not torch.isfinite(live[5].grad).all()                            # ... the accumulated gradient is not
+        w0 = [p.detach().clone() for p in live[:8]]
+        opt.step()
+        assert opt.skipped_steps == 1 and opt.t == 0 and all(torch.equal(p.detach(), w) for p, w in zip(live[:8], w0)), with_model
+        opt.zero_grad()
+        F.cross_entropy(m.img_txt_fusion(z_t, feats, caps), gt).backward()
+        opt.step()
+        assert opt.t == 1 and all(torch.isfinite(p).all() for p in live) and not torch.equal(live[0].detach(), w0[0])
+
+
 @pytest.mark.parametrize("dtype", [BF, HF], ids=["bf16", "fp16"])
 def test_training_step_with_dropout_against_oracle_with_the_same_masks(cuda, dtype):
     """Dropout ON (hidden 0.1, attention probabilities 0.1) end to end: the masks of every site - embeddings, both self-attention outputs,

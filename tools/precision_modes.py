@@ -1,4 +1,7 @@
-"""Rank fidelity and throughput of every operand / residual-stream precision mode on one MI355X (round 4).
+"""Rank fidelity and throughput of every operand / residual-stream precision mode on one MI355X (rounds 4-5).
+Round 5 adds the EXACT mode (fp32 on the f32-input MFMA) and the fixtures regrown to >= 16 scored queries
+(tests/golden/rank224_wide.npz c100 / c200 / f50, outlier224_wide.npz):  python tools/precision_modes.py --wide > profiles/r5_precision_modes.json
+
 
 For each mode: (i) the two rank fixtures that hold the REFERENCE's own outputs - tests/golden/outlier224.npz (outlier-channel
 weights, K = 100 + 5) and tests/golden/rank224.npz c100 (separated logits, K = 100 + 5) - scored through
@@ -34,6 +37,7 @@ MODES = {
     "f16 | streams f16": (HF, None, HF, "same"),
     "f16 | ViT stream f16, text f32": (HF, None, F32, HF),
     "f16 | streams f32": (HF, None, F32, "same"),
+    "exact (fp32 everywhere, f32-input MFMA)": (F32, None, F32, "same"),
 }
 
 
@@ -44,6 +48,10 @@ def order_stats(ours, ref):
 
 def apply(m, mode):
     dt, idt, sdt, vsdt = MODES[mode]
+    if dt == F32:
+        return m.set_precision("exact")
+    if m.compute_dtype == F32:
+        m.set_precision("f16")
     m.set_compute_dtype(dt, idt)
     m.set_stream_dtype(sdt, vit=vsdt)
     return m
@@ -58,26 +66,43 @@ def build(g, v, seed, profile, mode, dev):
 
 
 def fixture_stats(name, mode, dev):
+    """`name`: outlier224 | rank224_c100 (the round-4 fixtures: 2 / 4 scored queries) | outlier224_wide | rank224_wide_c100 | _c200 | _f50
+    (round 5: 16 scored queries each)."""
     g, v = H.geometry(H.FULL_BERT, dict(image_size=224))
-    if name == "outlier224":
-        z = H.load("outlier224.npz")
-        refs, cand, labels, caps, groups, targets, ref, gref = (z["refs"], z["cand"], z["labels"], z["caps"], z["groups"], z["targets"],
-                                                                z["logits"], z["group_logits"])
-    else:
-        z = H.load("rank224.npz")
-        refs, cand, labels, caps, groups, targets, ref, gref = (z["c100_refs"], z["c100_cand"], z["c100_labels"], z["c100_caps"], z["c100_groups"],
-                                                                z["c100_targets"], z["c100_logits"], z["c100_group_logits"])
+    fname, _, tag = name.partition("_c") if "_c" in name else name.partition("_f")
+    tag = ("c" if "_c" in name else "f") + tag if tag else ""
+    z = H.load(fname + ".npz")
+    pre = tag + "_" if tag else ""
+    refs, cand, labels, caps, ref = z[pre + "refs"], z[pre + "cand"], z[pre + "labels"], z[pre + "caps"], z[pre + "logits"]
+    fiq = tag.startswith("f")
+    groups, targets, gref = (None, None, None) if fiq else (z[pre + "groups"], z[pre + "targets"], z[pre + "group_logits"])
     m2, m1 = build(g, v, int(z["seed"]), str(z["profile"]), mode, dev)
     imgs = synthetic.scene_images(range(int(z["n_index"])), 224)
     bank = V.extract_index_features(imgs, m2, batch_size=64)
-    ds = V.RelativeValSet(ref_index=refs, cand_index=cand, labels=labels, captions=[str(c) for c in caps], group_index=groups, target_index=targets)
-    lt, gt = V.generate_cirr_val_predictions(m2, m1, ds, bank, query_batch=4)
-    logits, gl = lt.cpu().numpy(), gt.cpu().numpy()
+    if fiq:
+        ds = V.RelativeValSet(ref_index=refs, cand_index=cand, labels=labels, captions=[V.fiq_caption(str(p[0]), str(p[1])) for p in caps])
+        logits, gl = V.generate_fiq_val_predictions(m2, m1, ds, bank, query_batch=4).cpu().numpy(), None
+    else:
+        ds = V.RelativeValSet(ref_index=refs, cand_index=cand, labels=labels, captions=[str(c) for c in caps], group_index=groups, target_index=targets)
+        lt, gt = V.generate_cirr_val_predictions(m2, m1, ds, bank, query_batch=4)
+        logits, gl = lt.cpu().numpy(), gt.cpu().numpy()
     scored = labels.any(1)
-    st = np.array([order_stats(logits[q], ref[q]) for q in np.where(scored)[0]]).mean(0)
+    per_q = np.array([order_stats(logits[q], ref[q]) for q in np.where(scored)[0]])
+    st = per_q.mean(0)
     e = logits[scored] - ref[scored]
-    return dict(max_abs=float(max(np.abs(e).max(), np.abs(gl - gref).max())), rms_centred=float(np.sqrt(((e - e.mean(1, keepdims=True)) ** 2).mean())),
-                exact=float(st[0]), tau=float(st[1]), top10=float(st[2]))
+    # pairs the reference separates by more than 4 x this run's own max error: how many there are, and whether all keep their order
+    tol = float(np.abs(e).max())
+    dec = flips = tot = 0
+    for q in np.where(scored)[0]:
+        iu = np.triu_indices(logits.shape[1], 1)
+        dr, do = (ref[q][:, None] - ref[q][None, :])[iu], (logits[q][:, None] - logits[q][None, :])[iu]
+        d = np.abs(dr) > 4 * tol
+        dec += int(d.sum()); tot += len(dr); flips += int((np.sign(dr[d]) != np.sign(do[d])).sum())
+    return dict(scored_queries=int(scored.sum()), max_abs=float(max(np.abs(e).max(), 0.0 if gl is None else np.abs(gl - gref).max())),
+                rms_centred=float(np.sqrt(((e - e.mean(1, keepdims=True)) ** 2).mean())),
+                logit_sigma=float(ref[scored].std(axis=1).mean()), exact=float(st[0]), tau=float(st[1]), top10=float(st[2]),
+                tau_worst_query=float(per_q[:, 1].min()), top1_agree=float(np.mean([np.argmax(logits[q]) == np.argmax(ref[q]) for q in np.where(scored)[0]])),
+                pairs_decided_at_4x_own_error=dec / tot, decided_pairs_flipped=flips)
 
 
 def timing(mode, dev, q_n=64, k=105, steps=3):
@@ -112,6 +137,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--no-timing", action="store_true")
     ap.add_argument("--modes", default="")
+    ap.add_argument("--wide", action="store_true", help="round 5: the >= 16-query fixtures besides the two round-4 ones")
     args = ap.parse_args()
     dev = torch.device("cuda")
     rows = []
@@ -119,13 +145,18 @@ def main():
         if args.modes and not any(s in mode for s in args.modes.split(",")):
             continue
         row = dict(mode=mode)
-        for fx in ("outlier224", "rank224_c100"):
+        for fx in ("outlier224", "rank224_c100") + (("outlier224_wide", "rank224_wide_c100", "rank224_wide_c200", "rank224_wide_f50") if args.wide else ()):
             row[fx] = fixture_stats(fx, mode, dev)
         torch.cuda.empty_cache()
         if not args.no_timing:
             row["triplets_per_s"] = round(timing(mode, dev), 1)
         torch.cuda.empty_cache()
         rows.append(row)
+        for fx in row:
+            if fx.endswith(("_wide", "_c200", "_f50")) or fx == "rank224_wide_c100":
+                w = row[fx]
+                print(f"   {fx:20s} {w['scored_queries']:2d} q  max|d| {w['max_abs']:.2e}  exact {w['exact']:.3f}  tau {w['tau']:.4f} (worst {w['tau_worst_query']:.4f})  top10 {w['top10']:.3f}  "
+                      f"top1 {w['top1_agree']:.2f}  decided pairs {w['pairs_decided_at_4x_own_error']:.3f} flipped {w['decided_pairs_flipped']}", file=sys.stderr, flush=True)
         o, r = row["outlier224"], row["rank224_c100"]
         print(f"{mode:62s} outlier: max|d| {o['max_abs']:.2e} exact {o['exact']:.2f} tau {o['tau']:.3f} top10 {o['top10']:.2f} | rank224 c100: "
               f"max|d| {r['max_abs']:.2e} exact {r['exact']:.3f} tau {r['tau']:.4f} top10 {r['top10']:.2f} | {row.get('triplets_per_s', 0):.0f} triplets/s",
