@@ -639,6 +639,8 @@ def main():
     args.stream_dtype = stream_name(m2)                                              # what the run actually used
     dt = m2.token_dtype                                                              # 16-bit type of pixels / image tokens in HBM
     m2.engines(); m1.engines()
+    if os.environ.get("CIR_FOLD_CROSS") in ("0", "1"):                  # A/B runs only: the query-side fold of the cross-attention K / V projections
+        m2.engines()[1].fold_cross_kv = os.environ["CIR_FOLD_CROSS"] == "1"
 
     q_n, k, ns = args.queries, args.k, args.subset
     if args.mode == "bank":

@@ -234,6 +234,11 @@ class NlvrEngine:
         self.kv_chunk = 0       # candidates per K|V + cross-attention chunk (0 = all at once; attribute, for A/B runs)
         self.fold_cls_kv = xdt != torch.float32  # last layer: fold the cross K / V projections out of the token side (False: K|V GEMM +
                                                  # attention; the "exact" fp32 mode keeps the reference's order of operations)
+        # Round 5: the OTHER layers' cross-attention with the K / V projections folded to the query side (cir_cross_attention_folded:
+        # S = (q W_k) X^T, ctx = (P X) W_v^T + b_v - 614 instead of 969 MFLOP per candidate and layer, and no (T N, 4 D) K|V tensor).
+        # Taken when the geometry is the kernel's (D = Dv = 768, 12 heads, L <= 32, N <= 224: the 224-px benchmark geometry), no key
+        # mask, no K/V bank; anything else keeps the projected path.
+        self.fold_cross_kv = xdt != torch.float32 and geo.hidden_size == 768 and geo.encoder_width == 768 and geo.num_attention_heads == 12
         e = prefix + "embeddings."
         self.word, self.posemb = _f32(sd[e + "word_embeddings.weight"], device), _f32(sd[e + "position_embeddings.weight"], device)
         self.ge, self.be = _f32(sd[e + "LayerNorm.weight"], device), _f32(sd[e + "LayerNorm.bias"], device)
@@ -255,6 +260,10 @@ class NlvrEngine:
             kv_keys = [ca[0] + "key", ca[0] + "value", ca[1] + "key", ca[1] + "value"]
             ly["wkv"] = _w16(_cat(sd, kv_keys, ".weight"), xdt, device)           # (4D, Dv)
             ly["bkv"] = _f32(_cat(sd, kv_keys, ".bias"), device)
+            if self.fold_cross_kv:        # query-side fold: W_k^T per branch, W_v with its columns in MFMA k-slot order, b_v (b_k drops out of the softmax)
+                ly["wkt"] = ops.fold_pack_key(_w16(torch.stack([sd[c + "key.weight"].detach().float() for c in ca]), xdt, device))
+                ly["wvp"] = ops.fold_pack_value(_w16(torch.stack([sd[c + "value.weight"].detach().float() for c in ca]), xdt, device))
+                ly["bvf"] = _f32(torch.stack([sd[c + "value.bias"].detach().float() for c in ca]), device)
             # one-time weight preparation in fp64 on the host (keeps library GEMMs out of the device timeline)
             w0 = sd[p + "crossattention.output.dense0.weight"].detach().cpu().double()
             w1 = sd[p + "crossattention.output.dense1.weight"].detach().cpu().double()
@@ -381,7 +390,8 @@ class NlvrEngine:
                 a32, a16 = _ln(t, ly["g1"], ly["b1"], eps, xdt, sdt)
             elif i > 0:
                 a32, a16 = self._self_block(ly, h32, h16, t_n, l, smask)
-            qc = ops.gemm(a16, ly["wq"], ly["bq"]).view(2, t_n, lq, d).permute(1, 0, 2, 3)              # (T, 2, Lq, D) view
+            qraw = ops.gemm(a16, ly["wq"], ly["bq"])                                                    # (2, T Lq, D)
+            qc = qraw.view(2, t_n, lq, d).permute(1, 0, 2, 3)                                             # (T, 2, Lq, D) view
             ccl = cc if not cls_only else torch.empty((t_n, 1, 2, d), dtype=xdt, device=cc.device)
             fold = cls_only and emask is None and self.cls_fold is not None and self.fold_cls_kv and (kv_bank is None or kv_bank[i] is None)
             if kv_bank is not None and kv_bank[i] is None and not fold:
@@ -399,6 +409,9 @@ class NlvrEngine:
                     ops.gemm(q2[b].permute(1, 0, 2), f["wkt"][b], None, out=qp[:, b * h_n:(b + 1) * h_n, :].permute(1, 0, 2))
                 o = ops.cls_cross_attention(tok, qp, scale, x_index=None if kv_bank is None else cand_rows)
                 ops.gemm(o[:, :2 * h_n, :].permute(1, 0, 2), f["wv"], f["bv"], out=ccl.view(t_n, 2 * h_n, 64).permute(1, 0, 2))
+            elif (kv_bank is None and self.fold_cross_kv and "wkt" in ly and emask is None and not cls_only and l <= 32 and n <= 224
+                  and cand16.shape[2] == d):
+                ops.cross_attention_folded(qraw, cand16, ly["wkt"], ly["wvp"], ly["bvf"], ccl, l, scale, heads=geo.num_attention_heads)
             elif kv_bank is None:
                 # K|V projection + cross-attention, optionally in candidate chunks (`kv_chunk`; measured: no gain from
                 # keeping a chunk's K|V in the Infinity Cache, so the default is one launch each)

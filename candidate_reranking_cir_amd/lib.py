@@ -37,6 +37,8 @@ SIGNATURES = {
                               c_void_p, c_int64, c_int64, c_int64,
                               c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "cir_cls_cross_attention": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "cir_cross_attention_folded": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
+                                           c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "cir_embed_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                     c_int64, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "cir_patchify": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

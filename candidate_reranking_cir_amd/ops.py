@@ -202,6 +202,48 @@ def cls_cross_attention(x: torch.Tensor, qp: torch.Tensor, scale: float, out: Op
     return out
 
 
+def fold_pack_key(wk: torch.Tensor) -> torch.Tensor:
+    """key.weight (B, D, D) [(h, d) rows, feature columns] -> the MFMA-fragment order cir_cross_attention_folded reads (include/cirrank.h):
+    (B, unit = D/32, fbh 2, head 12, ks 2, lane 64, 8): lane (g = lane >> 4, i = lane & 15) of block (unit, fbh, head, ks) holds
+    W_k[head 64 + 32 ks + 8 g + j][32 unit + 8 (i >> 2) + 4 fbh + (i & 3)], j < 8 - one contiguous KiB per wave-load."""
+    b, d, _ = wk.shape
+    h = d // 64
+    w = wk.view(b, h, 2, 4, 8, d // 32, 4, 2, 4)          # [b][head][ks][g][j][unit][i>>2][fbh][i&3]
+    return w.permute(0, 5, 7, 1, 2, 3, 6, 8, 4).contiguous().view(b, d, d)      # [b][unit][fbh][head][ks][g][i>>2][i&3][j]
+
+
+def fold_pack_value(wv: torch.Tensor) -> torch.Tensor:
+    """value.weight (B, D, D) -> (B, unit = D/32, db 4, head 12, lane 64, 8): lane (g, i) of block (unit, db, head) holds
+    W_v[head 64 + 16 db + i][32 unit + (j < 4 ? 4 g + j : 16 + 4 g + j - 4)] - the k-slot order in which two 16x16 accumulator tiles of
+    P X become one MFMA B operand."""
+    b, d, _ = wv.shape
+    h = d // 64
+    w = wv.view(b, h, 4, 16, d // 32, 2, 4, 4)            # [b][head][db][i][unit][half: features 0-15 / 16-31][g][r]
+    return w.permute(0, 4, 2, 1, 6, 3, 5, 7).contiguous().view(b, d, d)          # [b][unit][db][head][g][i][half][r]: j = 4 half + r
+
+
+def cross_attention_folded(q: torch.Tensor, x: torch.Tensor, wkt: torch.Tensor, wvp: torch.Tensor, bv: torch.Tensor, out: torch.Tensor, l: int,
+                           scale: float, heads: int = 12) -> torch.Tensor:
+    """Folded two-branch cross-attention (cir_cross_attention_folded): q (2, T*L, D) cross-query projection, x (T, N, D) tokens, wkt (2, D, D) =
+    fold_pack_key(key.weight), wvp (2, D, D) = fold_pack_value(value.weight), bv (2, D) fp32 -> out (T, L, 2, D) view (written, returned)."""
+    _need_cuda(q, x, wkt, wvp, bv, out)
+    t_n, n, d = x.shape
+    assert q.shape == (2, t_n * l, d) and q.stride(2) == 1 and x.stride(2) == 1 and x.stride(1) == d
+    assert wkt.shape == (2, d, d) and wvp.shape == (2, d, d) and wkt.is_contiguous() and wvp.is_contiguous() and bv.shape == (2, d) and bv.is_contiguous()
+    assert out.shape == (t_n, l, 2, d) and out.stride(3) == 1 and q.dtype == x.dtype == wkt.dtype == wvp.dtype == out.dtype and bv.dtype == torch.float32
+    if PROFILE_ATTN is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    code = _lib.load().cir_cross_attention_folded(q.data_ptr(), q.stride(0), q.stride(1), x.data_ptr(), x.stride(0), wkt.data_ptr(), wvp.data_ptr(), d * d,
+                                                  bv.data_ptr(), out.data_ptr(), out.stride(0), out.stride(1), out.stride(2), t_n, l, n, d, heads,
+                                                  float(scale), _DT[x.dtype], _stream())
+    if PROFILE_ATTN is not None:
+        ev1.record()      # executed flops: per (candidate, branch) 2 x (H L x 64 x D) projections + 2 x (H L x D x N) products
+        PROFILE_ATTN.append((2.0 * t_n * 2 * (2 * heads * l * 64 * d + 2 * heads * l * d * n), ev0, ev1, ("folded", l, n)))
+    _lib.check(code, "cir_cross_attention_folded")
+    return out
+
+
 def embed_layernorm(ids: torch.Tensor, word: torch.Tensor, pos: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
                     eps: float, dtype16: torch.dtype = torch.bfloat16, stream_dtype: torch.dtype = torch.float32):
     """BERT embeddings: LayerNorm(word[ids] + pos[:L]); ids (R, L) int64 -> (y_stream, y16) of shape (R, L, cols)."""

@@ -139,6 +139,27 @@ int cir_cls_cross_attention(const void* x, int64_t x_s1, const int64_t* x_index,
                             float scale, int dtype, void* stream);
 
 /*
+ * Cross-attention of ALL caption tokens of both branches over a candidate's image tokens with the key and value projections folded out of
+ * the token side (ABI v11, round 5; csrc/xattn_fold.hip) - the two-branch BertLayer's crossattention.self{0,1} (nlvr_encoder.py:150-168,
+ * 183-217, called :321-344) without ever forming K = X W_k^T or V = X W_v^T:
+ *   out[t][tok][b][h 64 + d] = sum_f W_v[b][h 64 + d][f] (sum_j softmax_j((q[b][t L + tok][h] W_k[b][h]) . x[t][j] * scale) x[t][j][f]) + b_v[b][h 64 + d]
+ * (the key bias is constant over j and drops out of the softmax; the rows of the softmax sum to 1, so the value bias adds as it is).
+ * q (2, T L, D) 16-bit: the cross-attention QUERY projection incl. its bias (branch stride q_sb, row stride q_rs); x (T, N, D) 16-bit tokens
+ * (item stride x_s1, rows contiguous); wkt / wvp (2, D, D each, branch stride w_sb): key.weight / value.weight re-ordered per MFMA fragment, one
+ * contiguous KiB (64 lanes x 8 values; lane = 16 g + i) per wave-load -
+ *   wkt[b] block ((u 2 + t) 12 + h) 2 + s : lane (g, i) holds key.weight[64 h + 32 s + 8 g + j][32 u + 8 (i >> 2) + 4 t + (i & 3)],  j < 8
+ *   wvp[b] block (u 4 + e) 12 + h         : lane (g, i) holds value.weight[64 h + 16 e + i][32 u + (j < 4 ? 4 g + j : 16 + 4 g + j - 4)]
+ * (u < D / 32 feature units, t < 2, s < 2, e < 4, h < 12; candidate_reranking_cir_amd/ops.py: fold_pack_key / fold_pack_value);
+ * bv (2, D) fp32 value bias; out (T, L, 2, D)-shaped through strides.
+ * D = 768, H = 12, L <= 32, N <= 224, no key mask (CIR_ESHAPE otherwise: use cir_gemm_bias_act + cir_attention).  16-bit operands, fp32
+ * accumulation and softmax; Q' = q W_k and C' = P X are rounded to the operand type where the projected path rounds K and V.
+ * 614 MFLOP per (candidate, both branches) instead of 969, and no (T N, 4 D) K|V tensor.
+ */
+int cir_cross_attention_folded(const void* q, int64_t q_sb, int64_t q_rs, const void* x, int64_t x_s1, const void* wkt, const void* wvp, int64_t w_sb,
+                               const float* bv, void* out, int64_t o_st, int64_t o_sr, int64_t o_sb, int T, int L, int N, int D, int H, float scale,
+                               int dtype, void* stream);
+
+/*
  * BertEmbeddings.forward (nlvr_encoder.py:68-91, med.py:87-110):
  *   y[r] = LayerNorm(word[ids[r]] + pos[r % L]) for r < rows; fp32 tables, outputs as cir_layernorm
  *   (y_stream in CIR_F32 / CIR_F16, y16 in dtype16).

@@ -131,6 +131,16 @@ def test_rank224_and_bxb224():
         np.testing.assert_allclose(zt[:, 0].numpy(), b["z_t_cls"], atol=1e-4)
         out = torch.stack([O.img_txt_fusion_val(sd2, zt[i:i + 1], bank[4:8], ids[i:i + 1], mask[i:i + 1]) for i in range(4)])
     np.testing.assert_allclose(out.numpy(), b["logits"], atol=2e-4)
+    # the >= 16-query regrowth of the fixture (round 5, rank224_wide.npz: same weights and bank): the CIRR subset of one K = 200 query
+    zw = H.load("rank224_wide.npz")
+    qw = 3
+    rows_w = [int(zw["c200_refs"][qw])] + [int(i) for i in zw["c200_groups"][qw]]
+    with torch.no_grad():
+        fw = O.img_embed(sd2, synthetic.scene_images(rows_w, 224))
+        ids, mask = H.tokenize([str(zw["c200_caps"][qw])])
+        glog = O.img_txt_fusion_val(sd2, O.stage1_z_t(sd1, fw[:1], ids, mask), fw[1:], ids, mask)
+    np.testing.assert_allclose(glog.numpy(), zw["c200_group_logits"][qw], atol=2e-4)
+    assert int(zw["c100_labels"].any(1).sum()) == 16 and int(zw["c200_labels"].any(1).sum()) == 16 and int(zw["f50_labels"].any(1).sum()) == 16
 
 
 def test_outlier224():
@@ -158,6 +168,15 @@ def test_outlier224():
         zt = O.stage1_z_t(sd1, feats[pos[rows[6]]][None], ids, mask)
         logits = O.img_txt_fusion_val(sd2, zt, feats[[pos[i] for i in rows[7:19]]], ids, mask)
         np.testing.assert_allclose(logits.numpy(), z["logits"][1][:12], atol=3e-4)
+        # outlier224_wide.npz (round 5: 16 scored queries on the same weights): the CIRR subset of one of its queries
+        zw = H.load("outlier224_wide.npz")
+        qw = 5
+        rows_w = [int(zw["refs"][qw])] + [int(i) for i in zw["groups"][qw]]
+        fw = O.img_embed(sd2, synthetic.scene_images(rows_w, 224))
+        ids, mask = H.tokenize([str(zw["caps"][qw])])
+        glog = O.img_txt_fusion_val(sd2, O.stage1_z_t(sd1, fw[:1], ids, mask), fw[1:], ids, mask)
+        np.testing.assert_allclose(glog.numpy(), zw["group_logits"][qw], atol=3e-4)
+        assert int(zw["labels"].any(1).sum()) == 16 and bool((zw["logits"][~zw["labels"].any(1)] == np.float32(-99999.99)).all())
 
 
 def test_vit_large_tiny():
