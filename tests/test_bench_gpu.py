@@ -138,7 +138,10 @@ def test_loop_mode_line():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
     assert d["value"] > 0 and "scoring loop" in d["metric"] and d["host_overhead_frac"] < 1
-    assert d["recall"] == d["recall_kv_bank"] and d["logits_max_abs_diff_bank_vs_loop"] == 0.0 and d["level1_ms_per_query"] > 0
+    # (the loop folds the cross-attention K / V projections to the query side since round 5, the K/V bank holds PROJECTED keys / values: the two
+    #  paths agree within the operand rounding, no longer bit for bit; test_model_gpu.py::test_kv_bank_reuse_is_bit_identical pins the identity
+    #  with the fold switched off)
+    assert d["logits_max_abs_diff_bank_vs_loop"] < 5e-3 and d["level1_ms_per_query"] > 0 and len(d["recall"]) == len(d["recall_kv_bank"])
 
 
 def test_train_mode_line():

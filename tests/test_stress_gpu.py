@@ -73,4 +73,4 @@ def test_config4_one_rank_share_properties():
     V.generate_val_predictions(m2, m1, mk(cand[:16], labels[:16], group[:16], np.arange(16)), bank, query_batch=qb)
     peak_16 = torch.cuda.max_memory_allocated() - base_mem
     print(f"\n[configs[4] share] 64 x 205 fp16 K=200: peak {peak_64 / 2**30:.2f} GiB at Q=64, {peak_16 / 2**30:.2f} GiB at Q=16 (query_batch {qb})")
-    assert peak_64 < 1.1 * peak_16 + (q_n * (k + ns) * 4) * 4
+    assert peak_64 < 1.25 * peak_16 + (q_n * (k + ns) * 4) * 4        # (1.12 since the folded cross-attention removed the per-batch K|V tensor: the fixed part weighs more)
