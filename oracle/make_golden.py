@@ -725,18 +725,24 @@ def train_goldens_197(R, full_bert):
     print("train197: loss", loss.item(), "logits sigma", logits.std().item(), "params with grad", len(names), "norm range", min(norms), max(norms))
 
 
-def train_goldens_imgtune(R, full_bert):
-    """tests/golden/train_imgtune.npz: ONE training step of the real reference WITH the image encoder trained (`--blip-img-tune`,
+def train_goldens_imgtune(R, full_bert, real_geometry=False):
+    """`real_geometry` (round 5, `make_golden.py train imgtune224` -> tests/golden/train_imgtune224.npz): the same step at the image encoder's REAL
+    geometry - ViT-B/16 at 224 px, depth 12, 197 tokens - so that the 12-block reverse pass `bench --mode train --img-tune` times is pinned by the
+    reference too (150 ViT + 572 text-side gradients); stores a slice of the target tokens instead of all 600 k values, and the reference's
+    cls_head.0 pre-activations (which ReLU entries sit within a 16-bit forward's drift of zero).
+    tests/golden/train_imgtune.npz: ONE training step of the real reference WITH the image encoder trained (`--blip-img-tune`,
     stage2_train.py:87-92, 191-199): as train768 - full 12-layer med_config over a 2-block 64-px ViT, B = 4 ragged captions, dropout 0, fp32
     CPU - but the target images' tokens come from `model.img_embed` in .train() mode with a graph, so `loss.backward()` also fills the
     gradients of every visual_encoder parameter (through the cross-attention K|V projections of all 24 branch layers, the final LayerNorm,
     both blocks, position embedding, class token and the patch-embedding convolution).  DropPath (stochastic depth, the only random part of
     the image encoder in train mode) is switched off like the dropouts.  Stored like train768, plus the target tokens."""
     cfg = dict(full_bert, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
-    vit = dict(image_size=64, width=768, depth=2, num_heads=12, drop_path_rate=0.0)
+    vit = dict(image_size=224 if real_geometry else 64, width=768, depth=12 if real_geometry else 2, num_heads=12, drop_path_rate=0.0)
     m2, m1, g, v = build_reference_models(R, cfg, vit, seed=17, profile="test")
     for blk in m2.visual_encoder.blocks:                                         # blip_stage2.py:37 builds the ViT with drop_path_rate 0.1: block 1
         blk.drop_path = torch.nn.Identity()                                      # of 2 would drop samples at random - the fixture pins rate 0
+    pre = {}
+    hook = m2.cls_head[0].register_forward_hook(lambda mod, inp, out: pre.__setitem__("x", out.detach().clone()))
     b = 4
     caps = [synthetic.caption_text(270 + i, n) for i, n in enumerate((6, 4, 9, 5))]
     images = synthetic.scene_images(range(2 * b), v.image_size)
@@ -759,10 +765,14 @@ def train_goldens_imgtune(R, full_bert):
         gq = p.grad.detach().flatten()
         names.append(name); norms.append(gq.double().norm().item()); sums.append(gq.double().sum().item())
         samples.append(gq[torch.from_numpy(grad_sample_index(gq.numel()))].numpy())
-    np.savez_compressed(os.path.join(OUT, "train_imgtune.npz"), bert_cfg=json.dumps(cfg), vit_cfg=json.dumps(vit), seed=17, profile="test",
-                        caps=np.array(caps), input_ids=ids.numpy(), attention_mask=tok.attention_mask.numpy(), image_ids=np.arange(b, 2 * b),
-                        z_t=z.last_hidden_state.numpy(), feats=feats_t.detach().numpy(), logits=logits.detach().numpy(), loss=loss.item(),
-                        names=np.array(names), norms=np.array(norms), sums=np.array(sums), samples=np.stack(samples))
+    hook.remove()
+    feats_np = feats_t.detach().numpy()
+    extra = dict(feats=feats_np) if not real_geometry else dict(feats_slice=feats_np[:, :6, :32], feats_sum=float(feats_t.detach().double().sum()),
+                                                              feats_abs_mean=float(feats_t.detach().abs().mean()), cls_pre=pre["x"].numpy())
+    np.savez_compressed(os.path.join(OUT, "train_imgtune224.npz" if real_geometry else "train_imgtune.npz"), bert_cfg=json.dumps(cfg), vit_cfg=json.dumps(vit),
+                        seed=17, profile="test", caps=np.array(caps), input_ids=ids.numpy(), attention_mask=tok.attention_mask.numpy(), image_ids=np.arange(b, 2 * b),
+                        z_t=z.last_hidden_state.numpy(), logits=logits.detach().numpy(), loss=loss.item(),
+                        names=np.array(names), norms=np.array(norms), sums=np.array(sums), samples=np.stack(samples), **extra)
     nv = [n_ for n_, nm in zip(norms, names) if nm.startswith("visual_encoder.")]
     print("train_imgtune: loss", loss.item(), "logits sigma", logits.std().item(), "params with grad", len(names), "of them ViT", len(nv),
           "ViT norm range", min(nv), max(nv))
@@ -855,8 +865,8 @@ def main():
         full_bert = json.load(open(os.path.join(ref_shim.REFERENCE_ROOT, "configs", "med_config.json")))
         if len(sys.argv) > 2 and sys.argv[2] == "197":
             return train_goldens_197(R, full_bert)
-        if len(sys.argv) > 2 and sys.argv[2] == "imgtune":
-            return train_goldens_imgtune(R, full_bert)
+        if len(sys.argv) > 2 and sys.argv[2] in ("imgtune", "imgtune224"):
+            return train_goldens_imgtune(R, full_bert, real_geometry=sys.argv[2] == "imgtune224")
         return train_goldens(R, full_bert)
     if len(sys.argv) > 1 and sys.argv[1] == "ckpt":     # only the checkpoint-loader fixture
         torch.manual_seed(0)

@@ -234,14 +234,16 @@ def test_training_step_gradients(fixture):
             np.testing.assert_allclose(w[key[6:]].grad.numpy(), z[key], atol=1e-3 * np.abs(z[key]).max() + 1e-7 * gmax, err_msg=key)
 
 
-def test_training_step_gradients_with_vit_fine_tuning():
+@pytest.mark.parametrize("fixture", ["train_imgtune.npz", "train_imgtune224.npz"], ids=["depth2-64px", "vitb16-224px"])
+def test_training_step_gradients_with_vit_fine_tuning(fixture):
     """`--blip-img-tune` (stage2_train.py:87-92, 191-199): the oracle's autograd through O.vit_forward + O.img_txt_fusion_train against ONE
     step of the real reference with the image encoder trained (tests/golden/train_imgtune.npz, `oracle/make_golden.py train imgtune`):
-    target tokens, logits, loss, the SET of parameters with a gradient (572 text-side + 30 ViT), every gradient's norm and 64 samples."""
+    target tokens, logits, loss, the SET of parameters with a gradient (572 text-side + 30 ViT), every gradient's norm and 64 samples.
+    Round 5: the same at the image encoder's REAL geometry (train_imgtune224.npz: ViT-B/16, depth 12, 224 px / 197 tokens, 150 ViT gradients)."""
     import json
     import torch.nn.functional as F
     from candidate_reranking_cir_amd import synthetic
-    z = H.load("train_imgtune.npz")
+    z = H.load(fixture)
     g, v = H.geometry(json.loads(str(z["bert_cfg"])), json.loads(str(z["vit_cfg"])))
     sd2, _ = H.state_dicts(g, v, int(z["seed"]), str(z["profile"]))
     torch.set_num_threads(8)
@@ -250,7 +252,11 @@ def test_training_step_gradients_with_vit_fine_tuning():
     for k in keys:
         w[k].requires_grad_(True)
     feats = O.vit_forward(w, synthetic.scene_images(z["image_ids"].tolist(), v.image_size))
-    np.testing.assert_allclose(feats.detach().numpy(), z["feats"], atol=2e-4)
+    if "feats" in z.files:
+        np.testing.assert_allclose(feats.detach().numpy(), z["feats"], atol=2e-4)
+    else:
+        np.testing.assert_allclose(feats.detach().numpy()[:, :6, :32], z["feats_slice"], atol=2e-4)
+        assert abs(feats.detach().double().sum().item() - float(z["feats_sum"])) < 1e-5 * float(z["feats_abs_mean"]) * feats.numel()
     bsz = z["input_ids"].shape[0]
     logits = O.img_txt_fusion_train(w, torch.from_numpy(z["z_t"]), feats, torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]))
     loss = F.cross_entropy(logits, torch.arange(bsz))
@@ -258,7 +264,8 @@ def test_training_step_gradients_with_vit_fine_tuning():
     np.testing.assert_allclose(logits.detach().numpy(), z["logits"], atol=2e-4)
     assert abs(loss.item() - float(z["loss"])) < 1e-4
     names = [str(n) for n in z["names"]]
-    assert sorted(names) == sorted(k for k in keys if w[k].grad is not None) and sum(n.startswith("visual_encoder.") for n in names) == 30
+    assert sorted(names) == sorted(k for k in keys if w[k].grad is not None)
+    assert sum(n.startswith("visual_encoder.") for n in names) == 6 + 12 * v.depth and sum(not n.startswith("visual_encoder.") for n in names) == 572
     gmax = float(z["norms"].max())
     for i, n in enumerate(names):
         gq = w[n].grad.flatten()

@@ -25,23 +25,26 @@ def cuda():
     return torch.device("cuda")
 
 
-def _setup(dtype):
-    z = H.load("train_imgtune.npz")
+def _setup(dtype, fixture="train_imgtune.npz"):
+    z = H.load(fixture)
     g, v = H.geometry(json.loads(str(z["bert_cfg"])), json.loads(str(z["vit_cfg"])))
     m2, sd2 = build(g, v, int(z["seed"]), str(z["profile"]), dtype)
     images = synthetic.scene_images(z["image_ids"].tolist(), v.image_size)
     return z, g, v, m2, sd2, images
 
 
+@pytest.mark.parametrize("fixture", ["train_imgtune.npz", "train_imgtune224.npz"], ids=["depth2-64px", "vitb16-224px"])
 @pytest.mark.parametrize("dtype", [BF, HF], ids=["bf16", "fp16"])
-def test_vit_fine_tuning_step_matches_reference(cuda, dtype):
-    z, g, v, m2, sd2, images = _setup(dtype)
+def test_vit_fine_tuning_step_matches_reference(cuda, dtype, fixture):
+    """Round 5: also at the image encoder's REAL geometry (train_imgtune224.npz: ViT-B/16 at 224 px, depth 12, 197 tokens - the 12-block reverse
+    pass `bench --mode train --img-tune` times), 150 ViT + 572 text-side gradients of ONE step of the real reference."""
+    z, g, v, m2, sd2, images = _setup(dtype, fixture)
     assert v.drop_path_rate == 0.0 and g.hidden_dropout_prob == 0.0
     bsz = z["input_ids"].shape[0]
     m2.train()
     feats = m2.img_embed(images.cuda())                                       # train mode + autograd + trainable ViT: carries a graph
     assert feats.requires_grad and feats.dtype == torch.float32
-    e_f = np.abs(feats.detach().cpu().numpy() - z["feats"]).max()
+    e_f = np.abs(feats.detach().cpu().numpy() - z["feats"]).max() if "feats" in z.files else np.abs(feats.detach()[:, :6, :32].cpu().numpy() - z["feats_slice"]).max()
     caps = [str(c) for c in z["caps"]]
     logits = m2.img_txt_fusion(torch.from_numpy(z["z_t"]).cuda(), feats.float(), caps, train=True)
     loss = F.cross_entropy(logits, torch.arange(bsz, device=cuda))
@@ -50,7 +53,15 @@ def test_vit_fine_tuning_step_matches_reference(cuda, dtype):
     params = dict(m2.named_parameters())
     names = [str(n) for n in z["names"]]
     assert sorted(names) == sorted(n for n, p in params.items() if p.grad is not None), "set of parameters that received a gradient"
-    assert sum(n.startswith("visual_encoder.") for n in names) == 30
+    assert sum(n.startswith("visual_encoder.") for n in names) == 6 + 12 * v.depth
+    flips = None
+    if "cls_pre" in z.files:
+        # cls_head's ReLU: which units the 16-bit forward put on the other side of zero than the reference's fp32 forward - every one of them must
+        # sit within the forward's own drift of zero in the REFERENCE (a flip anywhere else would be a forward error, not a rounding)
+        pre = torch.from_numpy(z["cls_pre"])
+        flip = m2._trainer.head_mask().cpu() != (pre > 0)
+        flips = int(flip.sum())
+        assert flips == 0 or float(pre[flip].abs().max()) < 4 * LOGIT_ABS[dtype], (flips, float(pre[flip].abs().max()))
     gmax = float(z["norms"].max())
     worst, num, den = (0.0, ""), 0.0, 0.0
     for i, n in enumerate(names):
@@ -63,8 +74,8 @@ def test_vit_fine_tuning_step_matches_reference(cuda, dtype):
         e = max(float(np.sqrt(np.mean((got - z["samples"][i]) ** 2)) / (ref_norm / np.sqrt(gq.numel()))), abs(gq.double().norm().item() - ref_norm) / ref_norm)
         worst = max(worst, (e, n))
         num, den = num + e * ref_norm, den + ref_norm
-    print(f"\n[train_imgtune {dtype}] tokens {e_f:.3e}  logits {e_log:.3e}  loss {loss.item():.5f} vs {float(z['loss']):.5f}  worst grad rel {worst[0]:.3e} "
-          f"({worst[1]})  norm-weighted mean {num / den:.3e}")
+    print(f"\n[{fixture[:-4]} {dtype}] tokens {e_f:.3e}  logits {e_log:.3e}  loss {loss.item():.5f} vs {float(z['loss']):.5f}  worst grad rel {worst[0]:.3e} "
+          f"({worst[1]})  norm-weighted mean {num / den:.3e}" + ("" if flips is None else f"  ReLU units flipped against the reference: {flips} of {z['cls_pre'].size}"))
     assert e_f < FEATS_ABS[dtype] and e_log < 2 * LOGIT_ABS[dtype] and abs(loss.item() - float(z["loss"])) < 2 * LOGIT_ABS[dtype]
     assert worst[0] < GOLDEN_REL[dtype] and num / den < GOLDEN_REL_MEAN[dtype]
     # the backward arithmetic proper: autograd of the oracle (ViT included) on the ReLU piece this forward took, full tensors
@@ -89,9 +100,10 @@ def test_vit_fine_tuning_step_matches_reference(cuda, dtype):
             w_e = max(w_e, (e, n))
             tot, cnt = tot + e, cnt + 1
         res[part] = (w_e, tot / cnt)
-        print(f"[train_imgtune {dtype}] same ReLU piece, {part:15s} worst grad rel {w_e[0]:.3e} ({w_e[1]})  mean {tot / cnt:.3e}")
+        print(f"[{fixture[:-4]} {dtype}] same ReLU piece, {part:15s} worst grad rel {w_e[0]:.3e} ({w_e[1]})  mean {tot / cnt:.3e}")
     assert res["text"][0][0] < GRAD_REL[dtype] and res["text"][1] < GRAD_REL_MEAN[dtype]
-    assert res["visual_encoder."][0][0] < 1.5 * GRAD_REL[dtype] and res["visual_encoder."][1] < 2 * GRAD_REL_MEAN[dtype]   # a 2-block ViT behind 24 K|V projections
+    deep = 2.0 if v.depth > 2 else 1.0     # (12 blocks of reverse pass behind 24 K|V projections accumulate more operand rounding than 2)
+    assert res["visual_encoder."][0][0] < 1.5 * deep * GRAD_REL[dtype] and res["visual_encoder."][1] < 2 * deep * GRAD_REL_MEAN[dtype]
     m2.eval()
 
 
