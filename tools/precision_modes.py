@@ -109,7 +109,15 @@ def fixture_stats(name, mode, dev):
         dr, do = (ref[q][:, None] - ref[q][None, :])[iu], (logits[q][:, None] - logits[q][None, :])[iu]
         d = np.abs(dr) > 4 * tol
         dec += int(d.sum()); tot += len(dr); flips += int((np.sign(dr[d]) != np.sign(do[d])).sum())
-    return dict(scored_queries=int(scored.sum()), max_abs=float(max(np.abs(e).max(), 0.0 if gl is None else np.abs(gl - gref).max())),
+    extra = {}
+    if "logits_f64" in z.files:      # conditioning: the reference's own fp32-vs-fp64 deviation per query (oracle/make_golden.py wide outlier64)
+        qs = np.where(scored)[0]
+        noise = np.abs(z["logits_f64"][qs] - ref[qs].astype(np.float64)).max(1)
+        well = noise < 2e-5
+        extra = dict(well_conditioned_queries=int(well.sum()), reference_fp32_vs_fp64_noise_max=float(noise.max()),
+                     well_max_abs=float(np.abs(e[well]).max()), well_exact=float(per_q[well, 0].mean()), well_tau=float(per_q[well, 1].mean()),
+                     well_tau_worst=float(per_q[well, 1].min()), well_top10=float(per_q[well, 2].mean()))
+    return dict(**extra, scored_queries=int(scored.sum()), max_abs=float(max(np.abs(e).max(), 0.0 if gl is None else np.abs(gl - gref).max())),
                 rms_centred=float(np.sqrt(((e - e.mean(1, keepdims=True)) ** 2).mean())),
                 logit_sigma=float(ref[scored].std(axis=1).mean()), exact=float(st[0]), tau=float(st[1]), top10=float(st[2]),
                 tau_worst_query=float(per_q[:, 1].min()), top1_agree=float(np.mean([np.argmax(logits[q]) == np.argmax(ref[q]) for q in np.where(scored)[0]])),
@@ -166,6 +174,9 @@ def main():
         for fx in row:
             if fx.endswith(("_wide", "_c200", "_f50")) or fx == "rank224_wide_c100":
                 w = row[fx]
+                if "well_tau" in w:
+                    print(f"   {fx:20s} well-conditioned {w['well_conditioned_queries']} q: max|d| {w['well_max_abs']:.2e}  exact {w['well_exact']:.3f}  tau {w['well_tau']:.4f} "
+                          f"(worst {w['well_tau_worst']:.4f})  top10 {w['well_top10']:.3f}", file=sys.stderr, flush=True)
                 print(f"   {fx:20s} {w['scored_queries']:2d} q  max|d| {w['max_abs']:.2e}  exact {w['exact']:.3f}  tau {w['tau']:.4f} (worst {w['tau_worst_query']:.4f})  top10 {w['top10']:.3f}  "
                       f"top1 {w['top1_agree']:.2f}  decided pairs {w['pairs_decided_at_4x_own_error']:.3f} flipped {w['decided_pairs_flipped']}", file=sys.stderr, flush=True)
         o, r = row["outlier224"], row["rank224_c100"]
