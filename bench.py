@@ -815,7 +815,7 @@ def main():
             precision[f"{od}+{sd_}_stream"] = round(n_cand * 3 / (time.perf_counter() - tv), 1)
             del images_v
         precision["note"] = ("triplets/s of the same step at each operand mode + residual-stream storage (3 steps each; split = text side fp32, "
-                             "ViT fp16).  Rank fidelity of every mode against the reference's fp32 outputs: profiles/r4_precision_modes.json, "
+                             "ViT fp16).  Rank fidelity of every mode against the reference's fp32 outputs: profiles/r5_precision_modes.json, "
                              "DESIGN.md section 2")
 
     if rank == 0:
@@ -835,7 +835,7 @@ def main():
         # HBM bytes per launch of the dominant kernel: offline PMC passes of this same command (tools/collect_profiles.sh); the
         # summary names the workload and the hash of the kernel sources it was measured on - any other build reports null
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r4_pmc_summary.json")
+        tpath = os.path.join(ROOT, "profiles", "r5_pmc_summary.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             same = (tj.get("csrc_sha16") == csrc_sha16() and tj.get("queries") == q_n and tj.get("k") == k and tj.get("subset") == ns
@@ -844,7 +844,7 @@ def main():
             ent = tj.get("by_kernel", {}).get(dom_name) if same else None
             if ent:
                 traffic = round(ent["hbm_bytes_per_launch"])
-                traffic_src = ("profiles/r4_pmc_summary.json: offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these "
+                traffic_src = ("profiles/r5_pmc_summary.json: offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these "
                                "kernel sources (csrc_sha16 matches; not this run)")
         line = {
             "metric": "query-candidate triplets scored/sec at K=100", "value": round(value, 2), "unit": "triplets/s",

@@ -7,15 +7,15 @@
 # The profiled program is `python3 bench.py ...` directly after `--` (no env / bash -c hop: the profiler's preloaded
 # library has initialised the GPU before the program starts).
 set -euo pipefail
-TAG=${1:-r4}
+TAG=${1:-r5}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o run -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-precision-table > $OUT/${TAG}_stats.json 2> $OUT/${TAG}_stats.err
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmc_sq -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-precision-table > $OUT/${TAG}_pmc_sq.json 2> $OUT/${TAG}_pmc_sq.err
-rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_fetch -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-precision-table > $OUT/${TAG}_pmc_fetch.json 2> $OUT/${TAG}_pmc_fetch.err
-rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_write -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-precision-table > $OUT/${TAG}_pmc_write.json 2> $OUT/${TAG}_pmc_write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o run -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-precision-table --no-rank-fidelity > $OUT/${TAG}_stats.json 2> $OUT/${TAG}_stats.err
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmc_sq -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-precision-table --no-rank-fidelity > $OUT/${TAG}_pmc_sq.json 2> $OUT/${TAG}_pmc_sq.err
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_fetch -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-precision-table --no-rank-fidelity > $OUT/${TAG}_pmc_fetch.json 2> $OUT/${TAG}_pmc_fetch.err
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_write -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-precision-table --no-rank-fidelity > $OUT/${TAG}_pmc_write.json 2> $OUT/${TAG}_pmc_write.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_train_stats -o run -- python3 $ROOT/bench.py --mode train --image-size 384 --steps 4 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_train_stats.json 2> $OUT/${TAG}_train_stats.err
 # the training step's kernels under the same three PMC passes (MFMA-pipe utilisation, fetched / written bytes per launch)
 for grp in "sq:SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do

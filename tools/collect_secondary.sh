@@ -2,7 +2,7 @@
 # Secondary-configuration bench lines, per-shape GEMM table, stand-alone kernel timings (GPU box; run through gpurun from
 # the repo root):   bash tools/collect_secondary.sh r3   -> gpurun_out/<tag>_sec/*.json|txt   (copy what is judged into profiles/)
 set -uo pipefail
-TAG=${1:-r4}
+TAG=${1:-r5}
 O=gpurun_out/${TAG}_sec
 mkdir -p $O
 python bench.py --steps 20 --warmup 5 > $O/bench_default_20steps.json 2> $O/err.txt                                   # the driver's command

@@ -40,11 +40,16 @@ def canonical(name: str):
         st = ",_Float16" if "_Float16" in name else ""
         res = "true" if re.search(r"true(, *[_A-Za-z0-9-]+)*>", name) else "false"
         return f"cir::gemm256_kernel<?,true,{res}{st}>"
+    if "gemm_kernelIfLi1E" in name or "gemm_kernel<float" in name:
+        return "cir::gemm_kernel<float,1>"
     m = re.search(r"gemm_kernelI(DF16b|DF16_|Dh)Li([012])E", name)
     if m:
         return f"cir::gemm_kernel<{'__bf16' if m.group(1) == 'DF16b' else '_Float16'},{m.group(2)}>"
     if "gemm_kernel<" in name:
         return "cir::gemm_kernel<?>"
+    for short in ("xattn_fold_kernel", "attn_f32_kernel"):
+        if short in name:
+            return f"cir::{short}"
     for short in ("attn_shared_kernel", "attn_stream_kernel", "layernorm_h16_kernel", "layernorm_kernel", "embed_ln_kernel", "patchify_kernel", "vit_assemble_kernel",
                   "gather_rows_kernel", "topk_desc_kernel", "small_linear_kernel", "cls_xattn_kernel"):
         if short in name:
