@@ -97,6 +97,10 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} is missing: build the gfx950 kernels first "
             f"(`python -c 'import __graft_entry__ as g; g.build()'` or `make -C candidate_reranking_cir_amd/csrc`). "
             f"There is no CPU/PyTorch fallback for this path.")
+    # torch FIRST: its wheel bundles its own libamdhip64; a process that loads libcirrank.so before torch would bind the kernels to the
+    # system HIP runtime and torch's tensors to the bundled one - two runtimes, and every launch fails with "no ROCm-capable device"
+    # (seen with `g.build(); g.smoke()` in one process).  With torch loaded the library's HIP symbols resolve to the runtime torch uses.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
