@@ -201,6 +201,8 @@ class BLIP_NLVR(_EngineHost):
                                         cross_dtype=self.token_dtype))
             self._text_stale = False
             self._packed_epoch = _lib.PARAM_EPOCH[0]
+            self._vit_stale = False                    # (a full build packs the ViT too: no second VitEngine below - round-4 advisor finding)
+            self._vit_packed_epoch = _lib.PARAM_EPOCH[0]
         if self._engines is not None and (getattr(self, "_vit_stale", False) or (getattr(self, "_vit_trainer", None) is not None
                                                                                  and getattr(self, "_vit_packed_epoch", None) != _lib.PARAM_EPOCH[0])):
             # the ViT is being fine-tuned (train_vit.py): its packed engine follows the parameters the same way the text side's does

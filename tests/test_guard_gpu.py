@@ -305,3 +305,67 @@ def test_attention_kv_bank_many_workgroups(ops):
     ops.attention(q, gth[:, :, 0::2].permute(0, 2, 1, 3), gth[:, :, 1::2].permute(0, 2, 1, 3), out_b, 0.125)
     torch.cuda.synchronize()
     assert torch.equal(out_a, out_b)
+
+
+# ------------------------------------------------------------------------------------------------ round 5 kernels
+@pytest.mark.parametrize("m,n,k", [(333, 400, 224), (1, 16, 32), (257, 768, 768), (5000, 2304, 64)])
+@pytest.mark.parametrize("variant", ["plain", "gelu", "res_alias"])
+def test_gemm_f32_guard_bands(ops, m, n, k, variant):
+    """The fp32-operand instantiation of the 128-tile GEMM (exact mode): ragged M / N edges, output view inside canaries."""
+    a = _ints((m, k), -3, 3, torch.float32, seed=m + k)
+    w = _ints((n, k), -3, 3, torch.float32, seed=n + k + 1)
+    bias = _ints((n,), -5, 5, torch.float32, seed=3)
+    guard = Guarded(m, n, torch.float32)
+    ref = a @ w.T + bias
+    if variant == "res_alias":
+        res = _ints((m, n), -4, 4, torch.float32, seed=9)
+        out = guard.fill_view(res)
+        ops.gemm(a, w, bias, residual=out, out=out)
+        ref = ref + res
+    else:
+        ops.gemm(a, w, bias, act=1 if variant == "gelu" else 0, out=guard.view)
+        if variant == "gelu":
+            ref = F.gelu(ref)
+    torch.cuda.synchronize()
+    guard.assert_intact(f"gemm f32 {variant} {m}x{n}x{k}")
+    assert torch.equal(guard.view, ref) if variant != "gelu" else (guard.view - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("b1,h,lq,lk", [(3, 2, 33, 65), (2, 12, 197, 197), (5, 1, 1, 9), (2, 3, 32, 577)])
+def test_attention_f32_guard_bands(ops, b1, h, lq, lk):
+    """attn_f32_kernel stores through per-lane row pointers with a ragged last query tile: the (B, Lq, H 64) output sits inside canaries."""
+    d = 64 * h
+    g = torch.Generator(device="cpu").manual_seed(lq * 7 + lk)
+    q, k, v = (torch.randn((b1, 1, n_, d), generator=g).cuda() for n_ in (lq, lk, lk))
+    guard = Guarded(b1 * lq, d, torch.float32)
+    out = guard.view.unflatten(0, (b1, 1, lq))
+    ops.attention(q, k, v, out, 0.125)
+    torch.cuda.synchronize()
+    guard.assert_intact(f"attention f32 {b1}x{h} {lq}x{lk}")
+    ref = F.scaled_dot_product_attention(q.view(b1, lq, h, 64).transpose(1, 2), k.view(b1, lk, h, 64).transpose(1, 2), v.view(b1, lk, h, 64).transpose(1, 2))
+    assert (out.view(b1, lq, h, 64).transpose(1, 2) - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "fp16"])
+@pytest.mark.parametrize("t_n,l,n", [(3, 32, 197), (5, 7, 197), (2, 31, 224), (9, 1, 33)])
+def test_folded_cross_attention_guard_bands(ops, dtype, t_n, l, n):
+    """xattn_fold_kernel writes token rows < L of a (T, L, 2, 768) tensor from 48-row wave tiles (rows beyond L are computed on zero queries and
+    must not be stored), reads X rows clamped to N - 1 and weight fragments through buffer descriptors: output inside canaries, and the
+    tokens / weights sit at the END of their allocations (a read past them would hit the next allocation's canary NaNs and poison the result)."""
+    D = 768
+    g = torch.Generator(device="cpu").manual_seed(t_n * 31 + l)
+    r = lambda shape, s: (torch.randn(shape, generator=g) * s).to(dtype).cuda()
+    q, x = r((2, t_n * l, D), 1.0), r((t_n, n, D), 1.0)
+    wk, wv, bv = r((2, D, D), 0.03), r((2, D, D), 0.03), torch.randn((2, D), generator=g).cuda()
+    guard = Guarded(t_n * l, 2 * D, dtype)
+    out = guard.view.unflatten(0, (t_n, l)).unflatten(2, (2, D))
+    ops.cross_attention_folded(q, x, ops.fold_pack_key(wk), ops.fold_pack_value(wv), bv, out, l, 0.125)
+    torch.cuda.synchronize()
+    guard.assert_intact(f"folded cross-attention T {t_n} L {l} N {n}")
+    assert torch.isfinite(out.float()).all()
+    # against the projected path of the library on the same inputs
+    wkv, bkv = torch.cat([wk[0], wv[0], wk[1], wv[1]]), torch.cat([torch.zeros(D, device="cuda"), bv[0], torch.zeros(D, device="cuda"), bv[1]])
+    kv = ops.gemm(x.view(t_n * n, D), wkv, bkv).view(t_n, n, 4, D)
+    o2 = torch.empty((t_n, l, 2, D), dtype=dtype, device="cuda")
+    ops.attention(q.view(2, t_n, l, D).permute(1, 0, 2, 3), kv[:, :, 0::2].permute(0, 2, 1, 3), kv[:, :, 1::2].permute(0, 2, 1, 3), o2.permute(0, 2, 1, 3), 0.125)
+    assert (out.float() - o2.float()).abs().max().item() < (3e-2 if dtype == torch.bfloat16 else 4e-3)
