@@ -29,6 +29,13 @@ def _setup(dtype, fixture="train_imgtune.npz"):
     z = H.load(fixture)
     g, v = H.geometry(json.loads(str(z["bert_cfg"])), json.loads(str(z["vit_cfg"])))
     m2, sd2 = build(g, v, int(z["seed"]), str(z["profile"]), dtype)
+    if "cls_bias_shift" in z.files:          # the fixture margin-separates cls_head's ReLU pre-activations: a 768-float shift of cls_head.0.bias
+        shift = torch.from_numpy(z["cls_bias_shift"])
+        sd2 = dict(sd2)
+        sd2["cls_head.0.bias"] = sd2["cls_head.0.bias"] - shift
+        with torch.no_grad():
+            dict(m2.named_parameters())["cls_head.0.bias"].sub_(shift.to(m2.device))
+        m2._engines = None
     images = synthetic.scene_images(z["image_ids"].tolist(), v.image_size)
     return z, g, v, m2, sd2, images
 
@@ -61,7 +68,7 @@ def test_vit_fine_tuning_step_matches_reference(cuda, dtype, fixture):
         pre = torch.from_numpy(z["cls_pre"])
         flip = m2._trainer.head_mask().cpu() != (pre > 0)
         flips = int(flip.sum())
-        assert flips == 0 or float(pre[flip].abs().max()) < 4 * LOGIT_ABS[dtype], (flips, float(pre[flip].abs().max()))
+        assert flips == 0, (flips, float(pre[flip].abs().max()))             # margin-separated (smallest |pre-activation| 0.038): no unit changes side
     gmax = float(z["norms"].max())
     worst, num, den = (0.0, ""), 0.0, 0.0
     for i, n in enumerate(names):
@@ -77,7 +84,12 @@ def test_vit_fine_tuning_step_matches_reference(cuda, dtype, fixture):
     print(f"\n[{fixture[:-4]} {dtype}] tokens {e_f:.3e}  logits {e_log:.3e}  loss {loss.item():.5f} vs {float(z['loss']):.5f}  worst grad rel {worst[0]:.3e} "
           f"({worst[1]})  norm-weighted mean {num / den:.3e}" + ("" if flips is None else f"  ReLU units flipped against the reference: {flips} of {z['cls_pre'].size}"))
     assert e_f < FEATS_ABS[dtype] and e_log < 2 * LOGIT_ABS[dtype] and abs(loss.item() - float(z["loss"])) < 2 * LOGIT_ABS[dtype]
-    assert worst[0] < GOLDEN_REL[dtype] and num / den < GOLDEN_REL_MEAN[dtype]
+    if flips == 0:
+        # no ReLU unit on the other side of zero than in the reference: the comparison with the REFERENCE'S OWN gradients is a statement about the
+        # backward arithmetic again - the round-3 bounds (the round-4 review: "return GOLDEN_REL to <= 0.15 bf16 / 0.03 fp16")
+        assert worst[0] < (0.15 if dtype == BF else 0.03) and num / den < (0.04 if dtype == BF else 0.008), (worst, num / den)
+    else:
+        assert worst[0] < GOLDEN_REL[dtype] and num / den < GOLDEN_REL_MEAN[dtype]
     # the backward arithmetic proper: autograd of the oracle (ViT included) on the ReLU piece this forward took, full tensors
     from oracle import cir_oracle as O
     w = {k: t.clone().float() for k, t in sd2.items()}
