@@ -21,8 +21,7 @@
 // Bound: MFMA.  20 736 MFMAs (16x16x32) per workgroup = 83 k cycles per CU at one MFMA per 16 cycles and SIMD; operand traffic from L2
 // ~3.9 MB per workgroup (W_k^T, W_v: 1.33 x 1.18 MB each - neighbouring waves share a head -, X twice).
 
-#include "common.hpp"
-#include "gemm_args.hpp"
+#include "xattn_fold.hpp"
 
 #ifndef FOLD_DBG
 #define FOLD_DBG 0      // diagnostic builds only (make folddbg; timing, wrong results): 1 no weight re-loads, 2 no LDS fragment re-reads, 4 no DMA / barriers after the first chunk
@@ -41,41 +40,6 @@ __device__ unsigned long long g_fold_stamps[8 * 64];        // [workgroup < 4][w
 #else
 #define FOLD_STAMP(K) do {} while (0)
 #endif
-
-struct FoldArgs {
-    const void* q; int64_t q_sb, q_rs;          // element (branch b, row t L + tok, col) at q + b q_sb + row q_rs + col
-    const void* x; int64_t x_s1;                // tokens (T, N, 768), rows contiguous
-    const void* wkt; const void* wvp; int64_t w_sb;   // W_k^T (2, 768 f, 768 (h, d)); W_v (2, 768 (h, d), 768 f permuted)
-    const float* bv;                            // (2, 768)
-    void* out; int64_t o_st, o_sr, o_sb;        // element (t, tok, b, col) at out + t o_st + tok o_sr + b o_sb + col
-    int T, L, N;
-    float scale;
-};
-
-typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr_f;
-constexpr int kFoldD = 768, kFoldChunks = 12, kFoldKB = 14;      // width, 64-feature chunks, 16-key blocks (224 keys)
-constexpr int kFoldBuf = 2560 * 16;                              // one X-chunk buffer: 2560 16-byte slots (phase 2: 224 rows x 10 slots + slack)
-constexpr int kStride2 = 160;                                    // phase 2's LDS row stride: conflict-free transposing reads
-constexpr int kStrideQ = 1568;                                   // q rows in LDS (1536 B + 32: the 16-lane groups of ds_read_b128 hit 64 distinct banks)
-
-// LDS-DMA piece through a buffer descriptor (buffer_load_dwordx4 ... lds): wave-uniform resource + uniform byte offset + the lane's 32-bit
-// byte offset.  A load hipcc COUNTS - its vmcnt waits for the weight fragments then leave younger DMA pieces in flight (behind an asm
-// piece every compiler wait degenerates to "everything", i.e. to the HBM latency of the chunk just requested)
-#define FOLD_DMA(RS, VOFF, SOFF, LDS_DST) __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lptr_t)(LDS_DST), 16, VOFF, SOFF, 0, 0)
-
-// 16-byte weight fragment through a buffer descriptor: wave-uniform base (SGPR resource) + uniform byte offset + the lane's 32-bit byte offset
-template <typename X8>
-__device__ __forceinline__ X8 wload(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-    return __builtin_bit_cast(X8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
-}
-
-template <typename T>
-__device__ __forceinline__ typename Elem<T>::x8 pack_acc2(const f32x4& lo, const f32x4& hi) {
-    typename Elem<T>::x8 r;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { r[j] = static_cast<T>(lo[j]); r[4 + j] = static_cast<T>(hi[j]); }
-    return r;
-}
 
 template <typename T>
 __global__ __launch_bounds__(512, 2) void xattn_fold_kernel(const FoldArgs a) {
@@ -414,7 +378,7 @@ extern "C" int cir_cross_attention_folded(const void* q, int64_t q_sb, int64_t q
     using namespace cir;
     CIR_CHECK_PTR(q); CIR_CHECK_PTR(x); CIR_CHECK_PTR(wkt); CIR_CHECK_PTR(wvp); CIR_CHECK_PTR(bv); CIR_CHECK_PTR(out);
     if (T <= 0 || L <= 0 || N <= 0) return CIR_EINVAL;
-    if (D != kFoldD || H != 12 || L > 32 || N > 16 * kFoldKB) return CIR_ESHAPE;
+    if (D != kFoldD || H != 12 || L > 32 || N > 608) return CIR_ESHAPE;
     if (dtype != CIR_BF16 && dtype != CIR_F16) return CIR_EDTYPE;
     if (!cir_aligned16(q) || !cir_aligned16(x) || !cir_aligned16(wkt) || !cir_aligned16(wvp) || !cir_aligned16(bv) || (reinterpret_cast<uintptr_t>(out) & 7) ||
         q_sb % 8 || q_rs % 8 || x_s1 % 8 || w_sb % 8 || o_st % 4 || o_sr % 4 || o_sb % 4)
@@ -424,6 +388,7 @@ extern "C" int cir_cross_attention_folded(const void* q, int64_t q_sb, int64_t q
     a.q = q; a.q_sb = q_sb; a.q_rs = q_rs; a.x = x; a.x_s1 = x_s1; a.wkt = wkt; a.wvp = wvp; a.w_sb = w_sb; a.bv = bv;
     a.out = out; a.o_st = o_st; a.o_sr = o_sr; a.o_sb = o_sb; a.T = T; a.L = L; a.N = N; a.scale = scale;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (N > 16 * kFoldKB) return launch_fold16(a, dtype, s);       // 225 .. 608 keys: the 16-rows-per-wave kernel (xattn_fold16.hip)
     const size_t lds = 2 * kFoldBuf + 32 * kStrideQ;
     dim3 grid((unsigned)(8 * ((T + 3) / 4))), block(512);
     if (dtype == CIR_BF16) {

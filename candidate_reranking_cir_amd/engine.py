@@ -236,7 +236,7 @@ class NlvrEngine:
                                                  # attention; the "exact" fp32 mode keeps the reference's order of operations)
         # Round 5: the OTHER layers' cross-attention with the K / V projections folded to the query side (cir_cross_attention_folded:
         # S = (q W_k) X^T, ctx = (P X) W_v^T + b_v - 614 instead of 969 MFLOP per candidate and layer, and no (T N, 4 D) K|V tensor).
-        # Taken when the geometry is the kernel's (D = Dv = 768, 12 heads, L <= 32, N <= 224: the 224-px benchmark geometry), no key
+        # Taken when the geometry is the kernels' (D = Dv = 768, 12 heads, L <= 32, N <= 608: 224 px and the reference's 384 px), no key
         # mask, no K/V bank; anything else keeps the projected path.
         self.fold_cross_kv = xdt != torch.float32 and geo.hidden_size == 768 and geo.encoder_width == 768 and geo.num_attention_heads == 12
         e = prefix + "embeddings."
@@ -409,7 +409,7 @@ class NlvrEngine:
                     ops.gemm(q2[b].permute(1, 0, 2), f["wkt"][b], None, out=qp[:, b * h_n:(b + 1) * h_n, :].permute(1, 0, 2))
                 o = ops.cls_cross_attention(tok, qp, scale, x_index=None if kv_bank is None else cand_rows)
                 ops.gemm(o[:, :2 * h_n, :].permute(1, 0, 2), f["wv"], f["bv"], out=ccl.view(t_n, 2 * h_n, 64).permute(1, 0, 2))
-            elif (kv_bank is None and self.fold_cross_kv and "wkt" in ly and emask is None and not cls_only and l <= 32 and n <= 224
+            elif (kv_bank is None and self.fold_cross_kv and "wkt" in ly and emask is None and not cls_only and l <= 32 and n <= 608
                   and cand16.shape[2] == d):
                 ops.cross_attention_folded(qraw, cand16, ly["wkt"], ly["wvp"], ly["bvf"], ccl, l, scale, heads=geo.num_attention_heads)
             elif kv_bank is None:

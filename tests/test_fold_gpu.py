@@ -36,7 +36,7 @@ def _reference(q, x, wk, bk, wv, bv, l):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
-@pytest.mark.parametrize("t_n,l,n", [(3, 32, 197), (5, 11, 197), (2, 32, 224), (4, 1, 50), (2, 17, 17)])
+@pytest.mark.parametrize("t_n,l,n", [(3, 32, 197), (5, 11, 197), (2, 32, 224), (4, 1, 50), (2, 17, 17), (2, 32, 577), (3, 9, 300), (1, 32, 608), (5, 30, 225)])
 def test_folded_cross_attention_against_fp64_and_projected_path(ops, dtype, t_n, l, n):
     q = _rand((2, t_n * l, D), 1.0, 1, dtype)
     x = _rand((t_n, n, D), 1.0, 2, dtype)
@@ -79,10 +79,11 @@ def test_folded_cross_attention_exact_small_integers(ops):
     assert err < 0.13          # sums of ~50 terms up to ~100: one fp16 ulp there is 0.06 (P X is exact, the row sum of P rounds)
 
 
-def test_folded_cross_attention_scores_follow_the_keys(ops):
+@pytest.mark.parametrize("n", [197, 577])
+def test_folded_cross_attention_scores_follow_the_keys(ops, n):
     """One-hot attention: with a huge score on one key the output must be THAT key's projected value - exercises G1 / G2's k-slot maps and the
     key-block layout of the softmax, per head (each head is steered to a different key)."""
-    t_n, l, n = 1, 32, 197
+    t_n, l = 1, 32
     x = _rand((t_n, n, D), 1.0, 7, torch.float16)
     wk = _rand((2, D, D), 0.05, 8, torch.float16)
     wv = _rand((2, D, D), 0.03, 9, torch.float16)
@@ -112,6 +113,6 @@ def test_folded_cross_attention_rejects_other_geometries(ops):
     w, bv = torch.zeros((2, D, D), dtype=torch.float16, device="cuda"), torch.zeros((2, D), device="cuda")
     with pytest.raises(CirrankError):       # L > 32
         ops.cross_attention_folded(q, x, w, w, bv, torch.empty((2, 40, 2, D), dtype=torch.float16, device="cuda"), 40, 0.125)
-    x2 = torch.zeros((2, 577, D), dtype=torch.float16, device="cuda")
-    with pytest.raises(CirrankError):       # N > 224 (the 384-px geometry keeps the projected path)
+    x2 = torch.zeros((2, 609, D), dtype=torch.float16, device="cuda")
+    with pytest.raises(CirrankError):       # N > 608 keeps the projected path (577 tokens - the 384-px geometry - run on the 16-rows-per-wave kernel)
         ops.cross_attention_folded(q[:, :64], x2, w, w, bv, torch.empty((2, 32, 2, D), dtype=torch.float16, device="cuda"), 32, 0.125)

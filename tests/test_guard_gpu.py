@@ -347,7 +347,7 @@ def test_attention_f32_guard_bands(ops, b1, h, lq, lk):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "fp16"])
-@pytest.mark.parametrize("t_n,l,n", [(3, 32, 197), (5, 7, 197), (2, 31, 224), (9, 1, 33)])
+@pytest.mark.parametrize("t_n,l,n", [(3, 32, 197), (5, 7, 197), (2, 31, 224), (9, 1, 33), (2, 32, 577), (5, 13, 401)])
 def test_folded_cross_attention_guard_bands(ops, dtype, t_n, l, n):
     """xattn_fold_kernel writes token rows < L of a (T, L, 2, 768) tensor from 48-row wave tiles (rows beyond L are computed on zero queries and
     must not be stored), reads X rows clamped to N - 1 and weight fragments through buffer descriptors: output inside canaries, and the
@@ -368,4 +368,4 @@ def test_folded_cross_attention_guard_bands(ops, dtype, t_n, l, n):
     kv = ops.gemm(x.view(t_n * n, D), wkv, bkv).view(t_n, n, 4, D)
     o2 = torch.empty((t_n, l, 2, D), dtype=dtype, device="cuda")
     ops.attention(q.view(2, t_n, l, D).permute(1, 0, 2, 3), kv[:, :, 0::2].permute(0, 2, 1, 3), kv[:, :, 1::2].permute(0, 2, 1, 3), o2.permute(0, 2, 1, 3), 0.125)
-    assert (out.float() - o2.float()).abs().max().item() < (3e-2 if dtype == torch.bfloat16 else 4e-3)
+    assert (out.float() - o2.float()).abs().max().item() < (6.5e-2 if dtype == torch.bfloat16 else 4e-3)     # (two roundings: up to two bf16 ulps of 2^-5 at |ctx| ~ 4)
