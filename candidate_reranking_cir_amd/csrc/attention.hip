@@ -286,9 +286,40 @@ __global__ __launch_bounds__(1024) void attn_shared_kernel(const AttnArgs a, int
             softmax_tile<T, MASKED>(st, s, sl, mp, key0, hh, a.Lk, pf);
             pv_tile<T>(st, vt_base, voff, pf);
         }
-        if (q0 + r < a.Lq) {
-            T* op = reinterpret_cast<T*>(a.out) + b1 * a.o_s1 + b0 * a.o_s0 + (int64_t)(q0 + r) * a.o_rs + h * 64 + 4 * hh;
-            store_out<T>(st, op);
+        if (!a.wide_store) {             // several query tiles per wave (577 tokens), odd alignments: direct stores - 8-byte pieces, 32 rows per instruction
+            if (q0 + r < a.Lq) {
+                T* op = reinterpret_cast<T*>(a.out) + b1 * a.o_s1 + b0 * a.o_s0 + (int64_t)(q0 + r) * a.o_rs + h * 64 + 4 * hh;
+                store_out<T>(st, op);
+            }
+        } else {
+            // ONE tile per wave (197 tokens): the O tile goes out through LDS as WHOLE 128-byte rows (round 5).  The direct form writes a row's
+            // 128 bytes as 16 pieces of 8 bytes from two lanes - 8 store instructions per wave that each touch 32 rows, 256 partial-line
+            // requests where 32 full lines do; on the folded cross-attention kernel the CU's vector-memory request rate, not bytes or MFMAs,
+            // turned out to set the pace, and this kernel's life is load - compute - store with two workgroups per CU.  K / V are dead once
+            // every wave has finished its tile, so the tile (32 rows x 128 B, chunk position XOR (row & 7)) reuses their LDS.
+            __syncthreads();
+            char* ot = dyn + wave * 4096;
+            const float inv = 1.0f / st.l_run;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    u32x2 p;
+                    p.x = pack2<T>(st.o[dt][qd * 4 + 0] * inv, st.o[dt][qd * 4 + 1] * inv);
+                    p.y = pack2<T>(st.o[dt][qd * 4 + 2] * inv, st.o[dt][qd * 4 + 3] * inv);
+                    const int col = dt * 32 + 8 * qd + 4 * hh;                      // first of this piece's 4 features
+                    *reinterpret_cast<u32x2*>(ot + r * 128 + ((((col >> 3) ^ (r & 7)) << 4) | ((col & 7) << 1))) = p;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            T* ob = reinterpret_cast<T*>(a.out) + b1 * a.o_s1 + b0 * a.o_s0 + h * 64;
+            const int ch = lane & 7;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (lane >> 3) + 8 * i;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(ot + row * 128 + ((ch ^ (row & 7)) << 4));
+                if (q0 + row < a.Lq) *reinterpret_cast<u32x4*>(ob + (int64_t)(q0 + row) * a.o_rs + ch * 8) = v;
+            }
         }
     }
 }
@@ -544,6 +575,7 @@ extern "C" int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t 
     a.B0 = B0; a.H = H; a.Lq = Lq; a.Lk = Lk; a.nqt = (Lq + 31) / 32;
     a.total = (int64_t)B1 * B0 * H * a.nqt;
     a.scale = scale;
+    a.wide_store = 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == CIR_F32) return launch_attention_f32(a, s);      // "exact" mode: fp32 operands in both products (attention_f32.hip)
     const int lk_pad = (Lk + 31) & ~31;
@@ -559,6 +591,9 @@ extern "C" int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t 
         const int waves = (a.nqt + rounds - 1) / rounds;
         dim3 grid((unsigned)nblk), block(waves * 64);
         const size_t lds = (size_t)lk_pad * 256;
+        // whole-row output stores through the (then dead) K / V region: exactly one tile per wave (every wave reaches the barrier once),
+        // 16-byte-aligned output rows, 4 KiB of LDS per wave
+        a.wide_store = rounds == 1 && waves == a.nqt && (size_t)waves * 4096 <= lds && cir_aligned16(out) && o_s1 % 8 == 0 && o_s0 % 8 == 0 && o_rs % 8 == 0;
         const bool bf = dtype == CIR_BF16, mk = mask != nullptr;
         const void* fn = bf ? (mk ? reinterpret_cast<const void*>(&attn_shared_kernel<__bf16, true>) : reinterpret_cast<const void*>(&attn_shared_kernel<__bf16, false>))
                             : (mk ? reinterpret_cast<const void*>(&attn_shared_kernel<_Float16, true>) : reinterpret_cast<const void*>(&attn_shared_kernel<_Float16, false>));

@@ -12,6 +12,7 @@ struct AttnArgs {
     const int64_t* kv_index;   // optional: item b1 reads K/V of bank row kv_index[b1] (cross-query K/V cache)
     void* out; int64_t o_s1, o_s0, o_rs;
     int B0, H, Lq, Lk, nqt;
+    int wide_store;            // attn_shared_kernel: one tile per wave, 16-byte-aligned output rows and room in LDS -> whole-row stores through LDS
     int64_t total;
     float scale;
 };
