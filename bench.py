@@ -566,7 +566,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--queries", type=int, default=64, help="queries per step per GPU (one stage-II batch; the ViT runs in chunks of <= 2048 images)")
+    ap.add_argument("--queries", type=int, default=64, help="queries per step per GPU (one stage-II batch; the ViT runs in chunks of <= 4096 images)")
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--subset", type=int, default=5, help="CIRR subset members scored per query besides the K candidates (0: FashionIQ style)")
     ap.add_argument("--skip-rate", type=float, default=0.0, help="fraction of queries without a positive in their top-K (skip rule)")

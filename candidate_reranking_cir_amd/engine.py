@@ -88,7 +88,7 @@ class VitEngine:
                 w2=_w16(sd[b + "mlp.fc2.weight"], dtype, device), c2=_f32(sd[b + "mlp.fc2.bias"], device)))
         self.gf, self.bf = _f32(sd[p + "norm.weight"], device), _f32(sd[p + "norm.bias"], device)
 
-    def forward(self, image: torch.Tensor, want32: bool = False, chunk: int = 2048, out32: Optional[torch.Tensor] = None,
+    def forward(self, image: torch.Tensor, want32: bool = False, chunk: int = 4096, out32: Optional[torch.Tensor] = None,
                 out16: Optional[torch.Tensor] = None):
         """(B,3,H,W) fp32/16-bit -> tokens (B, N, D): 16-bit always, fp32 too if `want32`.  `out32` / `out16`: write the
         tokens there (contiguous (B, N, D) tensors) - the chunked path hands each chunk its slice of ONE result tensor, so
