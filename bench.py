@@ -639,6 +639,9 @@ def main():
     args.stream_dtype = stream_name(m2)                                              # what the run actually used
     dt = m2.token_dtype                                                              # 16-bit type of pixels / image tokens in HBM
     m2.engines(); m1.engines()
+    if os.environ.get("CIR_VIT_LNFOLD") in ("0", "1", "2"):             # A/B runs only: LayerNorm folded into the ViT's qkv (1) / qkv + fc1 (2) GEMMs
+        for v in (m2.engines()[0], m1.engines()[1]):                    # the two ViT engines (stage II's and stage I's)
+            v.ln_fold = min(int(os.environ["CIR_VIT_LNFOLD"]), 2 if "qkv_f" in v.blocks[0] else 0)
     if os.environ.get("CIR_FOLD_CROSS") in ("0", "1"):                  # A/B runs only: the query-side fold of the cross-attention K / V projections
         m2.engines()[1].fold_cross_kv = os.environ["CIR_FOLD_CROSS"] == "1"
 

@@ -319,3 +319,27 @@ extern "C" int cir_gemm_bias_act(const void* A, int64_t lda, int64_t strideA, co
 #undef CIR_LAUNCH128
     CIR_LAUNCH_RESULT();
 }
+
+extern "C" int cir_gemm_ln_bias_act(const void* X, int64_t ldx, const void* Wg, int64_t ldw, const float* colsum, const float* bias,
+                                    void* C, int64_t ldc, int64_t M, int N, int K, float eps, int act, int dtype, void* stream) {
+    using namespace cir;
+    CIR_CHECK_PTR(X); CIR_CHECK_PTR(Wg); CIR_CHECK_PTR(colsum); CIR_CHECK_PTR(bias); CIR_CHECK_PTR(C);
+    if (M <= 0 || N <= 0 || K <= 0 || !(eps > 0.f)) return CIR_EINVAL;
+    if (dtype != CIR_F16) return CIR_EDTYPE;                 // the rows ARE the fp16 residual stream: no bf16 / fp32 form
+    if (act != CIR_ACT_NONE && act != CIR_ACT_GELU) return CIR_EINVAL;
+    if (K % 128 != 0 || N % 16 != 0 || N < 64) return CIR_ESHAPE;   // K-tile pairs of the 256 x 256 kernel; whole 64-feature wave columns
+    if (ldx >= (1 << 21) || ldw >= (1 << 21)) return CIR_ESHAPE;
+    if (!cir_aligned16(X) || !cir_aligned16(Wg) || !cir_aligned16(C) || !cir_aligned16(colsum) || !cir_aligned16(bias) || ldx % 8 || ldw % 8 || ldc % 8)
+        return CIR_EALIGN;
+    GemmArgs a;
+    a.A = X; a.lda = ldx; a.sA = 0;
+    a.W = Wg; a.ldw = ldw; a.sW = 0;
+    a.bias = bias; a.sBias = 0;
+    a.R = nullptr; a.ldr = 0; a.sR = 0;
+    a.C = C; a.ldc = ldc; a.sC = 0;
+    a.M = M; a.N = N; a.K = K; a.batch = 1; a.act = act; a.group_w = 1; a.dbg = 0;
+    a.colsum = colsum; a.ln_eps = eps;
+    if (((M + 255) / 256) * (int64_t)((N + 255) / 256) > 0x7fffffff) return CIR_ESHAPE;
+    launch_gemm256(a, CIR_F16, 3, reinterpret_cast<hipStream_t>(stream));
+    CIR_LAUNCH_RESULT();
+}

@@ -90,10 +90,18 @@ constexpr int kDbuf = 4 * kHalf;   // A0 A1 B0 B1
 // built first: 495 us instead of 432 us on the ViT proj shape - its 8 passes each wait on the LDS round trip.)
 // ACT: the activation as a compile-time constant (CIR_ACT_NONE / CIR_ACT_GELU: the two the path runs at scale), or -1 = read
 // a.act at run time (a branch and a register copy per 8 outputs; kept for the rarely used combinations).
-template <typename T, bool OUT_F32, bool HAS_RES, typename ST = float, int ACT = -1>
+// LNF ("LayerNorm folded", round 5): A holds the RAW residual-stream rows x (K = the whole row), W the weight with the LayerNorm gain
+// folded in (W' = W diag(gamma)), bias b' = b + W beta, colsum s_n = sum_k W'[n,k]:
+//     C = act( rstd_m * (x W'^T - mean_m * s) + b' )  =  act( LayerNorm(x) W^T + b )
+// The row statistics come out of the main loop itself: the activation fragments a wave feeds to the MFMA pass through two
+// v_dot2_f32_f16 per dword (sum and sum of squares in fp32; the four waves that hold the same 64 rows take one 16-row block each =
+// 16 VALU ops per phase, in the issue gaps behind the MFMAs), are reduced over the four k-groups of lanes at the end of the tile and
+// exchanged through LDS.  No LayerNorm pass, no normalised copy of x in HBM (vit.py:107-109: norm1 / norm2 of every block).
+template <typename T, bool OUT_F32, bool HAS_RES, typename ST = float, int ACT = -1, bool LNF = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     constexpr bool FAST16 = !__is_same(ST, float);        // 16-bit residual-stream output (and residual)
     static_assert(!(FAST16 && OUT_F32), "the stream type is written by the 16-bit epilogue");
+    static_assert(!LNF || (__is_same(T, _Float16) && !OUT_F32 && !HAS_RES && !FAST16), "LNF: fp16 stream rows in, operand-type C out");
     using OT = typename std::conditional<FAST16, ST, T>::type;   // element type the 16-bit epilogue packs to
     using X8 = typename Elem<T>::x8;
     __shared__ __attribute__((aligned(16))) char smem[2 * kDbuf + 8 * 1024 + 4 * 4096];   // two K-tiles + a 1-KiB bias slot per wave + epilogue staging for waves 4-7
@@ -234,6 +242,38 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     MM4(MH, 0) PLACE(P0) MM4(MH, 4) MM(MH, 8) PLACE(P1) MM(MH, 9) MM(MH, 10) MM(MH, 11) MM4(MH, 12) PLACE(P2)            \
     MM4(MH, 16) MM(MH, 20) PLACE(P3) MM(MH, 21) MM(MH, 22) MM(MH, 23) MM(MH, 24) PLACE(P4) MM(MH, 25) MM(MH, 26)         \
     MM(MH, 27) MM(MH, 28) PLACE(P5) MM(MH, 29) MM(MH, 30) MM(MH, 31)
+// LNF: row statistics.  The four waves of a row group hold the same 64 rows; each takes one 16-row block (its column index wc) and
+// reads that block's two fragments of the K-tile a SECOND time into registers of their own (sf) - a wave-dependent choice among the
+// af registers is either a branch chain in the MFMA stream (measured: +29 % kernel time, and the compiler's merge of the arms lost
+// terms) or 24 selects per phase; the two extra ds_read_b128 per phase (18 / 10 instead of 16 / 8) measured free.  Per phase 32
+// v_fma_mix_f32 (fp16 sources, fp32 accumulators: sum += x * 1.0, sumsq += x * x per element) in the READ segment of the phase, behind
+// the issue of the phase's LDS reads, where they run under the OTHER wave group's MFMA segment: ~6 % of the kernel's time (8 % with the
+// GELU epilogue); the arrangement is what made them affordable at all - 16 v_dot2c_f32_f16 (two elements per op) cost +146 cycles per
+// phase between this wave's own MFMAs and +177 in the read segment (dependent 2-pass ops), and four independent dot2c chains spill.
+// (inline asm, volatile: left to the compiler the ops of four phases were sunk into one block of 64 behind copies of the fragments)
+[[maybe_unused]] float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
+[[maybe_unused]] X8 sf[2];
+[[maybe_unused]] const char* const s_rd = a_rd + wc * 2048;
+#define READ_S(H, DB)                                                                                  \
+    if constexpr (LNF) {   /* asm: issued FIRST and waited for with a COUNTED lgkmcnt (NY younger reads may stay in flight) */ \
+        const unsigned s0_ = (unsigned)(size_t)(lptr_t)(s_rd + (DB) * kDbuf + (H) * kHalf + c0);       \
+        const unsigned s1_ = (unsigned)(size_t)(lptr_t)(s_rd + (DB) * kDbuf + (H) * kHalf + c1);       \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(sf[0]), "=&v"(sf[1]) : "v"(s0_), "v"(s1_)); \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    }
+#define ST1(MH, D)                                                                                     \
+    { const unsigned d_ = __builtin_bit_cast(u32x4, sf[(D) >> 2])[(D) & 3];                            \
+      asm volatile("v_fma_mix_f32 %0, %2, 1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, %2, %1 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t" \
+                   "v_fma_mix_f32 %0, %2, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, %2, %1 op_sel:[1,1,0] op_sel_hi:[1,1,0]" \
+                   : "+v"(ssum[MH]), "+v"(ssq[MH]) : "v"(d_)); }
+#define STATS(MH, NY)   /* NY = ds_read_b128 the compiler issued between READ_S and here */          \
+    if constexpr (LNF) {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(NY) : "memory");                                   \
+        ST1(MH, 0) ST1(MH, 1) ST1(MH, 2) ST1(MH, 3) ST1(MH, 4) ST1(MH, 5) ST1(MH, 6) ST1(MH, 7)        \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    }
 #define COMPUTE(MH, NDMA, P0, P1, P2, P3, P4, P5) \
     SYNC();                                      \
     __builtin_amdgcn_s_setprio(1);               \
@@ -264,8 +304,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     // bias of the tile arrives by LDS-DMA into a private 1-KiB slot per wave (no VGPR-destination loads on the
     // tile boundary: the compiler would answer those with vmcnt(0), which also waits for the previous tile's stores)
     char* const bias_slot = smem + 2 * kDbuf + wave * 1024;
+// LNF: the slot holds the wave's OWN 64 features of b' (lanes 0-15 -> bytes 0-255) and of the column sums s (lanes 16-31 ->
+// bytes 256-511); bytes 512-767 are the wave's page of the row-statistics exchange (lanes 32-63 stay masked off).  Both vectors are
+// consumed at the HEAD of the epilogue (before the next tile's request overwrites them), not at the head of the tile.
 #define ISSUE_BIAS()                                                                                                   \
-    if (a.bias != nullptr) {                                                                                           \
+    if constexpr (LNF) {                                                                                               \
+        int ln_ = lane;                                                                                                \
+        asm volatile("" : "+v"(ln_));   /* recomputed per tile: hoisted out of the tile loop these lane values spilled */ \
+        int nm4_ = __builtin_amdgcn_readfirstlane(a.N - 4);                                                            \
+        asm volatile("" : "+s"(nm4_));   /* (as a hoisted VGPR copy this scalar spilled: its reload is a vmcnt(0)) */     \
+        if (ln_ < 32) {                                                                                                \
+            const int bn = min(n0 + wc * 64 + (ln_ & 15) * 4, nm4_);                                                   \
+            const float* src_ = (ln_ & 16) ? a.colsum : a.bias;                                                        \
+            __builtin_amdgcn_global_load_lds((gptr_t)(src_ + bn), (lptr_t)(bias_slot), 16, 0, 0);                      \
+        }                                                                                                              \
+    } else if (a.bias != nullptr) {                                                                                    \
         int bn = n0 + lane * 4;                                                                                        \
         bn = bn + 4 <= a.N ? bn : a.N - 4;   /* clamped lanes feed features whose outputs are never stored */          \
         __builtin_amdgcn_global_load_lds((gptr_t)(a.bias + z * a.sBias + bn), (lptr_t)(bias_slot), 16, 0, 0);         \
@@ -303,7 +356,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         //  around it grew by more; 72.9 against 72.5 ms of GEMM time per step.)
         {
             float bias[2][8];
-            if (a.bias != nullptr) {
+            if constexpr (LNF) {   // b' joins in the epilogue, behind the row scale
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { bias[0][q] = 0.f; bias[1][q] = 0.f; }
+                ssum[0] = ssum[1] = ssq[0] = ssq[1] = 0.f;
+            } else if (a.bias != nullptr) {
                 // LDS reads hidden from the compiler's wait-count pass: it would put vmcnt(0) in front of a ds_read of
                 // DMA-written LDS.  Loads and their lgkmcnt wait live in ONE statement (outputs early-clobber).
                 f32x4 b00, b01, b10, b11;
@@ -345,16 +402,45 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         // K-tile T0 from dbuf 0 (phases 1-4) / T1 = T0+1 from dbuf 1 (phases 5-8); refills: see the schedule at the top.
         // PA1 / PA2,PW2 / PA3,PW3: wave-uniform base pointers of K-tiles T0+1, T0+2, T0+3 (computed outside: no
         // selects or branches between the MFMAs).
+        // LNF: the row statistics are complete once the last phase's fragments have been added, i.e. in the READ segment of the tile's
+        // last phase.  There - under the other wave group's MFMA segment - they are summed over the four k-groups of lanes and
+        // (rstd, -rstd * mean) of this wave's two 16-row blocks go to its page of the exchange; the two barriers of that phase (and
+        // the trailing one of the staggered group) order the writes before any wave's epilogue reads: no barrier of their own.
+        // (A barrier + this block at the head of the epilogue: +1.7 k cycles per tile.)
+        // Cross-lane sum over lanes l, l ^ 16, l ^ 32, l ^ 48 with the gfx950 row / half swaps: copy, swap the upper half (odd rows)
+        // of one copy with the lower half (even rows) of the other, add - plain VALU, where __shfl_xor is two dependent round trips
+        // through the LDS crossbar.  (asm: with both operands the same value the builtin's two results were folded into one -
+        // v_add v1, v1, v1; wait states by hand, the hazard recogniser does not look inside)
+#define PUBLISH_STATS()                                                                                                      \
+        if constexpr (LNF) {                                                                                                 \
+            const float inv_k = 1.0f / (float)a.K;                                                                           \
+            int lp_ = lane;                                                                                                  \
+            asm volatile("" : "+v"(lp_));                                                                                    \
+            const unsigned xw = (unsigned)(size_t)(lptr_t)(bias_slot) + 512 + (lp_ & 15) * 8;                                \
+            _Pragma("unroll") for (int mh = 0; mh < 2; ++mh) {                                                               \
+                float sx = ssum[mh], sq = ssq[mh], t0, t1;                                                                   \
+                asm volatile("v_mov_b32 %2, %0\n\tv_mov_b32 %3, %1\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1\n\t" \
+                             "v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3\n\tv_mov_b32 %2, %0\n\tv_mov_b32 %3, %1\n\ts_nop 1\n\t"           \
+                             "v_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\ts_nop 1\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3" \
+                             : "+v"(sx), "+v"(sq), "=&v"(t0), "=&v"(t1));                                                    \
+                const float mean = sx * inv_k;                                                                               \
+                const float var = fmaxf(fmaf(sq, inv_k, -mean * mean), 0.f);                                                 \
+                const float rstd = __builtin_amdgcn_rsqf(var + a.ln_eps);   /* v_rsq_f32: 1 ulp, far inside the fp16 output's rounding */ \
+                const f32x2 st = {rstd, -rstd * mean};                                                                       \
+                if (lp_ < 16) asm volatile("ds_write_b64 %0, %1" :: "v"(xw + mh * 128), "v"(st) : "memory");                 \
+            }                                                                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                                               \
+        }
 #define KTILE_D0(PA1, PA2, PW2)                                                                                         \
-        READ_B(0, 0) READ_A(0, 0) READ_B(1, 0) WAIT_PRO(6)                                                               \
+        READ_S(0, 0) READ_B(0, 0) READ_A(0, 0) STATS(0, 12) READ_B(1, 0) WAIT_PRO(6)                                                               \
             COMPUTE(0, 2, PIECE_A(1, 1, PA1, 0), PIECE_A(1, 1, PA1, 1), , , , )                         /* phase a0 */   \
-        READ_A(1, 0) WAIT_PRO(2)                                                                                        \
+        READ_S(1, 0) READ_A(1, 0) STATS(1, 8) WAIT_PRO(2)                                                                                        \
             COMPUTE(1, 6, PIECE_A(0, 0, PA2, 0), PIECE_B(0, 0, PW2, 0), PIECE_B(1, 0, PW2, 0),                           \
                     PIECE_A(0, 0, PA2, 1), PIECE_B(0, 0, PW2, 1), PIECE_B(1, 0, PW2, 1))                /* phase b0 */
-#define KTILE_D1(PA2, PA3, PW3)                                                                                         \
-        READ_B(0, 1) READ_A(0, 1) READ_B(1, 1) WAIT_A1()                                                                \
+#define KTILE_D1(PA2, PA3, PW3, HOOK)                                                                                         \
+        READ_S(0, 1) READ_B(0, 1) READ_A(0, 1) STATS(0, 12) READ_B(1, 1) WAIT_A1()                                                                \
             COMPUTE(0, 2, PIECE_A(1, 0, PA2, 0), PIECE_A(1, 0, PA2, 1), , , , )                         /* phase a1 */   \
-        READ_A(1, 1) WAIT_ABB()                                                                                         \
+        READ_S(1, 1) READ_A(1, 1) STATS(1, 8) HOOK WAIT_ABB()                                                                                         \
             COMPUTE(1, 6, PIECE_A(0, 1, PA3, 0), PIECE_B(0, 1, PW3, 0), PIECE_B(1, 1, PW3, 0),                           \
                     PIECE_A(0, 1, PA3, 1), PIECE_B(0, 1, PW3, 1), PIECE_B(1, 1, PW3, 1))                /* phase b1 */
         // K-tiles past the end of this tile: the next tile's first two when the seam streams, else this tile's last one
@@ -368,7 +454,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
             bool skip = true;                            // first K-tile pair of the tile (see WAIT_PRO)
             for (int it = 1; it < (nk >> 1); ++it) {     // all K-tile pairs but the last: refills stay inside the tile
                 KTILE_D0(pa + 128, pa + 256, pw + 256)
-                KTILE_D1(pa + 256, pa + 384, pw + 384)
+                KTILE_D1(pa + 256, pa + 384, pw + 384, )
                 pa += 256;
                 pw += 256;
                 skip = false;
@@ -376,7 +462,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
             }
             // last pair (the dispatcher sends only K % 128 == 0 here): its refills are the K-tiles past the end
             KTILE_D0(pa + 128, A_e0, W_e0)
-            KTILE_D1(A_e0, A_e1, W_e1)
+            KTILE_D1(A_e0, A_e1, W_e1, PUBLISH_STATS())
         }
         STAMP(4)
         if (wr == 0) { SYNC(); }   // pair the trailing barrier of the staggered group: all LDS reads of this tile are done
@@ -389,7 +475,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         constexpr int NPASS = 128 / ROWS;
         constexpr int ROWB = OUT_F32 ? 256 : 128;               // bytes of this wave's 64 features in one row
         constexpr int LPR = ROWB / 16;                          // lanes per row when reading back
-        const int rr = lane / LPR, sl = lane % LPR;
+        // (LNF: the epilogue's lane geometry is recomputed per tile - kept live across the K loop, next to the statistics registers, it spills)
+        int lane_e = lane;
+        if constexpr (LNF) asm volatile("" : "+v"(lane_e));
+        [[maybe_unused]] const int r15e = lane_e & 15, ge = lane_e >> 4;
+        const int rr = lane_e / LPR, sl = lane_e % LPR;
         const int ncol = cn0 + wc * 64 + sl * (OUT_F32 ? 4 : 8);
         // fp32 residual, fetched in the SAME row-contiguous layout the stores use (1 KiB = 4 rows x 256 B per
         // instruction, whole lines) RD passes ahead; loading it in the accumulator layout (16 rows x 32-byte pieces
@@ -410,6 +500,32 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         }
         _Pragma("unroll") for (int p = 0; p < RD; ++p) { LOAD_RES(p) }
         __builtin_amdgcn_sched_barrier(0);
+        // ---- LNF: fetch b', s and the statistics of all eight row blocks this wave stores (published in the tile's last read segment)
+        [[maybe_unused]] float lb[2][8], ls[2][8], lal[2][4], lnm[2][4];
+        if constexpr (LNF) {
+            const unsigned baddr = (unsigned)(size_t)(lptr_t)(bias_slot) + (unsigned)(ge * 32);
+            const unsigned xr = (unsigned)(size_t)(lptr_t)(smem + 2 * kDbuf + wr * 4096 + 512) + r15e * 8;
+            f32x4 b00, b01, b10, b11, s00, s01, s10, s11;
+            f32x2 t00, t01, t02, t03, t10, t11, t12, t13;
+            asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:128\n\t"
+                         "ds_read_b128 %3, %8 offset:144\n\tds_read_b128 %4, %8 offset:256\n\tds_read_b128 %5, %8 offset:272\n\t"
+                         "ds_read_b128 %6, %8 offset:384\n\tds_read_b128 %7, %8 offset:400\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(b00), "=&v"(b01), "=&v"(b10), "=&v"(b11), "=&v"(s00), "=&v"(s01), "=&v"(s10), "=&v"(s11)
+                         : "v"(baddr) : "memory");
+            asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:1024\n\tds_read_b64 %2, %8 offset:2048\n\t"
+                         "ds_read_b64 %3, %8 offset:3072\n\tds_read_b64 %4, %8 offset:128\n\tds_read_b64 %5, %8 offset:1152\n\t"
+                         "ds_read_b64 %6, %8 offset:2176\n\tds_read_b64 %7, %8 offset:3200\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(t00), "=&v"(t01), "=&v"(t02), "=&v"(t03), "=&v"(t10), "=&v"(t11), "=&v"(t12), "=&v"(t13)
+                         : "v"(xr) : "memory");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                lb[0][q] = b00[q]; lb[0][4 + q] = b01[q]; lb[1][q] = b10[q]; lb[1][4 + q] = b11[q];
+                ls[0][q] = s00[q]; ls[0][4 + q] = s01[q]; ls[1][q] = s10[q]; ls[1][4 + q] = s11[q];
+            }
+            lal[0][0] = t00.x; lnm[0][0] = t00.y; lal[0][1] = t01.x; lnm[0][1] = t01.y; lal[0][2] = t02.x; lnm[0][2] = t02.y; lal[0][3] = t03.x; lnm[0][3] = t03.y;
+            lal[1][0] = t10.x; lnm[1][0] = t10.y; lal[1][1] = t11.x; lnm[1][1] = t11.y; lal[1][2] = t12.x; lnm[1][2] = t12.y; lal[1][3] = t13.x; lnm[1][3] = t13.y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
 
         // ---- request the next tile's first K-tile (and bias) before this tile's epilogue ------------------------------
         if (more) {
@@ -420,6 +536,34 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
             ISSUE_BIAS()
         }
         __builtin_amdgcn_sched_barrier(0);
+        // ---- LNF: row scale, mean correction and b' applied to all 128 accumulators in one pass of their own (under the next tile's
+        //      operand requests): inside the store passes the 48 extra live values spilled, and a spill reload there is a vmcnt(0)
+        if constexpr (LNF) {
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                            for (int jp = 0; jp < 2; ++jp) {   // two outputs per v_pk_fma_f32
+                                const int q = ni * 4 + jp * 2;
+                                const f32x2 al2 = {lal[mh][mi], lal[mh][mi]}, nm2 = {lnm[mh][mi], lnm[mh][mi]};
+                                const f32x2 t2 = __builtin_elementwise_fma(nm2, f32x2{ls[nh][q], ls[nh][q + 1]}, f32x2{lb[nh][q], lb[nh][q + 1]});
+                                const f32x2 v2 = __builtin_elementwise_fma(al2, f32x2{acc[mh][mi][nh][ni][jp * 2], acc[mh][mi][nh][ni][jp * 2 + 1]}, t2);
+                                acc[mh][mi][nh][ni][jp * 2] = v2.x;
+                                acc[mh][mi][nh][ni][jp * 2 + 1] = v2.y;
+                            }
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh) { asm volatile("" : "+v"(acc[mh][mi][nh][0]), "+v"(acc[mh][mi][nh][1])); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         STAMP(6)
 
         // ---- epilogue: activation, pack, then ROW-CONTIGUOUS stores through a private LDS staging tile ---------------
@@ -434,8 +578,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
             const unsigned stg_addr = (unsigned)(size_t)(lptr_t)(stg);
             // 16-bit epilogue: tile-invariant lane addresses of the staging tile (write: row r15 (+16 by immediate), slot nh*4 + g;
             // read: row rr (+8 j by immediate), slot sl - both XOR-swizzled with the row) and of the output row (bytes)
-            [[maybe_unused]] const unsigned st_w0 = stg_addr + r15 * 128 + (((0 + g) ^ (r15 & 7)) << 4);
-            [[maybe_unused]] const unsigned st_w1 = stg_addr + r15 * 128 + (((4 + g) ^ (r15 & 7)) << 4);
+            [[maybe_unused]] const unsigned st_w0 = stg_addr + r15e * 128 + (((0 + ge) ^ (r15e & 7)) << 4);
+            [[maybe_unused]] const unsigned st_w1 = stg_addr + r15e * 128 + (((4 + ge) ^ (r15e & 7)) << 4);
             [[maybe_unused]] const unsigned st_rd = stg_addr + rr * 128 + ((sl ^ (rr & 7)) << 4);
             [[maybe_unused]] const unsigned st_voff = (unsigned)((rr * a.ldc + wc * 64 + sl * 8) * (int64_t)sizeof(OT));
             [[maybe_unused]] const char* const c_tile = reinterpret_cast<const char*>(a.C) + (cz * a.sC + (cm0 + wr * 64) * a.ldc + cn0) * (int64_t)sizeof(OT);
@@ -613,7 +757,8 @@ static int persistent_grid() {
 }
 
 void launch_gemm256(const GemmArgs& a_in, int in_dtype, int out_kind, hipStream_t s) {
-    // out_kind: 0 = 16-bit C in the operand type, 1 = fp32 C (and R), 2 = fp16 residual-stream C (and R)
+    // out_kind: 0 = 16-bit C in the operand type, 1 = fp32 C (and R), 2 = fp16 residual-stream C (and R);
+    // 3 = LayerNorm folded in (fp16 rows in, fp16 C; a.colsum / a.ln_eps set; act NONE or GELU)
     GemmArgs a = a_in;
     a.dbg = 0;
 #ifdef CIR_GEMM_STAMPS
@@ -639,6 +784,11 @@ void launch_gemm256(const GemmArgs& a_in, int in_dtype, int out_kind, hipStream_
     dim3 grid((unsigned)(ntiles < g ? ntiles : g)), block(512);
     const bool res = a.R != nullptr;
 #define CIR_LAUNCH256(...) hipLaunchKernelGGL((gemm256_kernel<__VA_ARGS__>), grid, block, 0, s, a)
+    if (out_kind == 3) {
+        if (a.act == CIR_ACT_GELU) CIR_LAUNCH256(_Float16, false, false, float, CIR_ACT_GELU, true);
+        else CIR_LAUNCH256(_Float16, false, false, float, CIR_ACT_NONE, true);
+        return;
+    }
     // the activation is a compile-time constant where the path runs at scale: operand-type C with none / GELU (QKV, K|V,
     // cross-Q / fc1), residual-stream C with none (proj, fc2, merge); every other combination reads a.act at run time
 #define CIR_DISPATCH256(T)                                                                                                     \

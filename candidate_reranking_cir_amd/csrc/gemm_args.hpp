@@ -13,6 +13,8 @@ struct GemmArgs {
     int64_t M; int N, K, batch, act, tiles_m, tiles_n;
     int dbg;       // diagnostic (stamped) build only: experiment switches from the environment; 0 in the shipped library
     int group_w;   // gemm256: tiles are walked in column groups of this many n-panels (weights stay L2-resident)
+    const float* colsum = nullptr;   // gemm256 with the LayerNorm folded in (out_kind 3): s_n = sum_k W'[n,k]
+    float ln_eps = 0.f;
 };
 
 typedef __attribute__((address_space(1))) const void* gptr_t;

@@ -29,6 +29,8 @@ from .config import BertGeometry, VitGeometry
 
 SD = Dict[str, torch.Tensor]
 
+LN_FOLD_DEFAULT = 1   # VitEngine.ln_fold where the geometry allows it (bench.py's CIR_VIT_LNFOLD overrides for A/B runs)
+
 
 def _w16(t: torch.Tensor, dtype, device) -> torch.Tensor:
     return t.detach().to(device=device, dtype=torch.float32).to(dtype).contiguous()
@@ -87,6 +89,16 @@ class VitEngine:
                 w1=_w16(sd[b + "mlp.fc1.weight"], dtype, device), c1=_f32(sd[b + "mlp.fc1.bias"], device),
                 w2=_w16(sd[b + "mlp.fc2.weight"], dtype, device), c2=_f32(sd[b + "mlp.fc2.bias"], device)))
         self.gf, self.bf = _f32(sd[p + "norm.weight"], device), _f32(sd[p + "norm.bias"], device)
+        # LayerNorm folded into the GEMM behind it (cir_gemm_ln_bias_act, round 5): the rows must BE the operand type (fp16 operands on
+        # the fp16 stream) and K a multiple of 128.  ln_fold: 0 off, 1 norm1 -> qkv, 2 also norm2 -> fc1 (measured: the fc1 GEMM with its
+        # GELU epilogue loses in the statistics what the dropped pass saves - DESIGN section 4).  Geometry decides, never the batch size.
+        self.ln_fold = 0
+        if dtype == torch.float16 and self.stream_dtype == torch.float16 and d % 128 == 0:
+            self.ln_fold = LN_FOLD_DEFAULT
+            for i, blk in enumerate(self.blocks):
+                b = f"{p}blocks.{i}."
+                blk["qkv_f"] = ops.ln_fold_pack(sd[b + "attn.qkv.weight"].to(device), sd[b + "attn.qkv.bias"].to(device), blk["g1"], blk["b1"])
+                blk["fc1_f"] = ops.ln_fold_pack(sd[b + "mlp.fc1.weight"].to(device), sd[b + "mlp.fc1.bias"].to(device), blk["g2"], blk["b2"])
 
     def forward(self, image: torch.Tensor, want32: bool = False, chunk: int = 4096, out32: Optional[torch.Tensor] = None,
                 out16: Optional[torch.Tensor] = None):
@@ -117,13 +129,19 @@ class VitEngine:
         x = ops.vit_assemble(proj, self.cls, self.pos, bsz).view(bsz * n, d)   # vit.py:184-187 (residual stream, sdt)
         ctx = torch.empty((bsz, n, d), dtype=dt, device=x.device)
         for blk in self.blocks:
-            _, xb = _ln(x, blk["g1"], blk["b1"], geo.layer_norm_eps, dt, sdt, need_stream=False)
-            qkv = ops.gemm(xb, blk["wqkv"], blk["bqkv"]).view(bsz, n, 3, d)    # vit.py:72
+            if self.ln_fold >= 1:
+                qkv = ops.gemm_ln(x, *blk["qkv_f"], geo.layer_norm_eps).view(bsz, n, 3, d)   # vit.py:107 + :72, no LayerNorm pass
+            else:
+                _, xb = _ln(x, blk["g1"], blk["b1"], geo.layer_norm_eps, dt, sdt, need_stream=False)
+                qkv = ops.gemm(xb, blk["wqkv"], blk["bqkv"]).view(bsz, n, 3, d)    # vit.py:72
             ops.attention(qkv[:, :, 0].unsqueeze(1), qkv[:, :, 1].unsqueeze(1), qkv[:, :, 2].unsqueeze(1),
                           ctx.unsqueeze(1), scale)                             # vit.py:73-83
             ops.gemm(ctx.view(bsz * n, d), blk["wo"], blk["bo"], residual=x, out_dtype=sdt, out=x)  # :84,:108
-            _, xb = _ln(x, blk["g2"], blk["b2"], geo.layer_norm_eps, dt, sdt, need_stream=False)
-            f = ops.gemm(xb, blk["w1"], blk["c1"], act=ops.ACT_GELU)           # vit.py:36-37
+            if self.ln_fold >= 2:
+                f = ops.gemm_ln(x, *blk["fc1_f"], geo.layer_norm_eps, act=ops.ACT_GELU)   # vit.py:109 + :36-37
+            else:
+                _, xb = _ln(x, blk["g2"], blk["b2"], geo.layer_norm_eps, dt, sdt, need_stream=False)
+                f = ops.gemm(xb, blk["w1"], blk["c1"], act=ops.ACT_GELU)       # vit.py:36-37
             ops.gemm(f, blk["w2"], blk["c2"], residual=x, out_dtype=sdt, out=x)  # vit.py:39, :109
         if dt == torch.float32:                                                # "exact" mode: one fp32 token tensor serves both roles
             o = out16 if out16 is not None else out32

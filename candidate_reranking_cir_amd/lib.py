@@ -30,6 +30,8 @@ SIGNATURES = {
     "cir_gemm_bias_act": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                                   c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                   c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "cir_gemm_ln_bias_act": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                                     c_int64, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "cir_layernorm": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
                               c_int64, c_int64, c_int, c_int, c_float, c_int, c_void_p]),
     "cir_attention": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,

@@ -115,6 +115,41 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+def ln_fold_pack(w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, dtype=torch.float16):
+    """Fold a LayerNorm's affine into the Linear behind it (cir_gemm_ln_bias_act): fp32 W (N,K), b (N), gamma / beta (K) ->
+    (Wg = W diag(gamma) in `dtype`, colsum of the ROUNDED Wg in fp32, b' = b + W beta in fp32)."""
+    w32, g32 = w.detach().float(), gamma.detach().float()
+    wg = (w32 * g32[None, :]).to(dtype).contiguous()
+    colsum = wg.double().sum(dim=1).float().contiguous()
+    bias = (b.detach().double() + w32.double() @ beta.detach().double()).float().contiguous()
+    return wg, colsum, bias
+
+
+def gemm_ln(x: torch.Tensor, wg: torch.Tensor, colsum: torch.Tensor, bias: torch.Tensor, eps: float, act: int = ACT_NONE,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act(LayerNorm(x) @ W.T + b) from the RAW fp16 stream rows x (M,K) and the packed (Wg, colsum, b') of `ln_fold_pack`:
+    statistics inside the GEMM, no LayerNorm pass (vit.py:107-109 + :72 / :36-37)."""
+    _need_cuda(x, wg, colsum, bias, out)
+    m, k = x.shape
+    n = wg.shape[0]
+    assert x.dtype == torch.float16 and wg.dtype == torch.float16 and x.stride(1) == 1 and wg.stride(1) == 1 and wg.shape[1] == k
+    assert colsum.dtype == torch.float32 and bias.dtype == torch.float32 and colsum.shape == (n,) and bias.shape == (n,)
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float16, device=x.device)
+    assert out.shape == (m, n) and out.dtype == torch.float16 and out.stride(1) == 1
+    if PROFILE_GEMM is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    code = _lib.load().cir_gemm_ln_bias_act(x.data_ptr(), x.stride(0), wg.data_ptr(), wg.stride(0), colsum.data_ptr(), bias.data_ptr(),
+                                            out.data_ptr(), out.stride(0), m, n, k, float(eps), act, CIR_F16, _stream())
+    if PROFILE_GEMM is not None:
+        ev1.record()
+        PROFILE_GEMM.append((2.0 * m * n * k, ev0, ev1, float((m * k + n * k + m * n) * 2 + n * 8),
+                             f"cir::gemm256_kernel<_Float16,false,false,float,{act},true>"))
+    _lib.check(code, "cir_gemm_ln_bias_act")
+    return out
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, residual: Optional[torch.Tensor] = None,
               out32: Optional[torch.Tensor] = None, out16: Optional[torch.Tensor] = None, want32: bool = True,
               dtype16: Optional[torch.dtype] = torch.bfloat16, stream_dtype: Optional[torch.dtype] = None):

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CIR_ABI_VERSION 11
+#define CIR_ABI_VERSION 12
 
 enum { CIR_BF16 = 0, CIR_F16 = 1, CIR_F32 = 2 };
 enum { CIR_ACT_NONE = 0, CIR_ACT_GELU = 1, CIR_ACT_RELU = 2 };
@@ -91,6 +91,21 @@ int cir_gemm_bias_act(const void* A, int64_t lda, int64_t strideA,
                       void* C, int64_t ldc, int64_t strideC,
                       int64_t M, int N, int K, int batch,
                       int act, int in_dtype, int out_dtype, void* stream);
+
+/*
+ * C = act(LayerNorm(X; gamma, beta, eps) * W^T + b) WITHOUT a LayerNorm pass (ABI v12): the GEMM reads the raw fp16 residual-stream
+ * rows X (M, K) (ldx; K = the whole normalised row) and the caller hands over the affine folded into the weight:
+ *     Wg (N, K) = W diag(gamma) rounded to fp16 (ldw),   colsum[n] = sum_k Wg[n,k] (fp32, of the ROUNDED values),
+ *     bias[n] = b[n] + sum_k W[n,k] beta[k] (fp32)
+ * so that  C[m,n] = act( rstd_m * (sum_k X[m,k] Wg[n,k] - mean_m * colsum[n]) + bias[n] ),  C (M, N) fp16 (ldc).
+ * mean_m / rstd_m (biased variance E[x^2] - mean^2 in fp32, eps added before the root) are formed inside the kernel from the same
+ * fragments it multiplies (csrc/gemm256.hip, LNF): no normalised copy of X is written or read.  act CIR_ACT_NONE | CIR_ACT_GELU;
+ * dtype CIR_F16 only (CIR_EDTYPE otherwise: the rows are the fp16 stream).  K % 128 == 0, N % 16 == 0, N >= 64, 16-byte aligned rows.
+ * The result does not depend on M (always the 256 x 256 kernel; a row's statistics are summed in one fixed order).
+ * Replaces norm1 + attn.qkv and norm2 + mlp.fc1 of every ViT block: vit.py:107-109 with :72 / :36-37.
+ */
+int cir_gemm_ln_bias_act(const void* X, int64_t ldx, const void* Wg, int64_t ldw, const float* colsum, const float* bias,
+                         void* C, int64_t ldc, int64_t M, int N, int K, float eps, int act, int dtype, void* stream);
 
 /*
  * y[b] = LayerNorm(x[b] (+ residual[b]); gamma[b], beta[b], eps) over the last dimension.

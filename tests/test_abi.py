@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_symbol():
     cdll = lib.load()
     for name in _declared():
         assert hasattr(cdll, name), name
-    assert cdll.cir_version() == 11
+    assert cdll.cir_version() == 12
     assert b"aligned" in cdll.cir_strerror(-3)
 
 
@@ -78,6 +78,12 @@ def test_argument_validation_happens_before_any_launch():
     assert call(res=P, res_dtype=F16, ldr=12, out_dtype=F16) == EALIGN
     # bf16 operands + fp16 C is the residual stream: its epilogue reads an fp16 residual, an fp32 one is refused (not reinterpreted)
     assert call(res=P, res_dtype=F32, ldr=16, out_dtype=F16, in_dtype=BF16) == EDTYPE
+    # LayerNorm folded into the GEMM (ABI v12): fp16 rows only, K-tile pairs, every vector present
+    lnf = lambda **o: c.cir_gemm_ln_bias_act(*[{**dict(X=P, ldx=768, W=P, ldw=768, cs=P, b=P, C=P, ldc=768, M=4, N=768, K=768, eps=1e-6, act=0, dt=F16, st=None), **o}[k]
+                                               for k in ("X", "ldx", "W", "ldw", "cs", "b", "C", "ldc", "M", "N", "K", "eps", "act", "dt", "st")])
+    assert lnf(cs=None) == EINVAL and lnf(b=None) == EINVAL and lnf(eps=0.0) == EINVAL and lnf(act=2) == EINVAL      # no ReLU form
+    assert lnf(dt=BF16) == EDTYPE and lnf(dt=F32) == EDTYPE
+    assert lnf(K=64, ldx=64, ldw=64) == ESHAPE and lnf(N=48, ldc=48) == ESHAPE and lnf(ldx=772) == EALIGN and lnf(X=P + 2) == EALIGN
     # LayerNorm / attention / top-k: the same contract
     assert c.cir_layernorm(None, F32, 0, None, 0, P, P, 0, P, F32, None, 0, 4, 64, 1, 1e-6, BF16, None) == EINVAL
     assert c.cir_layernorm(P, F32, 0, None, 0, P, P, 0, None, F32, None, 0, 4, 64, 1, 1e-6, BF16, None) == EINVAL      # no output at all

@@ -556,7 +556,7 @@ def test_rank_identity_floors(rank, tag):
 WIDE_FLOORS = {
     "c100": {BF: (0.65, 0.991, 0.93), HF: (0.92, 0.9985, 0.95), DEF: (0.85, 0.997, 0.95)},
     "c200": {BF: (0.50, 0.991, 0.93), HF: (0.87, 0.9985, 0.95), DEF: (0.77, 0.997, 0.95)},
-    "f50": {BF: (0.80, 0.993, 0.93), HF: (0.94, 0.9985, 0.95), DEF: (0.93, 0.998, 0.95)},
+    "f50": {BF: (0.80, 0.993, 0.93), HF: (0.94, 0.9985, 0.95), DEF: (0.93, 0.9975, 0.95)},   # (default tau 0.9980 with norm1 folded into the qkv GEMM, 0.9983 before: one rounding realisation against another)
 }
 
 

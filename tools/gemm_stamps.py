@@ -13,8 +13,13 @@ a = torch.randn((m, k), device="cuda").bfloat16(); w = (torch.randn((n, k), devi
 out = torch.empty((m, n), device="cuda", dtype=torch.bfloat16)
 x = torch.randn((m, n), device="cuda") if res else None
 import time
+lnf = int(os.environ.get("LNF", "0"))                 # 1: LayerNorm folded in (cir_gemm_ln_bias_act), 2: the same shape through the plain fp16 kernel
+if lnf:
+    a, w, out = a.half(), w.half(), out.half()
+    wg, cs, bb = ops.ln_fold_pack(w.float(), b, torch.ones(k, device="cuda"), torch.zeros(k, device="cuda"))
 def launch():
-    if res: ops.gemm(a, w, b, residual=x, out_dtype=torch.float32, out=x)
+    if lnf == 1: ops.gemm_ln(a, wg, cs, bb, 1e-6, act, out=out)
+    elif res: ops.gemm(a, w, b, residual=x, out_dtype=torch.float32, out=x)
     else: ops.gemm(a, w, b, act=act, out=out)
 # >= 2 s of back-to-back launches first: the stamps then show the clock the part HOLDS under this load (MI355X guide, DVFS item 6)
 t_end = time.time() + float(os.environ.get("WARM_S", "2.5"))

@@ -24,7 +24,7 @@ def canonical(name: str):
     """rocprofv3 prints some instantiations mangled and some through a lossy demangler: map both to bench.py's names."""
     if "cir" not in name:
         return None
-    m = re.search(r"gemm256_kernelI(DF16b|DF16_|Dh)Lb([01])ELb([01])E(f|DF16_|Dh)Li(n?)(\d)E", name)
+    m = re.search(r"gemm256_kernelI(DF16b|DF16_|Dh)Lb([01])ELb([01])E(f|DF16_|Dh)Li(n?)(\d)E(?:Lb([01])E)?", name)
     if m:                                                 # names as ops.gemm_kernel_name prints them (ACT: template constant or run time)
         t = "__bf16" if m.group(1) == "DF16b" else "_Float16"
         f32, res = m.group(2) == "1", "true" if m.group(3) == "1" else "false"
@@ -34,7 +34,7 @@ def canonical(name: str):
         if stream16:
             return base + (",_Float16,0>" if act == 0 else ",_Float16>")
         if not f32 and act in (0, 1):
-            return base + f",float,{act}>"
+            return base + f",float,{act}" + (",true>" if m.group(7) == "1" else ">")   # ",true" = LayerNorm folded in (cir_gemm_ln_bias_act)
         return base + ">"
     if "gemm256_kernel<" in name:                         # lossy demangle: keeps the trailing template arguments only
         st = ",_Float16" if "_Float16" in name else ""
