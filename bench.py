@@ -318,6 +318,53 @@ def bank_mode(args, m2, m1, dev, dt, rank, world):
                        "one_off_index_vit_s": round(t_vit, 3), "one_off_kv_bank_s": round(t_kv, 3)}}), flush=True)
 
 
+def latency_mode(args, m2, m1, dev, dt):
+    """Single-query serving (the reference's own call: img_txt_fusion_val, blip_stage2.py:101-136 - ONE query against its K stage-I
+    candidates, tokens precomputed): wall time per call with every call synchronised, issued launch by launch from Python against one
+    captured HIP graph per shape (engine.ScoreGraph).  Reported separately from the headline metric."""
+    from candidate_reranking_cir_amd import synthetic
+    k, l = args.k, args.tokens
+    n_tok = (args.image_size // 16) ** 2 + 1
+    gen = torch.Generator(device=dev).manual_seed(3)
+    cand = m2.img_embed16(torch.randn((k, 3, args.image_size, args.image_size), generator=gen, device=dev).to(dt))
+    ref = m2.img_embed(torch.randn((1, 3, args.image_size, args.image_size), generator=gen, device=dev).to(dt))
+    ids = synthetic.caption_ids(0, l).unsqueeze(0).to(dev)
+    enc = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
+    z = m1.img_txt_fusion(ref, ref, enc, train=False, return_raw=True)
+    z = z.last_hidden_state if hasattr(z, "last_hidden_state") else z
+    sync = torch.cuda.synchronize
+
+    def timed(n):
+        ts = []
+        for _ in range(n):
+            sync(); t0 = time.perf_counter()
+            out = m2.img_txt_fusion_val(z, cand, enc)
+            sync(); ts.append(time.perf_counter() - t0)
+        return sorted(ts), out
+
+    res, outs = {}, {}
+    for name, lim in (("launches_from_python", 0), ("hip_graph", max(512, k))):
+        m2.enable_graphs(lim)
+        timed(max(3, args.warmup))
+        ts, outs[name] = timed(max(20, args.steps))
+        res[name] = {"p50_ms": round(ts[len(ts) // 2] * 1e3, 3), "p90_ms": round(ts[int(len(ts) * 0.9)] * 1e3, 3), "min_ms": round(ts[0] * 1e3, 3)}
+    m2.enable_graphs(0)
+    # GPU time of the same call (events around a burst of un-synchronised direct calls): what the graph can approach
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sync(); e0.record()
+    for _ in range(10):
+        m2.img_txt_fusion_val(z, cand, enc)
+    e1.record(); sync()
+    print(json.dumps({
+        "metric": "single-query re-ranking latency, one query x K candidates, tokens precomputed (img_txt_fusion_val; not the headline metric)",
+        "value": res["hip_graph"]["p50_ms"], "unit": "ms per query (p50, synchronised)", "n_gpus": 1, "steps": max(20, args.steps), "warmup": max(3, args.warmup),
+        "ms_per_step": res["hip_graph"]["p50_ms"], "higher_is_better": False, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"1 query x {k} candidates, {l} caption tokens, {n_tok} image tokens ({args.image_size} px)"},
+        "latency_ms": res, "pipelined_direct_ms_per_call": round(e0.elapsed_time(e1) / 10, 3),
+        "speedup_p50": round(res["launches_from_python"]["p50_ms"] / res["hip_graph"]["p50_ms"], 2),
+        "identical_logits": bool(torch.equal(outs["launches_from_python"], outs["hip_graph"]))}), flush=True)
+
+
 def loop_mode(args, m2, m1, dev, dt):
     """The loop the reference actually has (validate_stage2.py:209-298, utils.py:43-55), timed end to end on a synthetic
     CIRR-val-sized split; reported separately from the headline metric (the index images are encoded ONCE, so a triplet
@@ -584,7 +631,7 @@ def main():
     ap.add_argument("--loop-queries", type=int, default=512, help="loop mode: queries of the synthetic split (CIRR val: 4181)")
     ap.add_argument("--query-batch", type=int, default=16, help="loop mode: queries per stage-II batch")
     ap.add_argument("--index-batch", type=int, default=256, help="loop mode: images per extract_index_features batch")
-    ap.add_argument("--mode", default="pixels", choices=["pixels", "bank", "loop", "train"],
+    ap.add_argument("--mode", default="pixels", choices=["pixels", "bank", "loop", "train", "latency"],
                     help="pixels: headline metric (every candidate encoded from pixels); bank: SURVEY 8(f)-1 real-dataset regime, "
                          "candidates drawn from a resident index bank with cached ViT tokens and cross-attention K/V")
     ap.add_argument("--img-tune", action="store_true", help="train mode: fine-tune the ViT too (stage2_train.py --blip-img-tune): target tokens with a "
@@ -648,6 +695,10 @@ def main():
     q_n, k, ns = args.queries, args.k, args.subset
     if args.mode == "bank":
         return bank_mode(args, m2, m1, dev, dt, rank, world)
+    if args.mode == "latency":
+        if world != 1:
+            raise SystemExit("--mode latency is a single-GPU measurement")
+        return latency_mode(args, m2, m1, dev, dt)
     if args.mode == "train":
         if world != 1:
             raise SystemExit("--mode train is a single-GPU measurement")

@@ -360,6 +360,18 @@ class NlvrEngine:
             out.append(kv)
         return out
 
+    def forward_graphed(self, input_ids, attention_mask, z_t32, cand16, qidx) -> torch.Tensor:
+        """`forward` through a captured HIP graph per problem shape (ScoreGraph); at most 8 shapes are kept (oldest dropped)."""
+        graphs = self.__dict__.setdefault("_graphs", {})
+        z_t32 = z_t32.float().contiguous()
+        key = (tuple(input_ids.shape), tuple(cand16.shape), cand16.dtype)
+        g = graphs.get(key)
+        if g is None:
+            if len(graphs) >= 8:
+                graphs.pop(next(iter(graphs)))
+            g = graphs[key] = ScoreGraph(self, input_ids.contiguous(), attention_mask.contiguous(), z_t32, cand16.contiguous(), qidx.contiguous())
+        return g(input_ids, attention_mask, z_t32, cand16, qidx)
+
     def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, z_t32: torch.Tensor, cand16: Optional[torch.Tensor],
                 qidx: torch.Tensor, cand_mask: Optional[torch.Tensor] = None, taps: Optional[list] = None,
                 kv_bank: Optional[list] = None, cand_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -461,6 +473,32 @@ class NlvrEngine:
         hid = h16.view(2, t_n, l, d)[:, :, 0, :].permute(1, 0, 2).reshape(t_n, 2 * d)                     # cat(CLS_0, CLS_1) :906-908
         y = ops.gemm(hid, self.wc0, self.bc0, act=ops.ACT_RELU)                                           # blip_stage2.py:50-52
         return ops.small_linear(y, self.wc2, self.bc2)                                                    # blip_stage2.py:53
+
+
+class ScoreGraph:
+    """One captured HIP graph of `NlvrEngine.forward` for a fixed (Q, L, T, N) problem (round 5).  A single query against K = 100
+    candidates is ~330 launches of a few microseconds each: issued from Python the call is bound by the host (~30 us per launch), not
+    by the GPU.  The launch sequence has no host-side decision and every kernel takes its scalars by value, so it is captured once
+    (torch.cuda.CUDAGraph: hipStreamBeginCapture on the stream the C ABI is handed) and replayed with one hipGraphLaunch; inputs are
+    copied into the graph's static buffers (30 MB of tokens at K = 100).  Results are bit-identical to the direct call (same kernels,
+    same order).  Lives and dies with its engine (a re-packed engine starts without graphs)."""
+
+    def __init__(self, eng: "NlvrEngine", ids, mask, z32, cand16, qidx):
+        self.ids, self.mask, self.z, self.cand, self.qidx = (t.clone() for t in (ids, mask, z32, cand16, qidx))
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                          # warm-up off the capture: lazy caches (qp buffers, CU count) get built
+            for _ in range(2):
+                eng.forward(self.ids, self.mask, self.z, self.cand, self.qidx)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = eng.forward(self.ids, self.mask, self.z, self.cand, self.qidx)
+
+    def __call__(self, ids, mask, z32, cand16, qidx) -> torch.Tensor:
+        self.ids.copy_(ids); self.mask.copy_(mask); self.z.copy_(z32); self.cand.copy_(cand16); self.qidx.copy_(qidx)
+        self.graph.replay()
+        return self.out.clone()
 
 
 def _pad8(m: torch.Tensor) -> torch.Tensor:

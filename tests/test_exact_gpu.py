@@ -327,3 +327,43 @@ def test_exact_outlier_weights(cuda, fixture):
     assert np.all(per_q <= bound) and per_q[well].max() < EXACT_LOGIT_TOL
     assert tau >= 0.99 and top10 >= 0.97 and exact >= 0.80 and dec >= 0.85 * tot
     assert tau_w >= 0.999 and top_w >= 0.98 and exact_w >= 0.93
+
+
+def test_hip_graph_scoring_is_bit_identical_and_follows_the_engine():
+    """`enable_graphs`: small `score` calls replay one captured HIP graph per shape (engine.ScoreGraph) - same kernels in the same order,
+    so the logits are bit-identical to the launch-by-launch call; new inputs flow through the static buffers, a second shape gets its
+    own graph, calls above the limit stay direct, and a re-packed engine (precision change) starts without graphs."""
+    from candidate_reranking_cir_amd import synthetic
+    from candidate_reranking_cir_amd.config import BertGeometry, VitGeometry
+    from candidate_reranking_cir_amd.blip_stage2 import BLIP_NLVR
+    dev = torch.device("cuda")
+    vit = VitGeometry(image_size=64, patch_size=16, width=768, depth=1, num_heads=12)
+    torch.manual_seed(0)
+    m = BLIP_NLVR(BertGeometry(num_hidden_layers=3), vit_geometry=vit, tokenizer=synthetic.HashTokenizer()).to(dev).eval()
+    l, n = 12, vit.num_tokens
+    g = torch.Generator(device="cpu").manual_seed(1)
+
+    def inputs(q_n, k, seed):
+        g.manual_seed(seed)
+        z = torch.randn((q_n, l, 768), generator=g).to(dev)
+        ids = torch.randint(1000, 20000, (q_n, l), generator=g).to(dev)
+        mask = torch.ones_like(ids)
+        mask[0, l - 3:] = 0
+        cand = (torch.randn((q_n * k, n, 768), generator=g) * 0.5).to(dev).half()
+        qidx = torch.arange(q_n, device=dev).repeat_interleave(k)
+        return z, ids, mask, cand, qidx
+
+    cases = [inputs(1, 10, 5), inputs(1, 10, 6), inputs(2, 7, 7)]
+    direct = [m.score(*c) for c in cases]
+    m.enable_graphs(64)
+    graphed = [m.score(*c) for c in cases] + [m.score(*cases[0])]
+    for a, b in zip(direct + [direct[0]], graphed):
+        assert torch.equal(a, b)
+    eng = m.engines()[1]
+    assert len(eng._graphs) == 2                                   # (1 x 10) reused for the second input set, (2 x 7) its own
+    big = inputs(1, 80, 9)
+    assert torch.equal(m.score(*big), (m.enable_graphs(0), m.score(*big))[1]) and len(eng._graphs) == 2   # above the limit: direct
+    m.enable_graphs(64)
+    m.set_precision("bf16")
+    ref = m.enable_graphs(0).score(*cases[0])
+    assert torch.equal(m.enable_graphs(64).score(*cases[0]), ref) and m.engines()[1] is not eng
