@@ -84,6 +84,8 @@ class _EngineHost(nn.Module):
         self.image_dtype = None                # operand type of the ViT and the cross-attention block (None: = compute_dtype)
         self._stream_dtype = None              # None = automatic (see `stream_dtype`)
         self._vit_stream_dtype = None          # the ViT's own residual-stream storage (None = automatic)
+        self.text_stream32_from = None         # two-branch encoder: layers >= this index keep their residual stream in fp32 (None: `stream_dtype`
+                                               # everywhere) - `set_text_stream32_from`
         self.graph_candidates = 0              # `score` calls with at most this many candidate rows replay a captured HIP graph per
                                                # shape (0 = off; `enable_graphs`): single-query serving is launch-bound from the host
 
@@ -125,6 +127,13 @@ class _EngineHost(nn.Module):
             raise ValueError("fp32 operands are all-or-nothing: use set_precision('exact')")
         self.compute_dtype = dtype
         self.image_dtype = None if image_dtype == dtype else image_dtype
+        self._engines = None
+        return self
+
+    def set_text_stream32_from(self, layer: Optional[int]):
+        """fp32 storage of the two-branch encoder's residual stream from fusion layer `layer` on (the layers nearest the logits), the
+        layers below it in `stream_dtype`; None = `stream_dtype` everywhere.  A point between the all-fp16 default and the split mode."""
+        self.text_stream32_from = None if layer is None else int(layer)
         self._engines = None
         return self
 
@@ -207,6 +216,7 @@ class BLIP_NLVR(_EngineHost):
             self._engines = (VitEngine(sd, self.vit_geometry, self.token_dtype, dev, stream_dtype=self.vit_stream_dtype),
                              NlvrEngine(sd, self.bert_geometry, self.compute_dtype, dev, fold_merge=self.fold_merge and self.compute_dtype != torch.float32, stream_dtype=self.stream_dtype,
                                         cross_dtype=self.token_dtype))
+            self._engines[1].stream32_from = self.text_stream32_from
             self._text_stale = False
             self._packed_epoch = _lib.PARAM_EPOCH[0]
             self._vit_stale = False                    # (a full build packs the ViT too: no second VitEngine below - round-4 advisor finding)
@@ -223,6 +233,7 @@ class BLIP_NLVR(_EngineHost):
             # between backward() and step() cannot leave the engine on the pre-step weights): repack the two-branch encoder only (the ViT is frozen there),
             self._engines = (self._engines[0], NlvrEngine(self.state_dict(), self.bert_geometry, self.compute_dtype, self.device,
                                                           fold_merge=self.fold_merge and self.compute_dtype != torch.float32, stream_dtype=self.stream_dtype, cross_dtype=self.token_dtype))
+            self._engines[1].stream32_from = self.text_stream32_from
             self._text_stale = False           # and only when a caller needs it (`text`): img_embed between steps does not
             self._packed_epoch = _lib.PARAM_EPOCH[0]
         return self._engines

@@ -327,10 +327,11 @@ class NlvrEngine:
         self.wc2, self.bc2 = _w16(sd["cls_head.2.weight"], dtype, device), _f32(sd["cls_head.2.bias"], device)
 
     # ---------------------------------------------------------------------------------------------
-    def _self_block(self, ly, h32, h16, items, l, smask):
+    def _self_block(self, ly, h32, h16, items, l, smask, sdt=None):
         """Twin self-attention + LayerNormA/B on (2, items*L, D) hidden states (nlvr_encoder.py:427-433, 262-264).  The 16-bit
         copy of the result feeds the cross-attention query projection only: it is written in `xdtype`."""
-        d, dt, sdt, eps = self.geo.hidden_size, self.dtype, self.stream_dtype, self.geo.layer_norm_eps
+        d, dt, eps = self.geo.hidden_size, self.dtype, self.geo.layer_norm_eps
+        sdt = sdt or self.stream_dtype
         r = items * l
         qkv = ops.gemm(h16, ly["wqkv"], ly["bqkv"]).view(2, items, l, 3 * d)
         ctx = torch.empty((2, items, l, d), dtype=dt, device=h32.device)
@@ -379,7 +380,12 @@ class NlvrEngine:
         query each candidate belongs to -> logits (T, 2) fp32 (column 0 is the score).
         With `kv_bank` (from build_kv_bank) and `cand_rows` (T,) int64 bank rows, the per-candidate K|V GEMM is
         skipped and cross-attention reads K/V straight from the bank (cand16 is not used)."""
-        geo, dt, sdt, xdt = self.geo, self.dtype, self.stream_dtype, self.xdtype
+        geo, dt, xdt = self.geo, self.dtype, self.xdtype
+        # residual-stream storage per layer: `stream_dtype` everywhere, or fp32 from layer `stream32_from` on (the layers nearest the
+        # logits; DESIGN section 2) - a layer's last LayerNorm writes the stream of the NEXT layer's type
+        s32 = getattr(self, "stream32_from", None)
+        sd = lambda i: torch.float32 if (s32 is not None and i >= s32 and dt != torch.float32) else self.stream_dtype
+        sdt = sd(0)
         q_n, l = input_ids.shape
         if kv_bank is not None:
             cand_rows = cand_rows.to(torch.int64).contiguous()
@@ -396,7 +402,7 @@ class NlvrEngine:
         hq16 = hq_s if dt == sdt else ops.gather_rows(hq32.view(2 * q_n * l, d), None, dt).view(2, q_n * l, d)
         smask_q = additive_self_mask(attention_mask)                                                     # (Q, L)
         # layer 0 self-attention block depends only on (z_t, caption): once per query, then expand to candidates
-        a_sq, a16q = self._self_block(self.layers[0], hq_s, hq16, q_n, l, smask_q)
+        a_sq, a16q = self._self_block(self.layers[0], hq_s, hq16, q_n, l, smask_q, sdt)
         both = torch.cat([qidx, qidx + q_n])                                                              # rows of (2*Q, L*D)
         a32 = ops.gather_rows(a_sq.view(2 * q_n, l * d), both, sdt).view(2, r, d)
         a16 = a32 if xdt == sdt else ops.gather_rows(a16q.view(2 * q_n, l * d), both, xdt).view(2, r, d)
@@ -410,6 +416,7 @@ class NlvrEngine:
             # Only the two CLS rows of the last layer reach cls_head (nlvr_encoder.py:906-908): after its self-attention
             # (which still needs every token as key/value) everything per-token runs on 1 row per candidate instead of L.
             cls_only = self.trim_last and i == last and i > 0
+            sdt = sd(i)                                    # this layer's stream type (h32 arrives in it)
             lq = 1 if cls_only else l
             rq = t_n * lq
             if cls_only:
@@ -419,7 +426,7 @@ class NlvrEngine:
                 t = ops.gemm(ctx.view(2, t_n, d), ly["wo"], ly["bo"], residual=h32.view(2, t_n, l, d)[:, :, 0, :], out_dtype=sdt)
                 a32, a16 = _ln(t, ly["g1"], ly["b1"], eps, xdt, sdt)
             elif i > 0:
-                a32, a16 = self._self_block(ly, h32, h16, t_n, l, smask)
+                a32, a16 = self._self_block(ly, h32, h16, t_n, l, smask, sdt)
             qraw = ops.gemm(a16, ly["wq"], ly["bq"])                                                    # (2, T Lq, D)
             qc = qraw.view(2, t_n, lq, d).permute(1, 0, 2, 3)                                             # (T, 2, Lq, D) view
             ccl = cc if not cls_only else torch.empty((t_n, 1, 2, d), dtype=xdt, device=cc.device)
@@ -464,7 +471,7 @@ class NlvrEngine:
             x32, x16 = _ln(m, ly["g2"], ly["b2"], eps, dt, sdt, residual=a32)                            # LayerNormA/B(m + att_b)
             f = ops.gemm(x16.view(2 * rq, d), ly["w1"], ly["c1"], act=ops.ACT_GELU)                       # shared FFN :469-476
             t = ops.gemm(f, ly["w2"], ly["c2"], residual=x32.view(2 * rq, d), out_dtype=sdt)
-            h32, h16 = _ln(t, ly["g3"], ly["b3"], eps, dt, sdt)
+            h32, h16 = _ln(t, ly["g3"], ly["b3"], eps, dt, sd(i + 1))
             h32, h16 = h32.view(2, rq, d), h16.view(2, rq, d)
             if taps is not None:
                 hv = h32.view(2, t_n, lq, d)

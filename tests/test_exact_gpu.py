@@ -367,3 +367,33 @@ def test_hip_graph_scoring_is_bit_identical_and_follows_the_engine():
     m.set_precision("bf16")
     ref = m.enable_graphs(0).score(*cases[0])
     assert torch.equal(m.enable_graphs(64).score(*cases[0]), ref) and m.engines()[1] is not eng
+
+
+def test_partial_fp32_text_stream_sits_between_the_default_and_the_split_mode():
+    """`set_text_stream32_from(k)`: fp32 residual-stream storage for the fusion layers >= k only.  k = 0 IS the split mode (text stream
+    fp32, ViT fp16) bit for bit, k = None the default; a k in between lands between the two in distance to the exact mode."""
+    from candidate_reranking_cir_amd import synthetic
+    from candidate_reranking_cir_amd.config import BertGeometry, VitGeometry
+    from candidate_reranking_cir_amd.blip_stage2 import BLIP_NLVR
+    dev = torch.device("cuda")
+    vit = VitGeometry(image_size=64, patch_size=16, width=768, depth=1, num_heads=12)
+    torch.manual_seed(0)
+    m = BLIP_NLVR(BertGeometry(num_hidden_layers=8, merge_mlp_from_layer=4), vit_geometry=vit, tokenizer=synthetic.HashTokenizer()).to(dev).eval()
+    g = torch.Generator(device="cpu").manual_seed(2)
+    q_n, k, l, n = 3, 40, 14, vit.num_tokens
+    z = torch.randn((q_n, l, 768), generator=g).to(dev)
+    ids = torch.randint(1000, 20000, (q_n, l), generator=g).to(dev)
+    mask = torch.ones_like(ids)
+    cand = (torch.randn((q_n * k, n, 768), generator=g) * 0.5).to(dev)
+    qidx = torch.arange(q_n, device=dev).repeat_interleave(k)
+    run = lambda: m.score(z, ids, mask, cand, qidx).double()
+    default = run()
+    split = (m.set_stream_dtype(torch.float32, vit=torch.float16), run())[1]
+    m.set_stream_dtype(None, vit=None)
+    all32 = (m.set_text_stream32_from(0), run())[1]
+    half = (m.set_text_stream32_from(4), run())[1]
+    assert torch.equal((m.set_text_stream32_from(None), run())[1], default)
+    assert torch.equal(all32, split)
+    exact = (m.set_precision("exact"), run())[1]
+    e = {name: (v - exact).abs().max().item() for name, v in dict(default=default, half=half, split=split).items()}
+    assert e["split"] <= e["half"] * 1.25 and e["half"] <= e["default"] * 1.25, e

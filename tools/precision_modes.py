@@ -35,6 +35,9 @@ MODES = {
     "mixed (ViT+cross bf16, text f16) | ViT stream f16, text f32": (HF, BF, F32, HF),
     "mixed (ViT+cross bf16, text f16) | streams f16": (HF, BF, HF, HF),
     "f16 | streams f16": (HF, None, HF, "same"),
+    "f16 | streams f16, fusion layers 9-11 text stream f32": (HF, None, HF, "same", 9),
+    "f16 | streams f16, fusion layers 6-11 text stream f32": (HF, None, HF, "same", 6),
+    "f16 | streams f16, fusion layers 3-11 text stream f32": (HF, None, HF, "same", 3),
     "f16 | ViT stream f16, text f32": (HF, None, F32, HF),
     "f16 | streams f32": (HF, None, F32, "same"),
     "exact (fp32 everywhere, f32-input MFMA)": (F32, None, F32, "same"),
@@ -47,7 +50,9 @@ def order_stats(ours, ref):
 
 
 def apply(m, mode):
-    dt, idt, sdt, vsdt = MODES[mode]
+    dt, idt, sdt, vsdt = MODES[mode][:4]
+    if hasattr(m, "set_text_stream32_from"):                       # (the stage-I model has no two-branch encoder)
+        m.set_text_stream32_from(MODES[mode][4] if len(MODES[mode]) > 4 else None)
     if dt == F32:
         return m.set_precision("exact")
     if m.compute_dtype == F32:
