@@ -38,7 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2516.6, "f16": 2516.6, "mixed": 2516.6,  # dense 16-bit MFMA peak, 256 CU x 2.4 GHz x 4096 flop/clk/CU (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"bf16": 2516.6, "f16": 2516.6, "mixed": 2516.6, "text32": 2516.6,  # dense 16-bit MFMA peak, 256 CU x 2.4 GHz x 4096 flop/clk/CU (MI355X_MICROARCH.md); text32: the 16-bit peak too (a mixed path: its text side runs on the f32-input MFMA)
                "exact": 157.3}                                  # f32-input MFMA: 256 CU x 2.4 GHz x 256 flop/clk/CU (same guide: 1/16 of the 16-bit rate)
 _STREAMS = {"f16": ("f16", "f16"), "f32": ("f32", "f32"), "split": ("f32", "f16")}     # name -> (text-side storage, ViT storage)
 
@@ -47,7 +47,7 @@ def apply_precision(model, dtype: str, stream: str):
     """`dtype`: operand precision mode (BLIP_NLVR.set_precision: bf16 / f16 / mixed); `stream`: residual-stream storage -
     auto (the library's rule), f16, f32, or split (text side fp32, ViT fp16).  Returns the model."""
     model.set_precision(dtype)
-    if dtype == "exact":                 # fp32 everywhere, the streams included (set_precision did it)
+    if dtype in ("exact", "text32"):     # the streams follow the mode (set_precision did it): fp32 everywhere / fp32 text side over an fp16 ViT
         return model
     if stream == "auto":
         return model.set_stream_dtype(None, vit=None)
@@ -64,6 +64,8 @@ PRECISION_NOTE = {"f16": "fp16 MFMA operands everywhere, fp32 accumulate (the li
                   "bf16": "bf16 MFMA operands everywhere, fp32 accumulate",
                   "exact": "fp32 everywhere like the reference (model.float()): f32-input MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32), fp32 streams, erf GELU, "
                            "no algebraic folds - the mode that holds the reference's rank order (DESIGN.md section 2)",
+                  "text32": "fp32 operands (f32-input MFMA), fp32 stream and erf GELU for the text side (self-attention, FFN, cls_head of both text encoders); fp16 ViT and "
+                            "cross-attention block - most of the exact mode's rank fidelity at 3.7 x its throughput (DESIGN.md section 2)",
                   "mixed": "bf16 operands for the ViT and the cross-attention block, fp16 for text-side self-attention / FFN / cls_head; fp32 accumulate"}
 D, H, F, LAYERS = 768, 12, 3072, 12
 
@@ -619,7 +621,7 @@ def main():
     ap.add_argument("--skip-rate", type=float, default=0.0, help="fraction of queries without a positive in their top-K (skip rule)")
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--tokens", type=int, default=32)
-    ap.add_argument("--dtype", default=DEFAULT_DTYPE, choices=["bf16", "f16", "mixed", "exact"],
+    ap.add_argument("--dtype", default=DEFAULT_DTYPE, choices=["bf16", "f16", "mixed", "text32", "exact"],
                     help="MFMA operand precision (fp32 accumulate in all): exact = fp32 everywhere on the f32-input MFMA (the reference's precision), f16, bf16, or mixed = bf16 for the ViT and the cross-attention "
                          "block, fp16 for the text-side self-attention / FFN / cls_head (DESIGN.md section 2: rank fidelity per mode)")
     ap.add_argument("--stream-dtype", default="auto", choices=["auto", "f16", "f32", "split"],

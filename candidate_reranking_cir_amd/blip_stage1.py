@@ -47,7 +47,8 @@ class BLIP_Retrieval(_EngineHost):
                 raise RuntimeError("BLIP_Retrieval runs on an MI355X only: move the model to 'cuda' (no CPU path)")
             sd = self.state_dict()
             f32 = lambda k: sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()
-            self._engines = (MedEngine(sd, self.bert_geometry, self.compute_dtype, dev, stream_dtype=self.stream_dtype, cross_dtype=self.token_dtype),
+            self._engines = (MedEngine(sd, self.bert_geometry, self.compute_dtype, dev, stream_dtype=self.stream_dtype, cross_dtype=self.token_dtype,
+                                       split3=self.text_split3 and self.precision == "text32"),
                              VitEngine(sd, self.vit_geometry, self.token_dtype, dev, stream_dtype=self.vit_stream_dtype),
                              dict(vw=f32("vision_proj.weight"), vb=f32("vision_proj.bias"), tw=f32("text_proj.weight"), tb=f32("text_proj.bias")))
         return self._engines
@@ -97,8 +98,10 @@ def blip_stage1(pretrained: str = "", **kwargs) -> BLIP_Retrieval:
         model, msg = load_stage1_checkpoint(model, pretrained)      # blip.py:215-237 semantics
         print("missing keys:")
         print(msg.missing_keys)
-        # Real weights: the STRICT residual-stream setting (text side fp32, ViT fp16) - tau 0.94 / 0.95 of the K = 100 positions exact
-        # against the reference on the rank fixtures, for 4 % of the throughput; random-init models and the
-        # benchmark keep the all-fp16 default.  `set_stream_dtype(None, vit=None)` returns to it.
-        model.set_stream_dtype(torch.float32, vit=torch.float16)
+        # Real weights: "text32" (round 5) - the text side on fp32 rows as 3-product fp16 GEMMs (~20 bits), fp32 text stream, erf GELU; ViT and
+        # cross-attention block fp16.  Pretrained checkpoints carry outlier channels: on the fixture that mimics them the all-fp16 path holds
+        # tau 0.81 of the reference's order and the split-stream setting of round 4 0.86, this mode 0.99 (0.98 / 0.95 / 0.99 of the K = 100 /
+        # 200 / 50 positions exactly) at 0.67 x the default's throughput.  Random-init models and the benchmark keep
+        # the all-fp16 default; `set_precision("f16")` returns to it.
+        model.set_precision("text32")
     return model

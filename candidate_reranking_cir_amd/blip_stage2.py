@@ -84,6 +84,8 @@ class _EngineHost(nn.Module):
         self.image_dtype = None                # operand type of the ViT and the cross-attention block (None: = compute_dtype)
         self._stream_dtype = None              # None = automatic (see `stream_dtype`)
         self._vit_stream_dtype = None          # the ViT's own residual-stream storage (None = automatic)
+        self.text_split3 = True                # text32 mode: the text side's fp32 Linears as three fp16-MFMA products of (hi, lo) term pairs
+                                               # (ops.split_weight / cir_split16) instead of the f32-input MFMA; False = the f32-input MFMA
         self.text_stream32_from = None         # two-branch encoder: layers >= this index keep their residual stream in fp32 (None: `stream_dtype`
                                                # everywhere) - `set_text_stream32_from`
         self.graph_candidates = 0              # `score` calls with at most this many candidate rows replay a captured HIP graph per
@@ -113,7 +115,7 @@ class _EngineHost(nn.Module):
 
     @property
     def vit_stream_dtype(self) -> torch.dtype:
-        if self.compute_dtype == torch.float32:
+        if self.token_dtype == torch.float32:
             return torch.float32
         return self._vit_stream_dtype if self._vit_stream_dtype is not None else torch.float16
 
@@ -123,8 +125,8 @@ class _EngineHost(nn.Module):
         for d in (dtype, image_dtype):
             if d not in (None, torch.bfloat16, torch.float16, torch.float32) or dtype is None:
                 raise ValueError("compute dtype must be torch.bfloat16, torch.float16 (fp32 accumulate either way) or torch.float32 (exact mode)")
-        if torch.float32 in (dtype, image_dtype) and not (dtype == torch.float32 and image_dtype in (None, torch.float32)):
-            raise ValueError("fp32 operands are all-or-nothing: use set_precision('exact')")
+        if image_dtype == torch.float32 and dtype != torch.float32:
+            raise ValueError("an fp32 ViT under a 16-bit text side is not a mode: set_precision('exact') or ('text32')")
         self.compute_dtype = dtype
         self.image_dtype = None if image_dtype == dtype else image_dtype
         self._engines = None
@@ -143,7 +145,7 @@ class _EngineHost(nn.Module):
         self.graph_candidates = int(max_candidates)
         return self
 
-    PRECISIONS = ("bf16", "f16", "mixed", "exact")
+    PRECISIONS = ("bf16", "f16", "mixed", "text32", "exact")
 
     def set_precision(self, mode: str):
         """"bf16" / "f16": one operand type everywhere.  "mixed": bf16 operands for the ViT and the cross-attention block
@@ -160,8 +162,16 @@ class _EngineHost(nn.Module):
             # the default mode's throughput.
             self.set_compute_dtype(torch.float32)
             return self.set_stream_dtype(torch.float32)
-        if self.compute_dtype == torch.float32:        # leaving exact mode: back to the automatic stream storage
+        if self.compute_dtype == torch.float32:        # leaving exact / text32: back to the automatic stream storage
             self.set_stream_dtype(None)
+        if mode == "text32":
+            # Round 5 (tools/text_fp32_probe.py): the TEXT side alone in the exact mode's arithmetic - fp32 operands on the f32-input MFMA,
+            # fp32 stream, erf GELU, unfolded merge layers for self-attention / FFN / cls_head of both text encoders - over the fp16 ViT and
+            # fp16 cross-attention block (folds kept).  The rank error of a 16-bit run enters through the text side: this mode holds 0.97 /
+            # 0.95 / 0.99 of the K = 100 / 200 / 50 positions and tau 0.993 on the outlier-channel fixture (split streams: 0.857) at 3.7 x
+            # the exact mode's throughput.
+            self.set_compute_dtype(torch.float32, torch.float16)
+            return self.set_stream_dtype(None, vit=None)
         if mode == "mixed":
             return self.set_compute_dtype(torch.float16, torch.bfloat16)
         return self.set_compute_dtype(torch.bfloat16 if mode == "bf16" else torch.float16)
@@ -169,6 +179,8 @@ class _EngineHost(nn.Module):
     @property
     def precision(self) -> str:
         if self.image_dtype is not None:
+            if (self.compute_dtype, self.image_dtype) == (torch.float32, torch.float16):
+                return "text32"
             return "mixed" if (self.compute_dtype, self.image_dtype) == (torch.float16, torch.bfloat16) else \
                 f"{str(self.compute_dtype)[6:]}+{str(self.image_dtype)[6:]}"
         return {torch.bfloat16: "bf16", torch.float16: "f16", torch.float32: "exact"}[self.compute_dtype]
@@ -215,7 +227,7 @@ class BLIP_NLVR(_EngineHost):
             sd = self.state_dict()
             self._engines = (VitEngine(sd, self.vit_geometry, self.token_dtype, dev, stream_dtype=self.vit_stream_dtype),
                              NlvrEngine(sd, self.bert_geometry, self.compute_dtype, dev, fold_merge=self.fold_merge and self.compute_dtype != torch.float32, stream_dtype=self.stream_dtype,
-                                        cross_dtype=self.token_dtype))
+                                        cross_dtype=self.token_dtype, split3=self.text_split3 and self.precision == "text32"))
             self._engines[1].stream32_from = self.text_stream32_from
             self._text_stale = False
             self._packed_epoch = _lib.PARAM_EPOCH[0]
@@ -232,7 +244,7 @@ class BLIP_NLVR(_EngineHost):
             # after training steps (the forward marks it; every cir_adamw_step launch moves lib.PARAM_EPOCH, so an eval call made
             # between backward() and step() cannot leave the engine on the pre-step weights): repack the two-branch encoder only (the ViT is frozen there),
             self._engines = (self._engines[0], NlvrEngine(self.state_dict(), self.bert_geometry, self.compute_dtype, self.device,
-                                                          fold_merge=self.fold_merge and self.compute_dtype != torch.float32, stream_dtype=self.stream_dtype, cross_dtype=self.token_dtype))
+                                                          fold_merge=self.fold_merge and self.compute_dtype != torch.float32, stream_dtype=self.stream_dtype, cross_dtype=self.token_dtype, split3=self.text_split3 and self.precision == "text32"))
             self._engines[1].stream32_from = self.text_stream32_from
             self._text_stale = False           # and only when a caller needs it (`text`): img_embed between steps does not
             self._packed_epoch = _lib.PARAM_EPOCH[0]
@@ -334,8 +346,10 @@ def blip_stage2(pretrained: str = "", **kwargs) -> BLIP_NLVR:
         model, msg = load_stage2_checkpoint(model, pretrained)
         print("missing keys:")
         print(msg.missing_keys)
-        # Real weights: the STRICT residual-stream setting (text side fp32, ViT fp16) - tau 0.94 / 0.95 of the K = 100 positions exact
-        # against the reference on the rank fixtures, for 4 % of the throughput; random-init models and the
-        # benchmark keep the all-fp16 default.  `set_stream_dtype(None, vit=None)` returns to it.
-        model.set_stream_dtype(torch.float32, vit=torch.float16)
+        # Real weights: "text32" (round 5) - the text side on fp32 rows as 3-product fp16 GEMMs (~20 bits), fp32 text stream, erf GELU; ViT and
+        # cross-attention block fp16.  Pretrained checkpoints carry outlier channels: on the fixture that mimics them the all-fp16 path holds
+        # tau 0.81 of the reference's order and the split-stream setting of round 4 0.86, this mode 0.99 (0.98 / 0.95 / 0.99 of the K = 100 /
+        # 200 / 50 positions exactly) at 0.67 x the default's throughput.  Random-init models and the benchmark keep
+        # the all-fp16 default; `set_precision("f16")` returns to it.
+        model.set_precision("text32")
     return model

@@ -367,6 +367,61 @@ extern "C" int cir_gather_rows(const void* src, int src_dtype, const int64_t* in
     return CIR_EDTYPE;
 }
 
+namespace cir {
+// fp32 -> two fp16 terms hi + lo (hi = fp16(y), lo = fp16(y - hi)), y = act(x): the operand split of the 3-product text-side GEMMs
+// (text32 mode).  fp16 subnormals are kept by the MFMA, so lo needs no scaling: |lo| <= 2^-12 |y| is held to 2^-25 absolute.
+// 8 elements per thread; rows of `cols` elements with leading dimension ldx (elements); outputs with leading dimension ldo, `hi2`
+// (optional) receives a second copy of hi: with hi = buf, lo = buf + cols, hi2 = buf + 2 cols, ldo = 3 cols one row of buf is
+// [hi | lo | hi] - against a weight row [W_hi | W_hi | W_lo] ONE fp16 GEMM of depth 3 cols forms all three products in one accumulator.
+template <int ACT>
+__global__ __launch_bounds__(256) void split16_kernel(const float* __restrict__ x, int64_t ldx, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                      _Float16* __restrict__ hi2, int64_t ldo, int64_t rows, int cols) {
+    const int64_t per_row = cols >> 3;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * per_row) return;
+    const int64_t r = i / per_row;
+    const int c = (int)(i - r * per_row) * 8;
+    const float4 v0 = *reinterpret_cast<const float4*>(x + r * ldx + c), v1 = *reinterpret_cast<const float4*>(x + r * ldx + c + 4);
+    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    f16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float y = v[j];
+        if (ACT == CIR_ACT_GELU) y = 0.5f * y * (1.0f + erff(y * 0.70710678118654752f));   // as written in the reference (exact mode's GELU)
+        else if (ACT == CIR_ACT_RELU) y = fmaxf(y, 0.f);
+        asm volatile("" : "+v"(y));          // ONE value of y feeds both terms: re-evaluated with another contraction it can land on the
+        const _Float16 hj = (_Float16)y;     // other side of a rounding tie, and hi + lo then misses y by an fp16 ulp (seen: 159 of 3.8 M)
+        float hf = (float)hj;
+        asm volatile("" : "+v"(hf));
+        h[j] = hj;
+        l[j] = (_Float16)(y - hf);
+    }
+    *reinterpret_cast<f16x8*>(hi + r * ldo + c) = h;
+    *reinterpret_cast<f16x8*>(lo + r * ldo + c) = l;
+    if (hi2 != nullptr) *reinterpret_cast<f16x8*>(hi2 + r * ldo + c) = h;
+}
+}  // namespace cir
+
+extern "C" int cir_split16(const float* x, int64_t ldx, void* hi, void* lo, void* hi2, int64_t ldo, int64_t rows, int cols, int act, void* stream) {
+    using namespace cir;
+    CIR_CHECK_PTR(x); CIR_CHECK_PTR(hi); CIR_CHECK_PTR(lo);
+    if (rows <= 0 || cols <= 0) return CIR_EINVAL;
+    if (cols % 8 || ldx % 4 || ldo % 8 || ldo < cols) return CIR_ESHAPE;
+    if (act < CIR_ACT_NONE || act > CIR_ACT_RELU) return CIR_EINVAL;
+    if (!cir_aligned16(x) || !cir_aligned16(hi) || !cir_aligned16(lo) || (hi2 && !cir_aligned16(hi2))) return CIR_EALIGN;
+    const int64_t n = rows * (cols / 8);
+    if (n > 0x7fffffffLL * 256) return CIR_ESHAPE;
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    _Float16* h = reinterpret_cast<_Float16*>(hi);
+    _Float16* l = reinterpret_cast<_Float16*>(lo);
+    _Float16* h2 = reinterpret_cast<_Float16*>(hi2);
+    if (act == CIR_ACT_GELU) hipLaunchKernelGGL((split16_kernel<CIR_ACT_GELU>), grid, block, 0, s, x, ldx, h, l, h2, ldo, rows, cols);
+    else if (act == CIR_ACT_RELU) hipLaunchKernelGGL((split16_kernel<CIR_ACT_RELU>), grid, block, 0, s, x, ldx, h, l, h2, ldo, rows, cols);
+    else hipLaunchKernelGGL((split16_kernel<CIR_ACT_NONE>), grid, block, 0, s, x, ldx, h, l, h2, ldo, rows, cols);
+    CIR_LAUNCH_RESULT();
+}
+
 extern "C" int cir_linear_f32(const float* x, int64_t ldx, const float* W, const float* bias, float* y, int64_t M, int N, int K,
                               int mode, void* stream) {
     CIR_CHECK_PTR(x); CIR_CHECK_PTR(W); CIR_CHECK_PTR(y);

@@ -40,6 +40,16 @@ def _f32(t: torch.Tensor, device) -> torch.Tensor:
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+def _mark_split3(layers, *extra):
+    """text32 mode: every fp32 weight matrix of the text side (keys w*) takes the 3-product fp16 path of `ops.gemm` (ops.split_weight)."""
+    for ly in layers:
+        for k, v in ly.items():
+            if k.startswith("w") and torch.is_tensor(v) and v.dtype == torch.float32 and v.dim() >= 2:
+                ops.split_weight(v)
+    for w in extra:
+        ops.split_weight(w)
+
+
 def _auto_stream(dtype: torch.dtype, stream_dtype: Optional[torch.dtype]) -> torch.dtype:
     """Residual-stream storage: explicit, or fp16 (the sums are formed in fp32; DESIGN.md section 2 has what fp32 storage of
     the text-side stream buys - tau 0.91 -> 0.94 on the outlier fixture - and costs - 3.6 % of the step)."""
@@ -172,9 +182,10 @@ class MedEngine:
     """Stage-I BERT/MED text encoder with image cross-attention (med.py:348-398, 685-821) -> z_t."""
 
     def __init__(self, sd: SD, geo: BertGeometry, dtype: torch.dtype, device, prefix: str = "text_encoder.",
-                 stream_dtype: Optional[torch.dtype] = None, cross_dtype: Optional[torch.dtype] = None):
+                 stream_dtype: Optional[torch.dtype] = None, cross_dtype: Optional[torch.dtype] = None, split3: bool = False):
         geo.validate()
         self.geo, self.dtype, self.device, self.stream_dtype = geo, dtype, device, _auto_stream(dtype, stream_dtype)
+        self.split3 = split3 and dtype == torch.float32
         self.xdtype = xdt = cross_dtype or dtype       # operand type of the image-facing block (module docstring)
         e = prefix + "embeddings."
         self.word, self.posemb = _f32(sd[e + "word_embeddings.weight"], device), _f32(sd[e + "position_embeddings.weight"], device)
@@ -196,6 +207,8 @@ class MedEngine:
                 w1=_w16(sd[p + "intermediate.dense.weight"], dtype, device), c1=_f32(sd[p + "intermediate.dense.bias"], device),
                 w2=_w16(sd[p + "output.dense.weight"], dtype, device), c2=_f32(sd[p + "output.dense.bias"], device),
                 g3=_f32(sd[p + "output.LayerNorm.weight"], device), b3=_f32(sd[p + "output.LayerNorm.bias"], device)))
+        if self.split3:
+            _mark_split3(self.layers)
 
     def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, enc16: torch.Tensor,
                 enc_mask: Optional[torch.Tensor] = None):
@@ -244,9 +257,10 @@ class NlvrEngine:
     """
 
     def __init__(self, sd: SD, geo: BertGeometry, dtype: torch.dtype, device, prefix: str = "text_encoder.", fold_merge: bool = True,
-                 stream_dtype: Optional[torch.dtype] = None, cross_dtype: Optional[torch.dtype] = None):
+                 stream_dtype: Optional[torch.dtype] = None, cross_dtype: Optional[torch.dtype] = None, split3: bool = False):
         geo.validate()
         self.geo, self.dtype, self.device, self.fold_merge, self.stream_dtype = geo, dtype, device, fold_merge, _auto_stream(dtype, stream_dtype)
+        self.split3 = split3 and dtype == torch.float32
         self.xdtype = xdt = cross_dtype or dtype   # operand type of the cross-attention block = type of the candidate tokens (module docstring)
         self.trim_last = True   # last layer: per-token work on the CLS rows only (results identical for the rows that are used)
         self.kv_chunk = 0       # candidates per K|V + cross-attention chunk (0 = all at once; attribute, for A/B runs)
@@ -325,6 +339,8 @@ class NlvrEngine:
                 bv=_f32(torch.cat(bv).view(2 * h_n, 64), device), qp={})
         self.wc0, self.bc0 = _w16(sd["cls_head.0.weight"], dtype, device), _f32(sd["cls_head.0.bias"], device)
         self.wc2, self.bc2 = _w16(sd["cls_head.2.weight"], dtype, device), _f32(sd["cls_head.2.bias"], device)
+        if self.split3:
+            _mark_split3(self.layers, self.wc0)
 
     # ---------------------------------------------------------------------------------------------
     def _self_block(self, ly, h32, h16, items, l, smask, sdt=None):

@@ -32,6 +32,7 @@ SIGNATURES = {
                                   c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "cir_gemm_ln_bias_act": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                                      c_int64, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "cir_split16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "cir_layernorm": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
                               c_int64, c_int64, c_int, c_int, c_float, c_int, c_void_p]),
     "cir_attention": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,

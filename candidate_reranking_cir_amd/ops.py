@@ -64,12 +64,74 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+class SplitOperand:
+    """An fp32 matrix held as fp16 terms, rows [hi | lo | hi] (`split16`): the A operand of a 3-product GEMM.  Returned by `gemm` for a
+    GELU output on the split path, so that the FFN's intermediate never exists in fp32; accepted by `gemm` as `a`."""
+    dtype = torch.float32
+
+    def __init__(self, cat: torch.Tensor, k: int):
+        self.cat, self.k, self.shape, self.device = cat, k, cat.shape[:-1] + (k,), cat.device
+
+    @property
+    def hi(self):
+        return self.cat[..., :self.k]
+
+    @property
+    def lo(self):
+        return self.cat[..., self.k:2 * self.k]
+
+    def dim(self):
+        return self.cat.dim()
+
+
+def split16(x: torch.Tensor, act: int = ACT_NONE) -> SplitOperand:
+    """fp32 (..., K) with contiguous rows and ONE row stride -> SplitOperand with rows [fp16(y) | fp16(y - hi) | fp16(y)], y = act(x)."""
+    _need_cuda(x)
+    assert x.dtype == torch.float32 and x.stride(-1) == 1
+    k = x.shape[-1]
+    x2 = x if x.dim() == 2 else x.reshape(-1, k) if x.is_contiguous() else None
+    if x2 is None:                                   # (B, M, K) views with a uniform row stride (e.g. the CLS rows of a (.., L, D) tensor)
+        if x.dim() == 3 and x.stride(0) == x.shape[1] * x.stride(1):
+            x2 = x.as_strided((x.shape[0] * x.shape[1], k), (x.stride(1), 1))
+        else:
+            x2 = x.contiguous().view(-1, k)
+    cat = torch.empty(x.shape[:-1] + (3 * k,), dtype=torch.float16, device=x.device)
+    p = cat.data_ptr()
+    _lib.check(_lib.load().cir_split16(x2.data_ptr(), x2.stride(0), p, p + 2 * k, p + 4 * k, 3 * k, x2.shape[0], k, act, _stream()), "cir_split16")
+    return SplitOperand(cat, k)
+
+
+def split_weight(w32: torch.Tensor) -> torch.Tensor:
+    """Mark an fp32 weight (.., N, K) for the 3-product path: `gemm(a32, w32, ..)` then runs ONE fp16 GEMM of depth 3K,
+    [a_hi | a_lo | a_hi] [w_hi | w_hi | w_lo]^T = a_hi w_hi^T + a_lo w_hi^T + a_hi w_lo^T, in one fp32 accumulator."""
+    hi = w32.to(torch.float16)
+    lo = (w32 - hi.float()).to(torch.float16)
+    w32._split3 = torch.cat([hi, hi, lo], dim=-1).contiguous()
+    return w32
+
+
+def _gemm_split3(a, w_cat, bias, residual, act, out):
+    """out = act(a w^T + bias) (+ residual) in fp32 from fp16 term pairs (see split_weight).  GELU output: returned as a SplitOperand
+    (the exact-erf activation rides in the split pass that forms the next GEMM's operand)."""
+    sa = a if isinstance(a, SplitOperand) else split16(a)
+    assert act == ACT_NONE or residual is None, "activation and residual do not meet on this path"
+    s_ = gemm(sa.cat, w_cat, bias, residual=residual, out_dtype=torch.float32, out=out)
+    if act == ACT_GELU:
+        return split16(s_, ACT_GELU)
+    if act == ACT_RELU:
+        s_.relu_()
+    return s_
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          act: int = ACT_NONE, out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = act(a @ w.T + bias) (+ residual).  a (M,K) or (B,M,K) 16-bit - or fp32 with fp32 w / residual / out: the "exact"
     mode on the f32-input MFMA - with contiguous rows (any row stride); w (N,K) / (B,N,K); bias fp32 (N) / (B,N); out in a.dtype (operand copy), fp32 or fp16 (residual
     stream, also from bf16 operands); residual shaped like out: fp32 (out in a.dtype or fp32) or fp16 (with an fp16 out; the only
     residual an fp16 out from bf16 operands takes)."""
+    if isinstance(a, SplitOperand) or (a.dtype == torch.float32 and getattr(w, "_split3", None) is not None):
+        assert out_dtype in (None, torch.float32) and getattr(w, "_split3", None) is not None
+        return _gemm_split3(a, w._split3, bias, residual, act, out)
     _need_cuda(a, w, bias, residual, out)
     batched = a.dim() == 3
     if not batched:

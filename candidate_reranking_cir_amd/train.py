@@ -293,13 +293,19 @@ class _LN:
         return T.layernorm_bwd_fused(pre, self.g, dy, self.dg, self.db, self.eps, dtype, **kw)
 
 
+def train_dtype(model) -> torch.dtype:
+    """Operand type of the training step: the model's own when it is 16-bit; fp16 under the inference-only modes with an fp32 text side
+    ("text32" - what the factories set for real weights - and "exact"): the reference trains under fp16 autocast (stage2_train.py:210-218)."""
+    return model.compute_dtype if model.compute_dtype in (torch.float16, torch.bfloat16) else torch.float16
+
+
 class NlvrTrainer:
     """Forward (with saved activations) and backward of the two-branch encoder + cls_head for a B x B training batch."""
 
     def __init__(self, model, p_hidden: float = 0.1, p_attn: float = 0.1, seed: int = 0):
         self.model, self.p_hidden, self.p_attn, self.seed = model, float(p_hidden), float(p_attn), int(seed)
         self.geo = model.bert_geometry
-        self.dtype = model.compute_dtype
+        self.dtype = train_dtype(model)
         self.step_no = 0
         self._hd = self.geo.hidden_size // self.geo.num_attention_heads
         self.need_dfeats = False          # blip_img_tune (stage2_train.py:183-199): also return the gradient of the target image tokens
@@ -706,7 +712,7 @@ def fusion_train(model, z_t, feats, ids, mask, p_hidden: float = 0.1, p_attn: fl
         raise NotImplementedError("z_t requires a gradient: the reference computes it from the frozen stage-I model under torch.no_grad() "
                                   "(stage2_train.py:201-203); the backward pass stops at the two-branch encoder's z_t input")
     tr = getattr(model, "_trainer", None)
-    if tr is None or (tr.p_hidden, tr.p_attn) != (float(p_hidden), float(p_attn)) or tr.dtype != model.compute_dtype:
+    if tr is None or (tr.p_hidden, tr.p_attn) != (float(p_hidden), float(p_attn)) or tr.dtype != train_dtype(model):
         tr = model._trainer = NlvrTrainer(model, p_hidden, p_attn, seed)
         tr.anchor = torch.zeros((1,), device=z_t.device, requires_grad=True)
     tr.need_dfeats = bool(torch.is_tensor(feats) and feats.requires_grad)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CIR_ABI_VERSION 12
+#define CIR_ABI_VERSION 13
 
 enum { CIR_BF16 = 0, CIR_F16 = 1, CIR_F32 = 2 };
 enum { CIR_ACT_NONE = 0, CIR_ACT_GELU = 1, CIR_ACT_RELU = 2 };
@@ -106,6 +106,18 @@ int cir_gemm_bias_act(const void* A, int64_t lda, int64_t strideA,
  */
 int cir_gemm_ln_bias_act(const void* X, int64_t ldx, const void* Wg, int64_t ldw, const float* colsum, const float* bias,
                          void* C, int64_t ldc, int64_t M, int N, int K, float eps, int act, int dtype, void* stream);
+
+/*
+ * y = act(x),  hi = fp16(y),  lo = fp16(y - hi)   (ABI v13):  x (rows, cols) fp32 with leading dimension ldx; hi, lo (rows, cols) fp16
+ *   with leading dimension ldo; hi2 (optional, same layout) receives a second copy of hi.
+ *   act CIR_ACT_NONE | CIR_ACT_GELU (0.5 y (1 + erf(y / sqrt 2)), erff) | CIR_ACT_RELU.  cols % 8 == 0, ldx % 4 == 0, ldo % 8 == 0, 16-byte aligned.
+ *   The operand split of the "text32" precision mode: with hi = buf, lo = buf + cols, hi2 = buf + 2 cols, ldo = 3 cols a row of buf is
+ *   [hi | lo | hi]; against weight rows [W_hi | W_hi | W_lo] ONE cir_gemm_bias_act of depth 3 cols on fp16 operands forms
+ *   A_hi W_hi^T + A_lo W_hi^T + A_hi W_lo^T in one fp32 accumulator: ~20 significant bits of a fp32 Linear at 3/16 of the f32-input MFMA's
+ *   cost.  The MFMA keeps fp16 subnormals, so lo is stored unscaled.  No reference counterpart (the reference's fp32 Linear is what the
+ *   three products approximate).
+ */
+int cir_split16(const float* x, int64_t ldx, void* hi, void* lo, void* hi2, int64_t ldo, int64_t rows, int cols, int act, void* stream);
 
 /*
  * y[b] = LayerNorm(x[b] (+ residual[b]); gamma[b], beta[b], eps) over the last dimension.

@@ -72,6 +72,10 @@ def test_precision_flags_map_to_model_settings():
     b.apply_precision(m, "exact", "f16")
     assert (m.precision, m.compute_dtype, m.image_dtype, m.stream_dtype, m.vit_stream_dtype, m.token_dtype) == \
         ("exact", torch.float32, None, torch.float32, torch.float32, torch.float32) and b.stream_name(m) == "f32"
+    # text32 (round 5): the text side in the exact mode's arithmetic over the fp16 ViT / cross block
+    b.apply_precision(m, "text32", "f32")
+    assert (m.precision, m.compute_dtype, m.image_dtype, m.stream_dtype, m.vit_stream_dtype, m.token_dtype) == \
+        ("text32", torch.float32, torch.float16, torch.float32, torch.float16, torch.float16) and b.stream_name(m) == "split"
     b.apply_precision(m, "f16", "auto")
     assert (m.precision, m.stream_dtype, m.vit_stream_dtype) == ("f16", torch.float16, torch.float16)
-    assert set(b.PRECISION_NOTE) == {"f16", "bf16", "mixed", "exact"} == set(b.PEAK_TFLOPS) and b.PEAK_TFLOPS["exact"] == 157.3
+    assert set(b.PRECISION_NOTE) == {"f16", "bf16", "mixed", "text32", "exact"} == set(b.PEAK_TFLOPS) and b.PEAK_TFLOPS["exact"] == 157.3

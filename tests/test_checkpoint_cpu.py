@@ -56,7 +56,8 @@ def test_stage2_pretrained_matches_reference_loader(case, capsys):
     assert torch.equal(sd[k0], sd[k0.replace("self0", "self1")])
     # the factory prints what the reference's prints
     m = blip_stage2(pretrained=path, med_config=g, vit_geometry=v, tokenizer=synthetic.HashTokenizer())
-    assert (m.compute_dtype, m.stream_dtype, m.vit_stream_dtype) == (torch.float16, torch.float32, torch.float16)   # real weights: strict streams
+    assert (m.precision, m.compute_dtype, m.token_dtype, m.stream_dtype, m.vit_stream_dtype) == \
+        ("text32", torch.float32, torch.float16, torch.float32, torch.float16)   # real weights: the text side at ~20 bits (round 5)
     out = capsys.readouterr().out
     assert "reshape position embedding from 36 to 16" in out and "missing keys:" in out and isinstance(m, BLIP_NLVR)
 

@@ -397,3 +397,72 @@ def test_partial_fp32_text_stream_sits_between_the_default_and_the_split_mode():
     exact = (m.set_precision("exact"), run())[1]
     e = {name: (v - exact).abs().max().item() for name, v in dict(default=default, half=half, split=split).items()}
     assert e["split"] <= e["half"] * 1.25 and e["half"] <= e["default"] * 1.25, e
+
+
+TEXT32_FLOORS = {"c100": (0.95, 0.999), "c200": (0.92, 0.999), "f50": (0.97, 0.999)}      # measured 0.972 / 0.948 / 0.990, tau 0.9994-0.9996
+
+
+@pytest.fixture(scope="module")
+def text32_models():
+    from candidate_reranking_cir_amd import synthetic, validate_stage2 as V
+    from tests import helpers as H
+    from tests.test_model_gpu import build_models
+    z = H.load("rank224_wide.npz")
+    g, v = H.geometry(H.FULL_BERT, dict(image_size=224))
+    m2, m1 = build_models(g, v, int(z["seed"]), str(z["profile"]), torch.float16, torch.device("cuda"))
+    m2.set_precision("text32"); m1.set_precision("text32")
+    assert m2.precision == "text32" and m2.vit_stream_dtype == torch.float16 and m2.stream_dtype == torch.float32 and m2.token_dtype == torch.float16
+    bank = V.extract_index_features(synthetic.scene_images(range(int(z["n_index"])), 224), m2, batch_size=128)
+    return z, m2, m1, bank
+
+
+@pytest.mark.parametrize("tag", ["c100", "c200", "f50"])
+def test_text32_mode_on_the_reference_rank_fixtures(text32_models, tag):
+    """`set_precision("text32")`: the text side in the exact mode's arithmetic (fp32 operands on the f32-input MFMA, fp32 stream, erf GELU)
+    over the fp16 ViT and cross-attention block - against the REFERENCE's logits on the 16-query rank fixtures: between the split-stream
+    mode (0.96 / 0.91 / 0.98 exact positions) and the exact mode (1.000), logits within 8e-4."""
+    from candidate_reranking_cir_amd import validate_stage2 as V
+    from tests.test_model_gpu import order_stats
+    z, m2, m1, bank = text32_models
+    if tag == "f50":
+        caps = [V.fiq_caption(str(p[0]), str(p[1])) for p in z["f50_caps"]]
+        ds = V.RelativeValSet(ref_index=z["f50_refs"], cand_index=z["f50_cand"], labels=z["f50_labels"], captions=caps)
+        lt = V.generate_fiq_val_predictions(m2, m1, ds, bank, query_batch=4)
+        lt = lt[0] if isinstance(lt, tuple) else lt
+    else:
+        ds = V.RelativeValSet(ref_index=z[f"{tag}_refs"], cand_index=z[f"{tag}_cand"], labels=z[f"{tag}_labels"],
+                              captions=[str(c) for c in z[f"{tag}_caps"]], group_index=z[f"{tag}_groups"], target_index=z[f"{tag}_targets"])
+        lt, _ = V.generate_cirr_val_predictions(m2, m1, ds, bank, query_batch=4)
+    logits, ref = lt.cpu().numpy(), z[f"{tag}_logits"]
+    active = z[f"{tag}_labels"].any(1)
+    stats = np.array([order_stats(logits[q], ref[q]) for q in np.where(active)[0]])
+    exact, tau, top10 = stats.mean(0)
+    err = np.abs(logits[active] - ref[active]).max()
+    print(f"\n[text32 {tag}] max|dlogit| {err:.2e} exact positions {exact:.3f} tau {tau:.4f} top-10 {top10:.3f}")
+    assert err < 8e-4 and exact >= TEXT32_FLOORS[tag][0] and tau >= TEXT32_FLOORS[tag][1] and top10 >= 0.99
+
+
+@pytest.mark.parametrize("m,n,k,batch", [(5000, 768, 768, 1), (3000, 3072, 768, 2), (777, 768, 3072, 1)])
+def test_three_product_gemm_holds_twenty_bits(m, n, k, batch):
+    """text32's Linear: fp32 rows x fp32 weight as A_hi W_hi^T + (A_lo W_hi^T + A_hi W_lo^T) on the fp16 MFMA (cir_split16 + three
+    cir_gemm_bias_act launches chained through the fp32 residual) - against fp64: within 4e-6 of the result's scale (one fp16 product: 5e-4;
+    the f32-input MFMA: 1e-6), bias and residual included; the GELU form returns the NEXT product's operand pair."""
+    from candidate_reranking_cir_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(m + n)
+    shp = (lambda *s: (batch,) + s) if batch > 1 else (lambda *s: s)
+    a = (torch.randn(shp(m, k), generator=g) * 1.3).cuda()
+    a[..., 7] *= 30.0                                                   # an outlier channel
+    w = (torch.randn(shp(n, k), generator=g) * 0.02).cuda()
+    b = torch.randn(shp(n), generator=g).cuda()
+    r = torch.randn(shp(m, n), generator=g).cuda()
+    ops.split_weight(w)
+    got = ops.gemm(a, w, b, residual=r, out_dtype=torch.float32).double()
+    ref = a.double() @ w.double().transpose(-1, -2) + b.double().unsqueeze(-2) + r.double()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() < 4e-6 * scale
+    one = ops.gemm(a.half(), w.half(), b, residual=r, out_dtype=torch.float32).double()
+    assert (one - ref).abs().max().item() > 50 * (got - ref).abs().max().item()       # what the two lo products buy
+    f = ops.gemm(a, w, b, act=ops.ACT_GELU)
+    assert isinstance(f, ops.SplitOperand)
+    ref_f = F.gelu(a.double() @ w.double().transpose(-1, -2) + b.double().unsqueeze(-2))
+    assert ((f.hi.double() + f.lo.double()) - ref_f).abs().max().item() < 8e-6 * max(1.0, ref_f.abs().max().item())   # (the product's 4e-6 through GELU' <= 1.13, plus the pair's own 2^-21)

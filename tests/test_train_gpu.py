@@ -582,3 +582,27 @@ def test_fp16_loop_at_benchmark_geometry(cuda):
     assert all(np.isfinite(losses)) and getattr(opt, "skipped_steps", 0) == 0
     assert min(losses[-3:]) < losses[0] - 0.05               # random inputs, dropout noise at lr 2e-4: measured 2.780 -> 2.663
     m2.eval()
+
+
+def test_a_model_in_text32_precision_trains_with_fp16_operands(cuda):
+    """The factories put real weights in the "text32" inference mode (fp32 text side): `.train()` + `img_txt_fusion` must still be the
+    reference's fp16-autocast training step (stage2_train.py:210-218) - same logits and gradients as the model in the f16 mode - and
+    the evaluation engines keep the text32 mode afterwards."""
+    zf, g, v, _, _ = H.tiny_setup()
+    caps = [synthetic.caption_text(40 + i, n) for i, n in enumerate((5, 7, 3))]
+    rng = torch.Generator().manual_seed(4)
+    l = H.tokenize(caps)[0].shape[1]
+    z_t = torch.randn((3, l, g.hidden_size), generator=rng).cuda()
+    feats = torch.randn((3, 17, g.encoder_width), generator=rng).cuda()
+    gt = torch.arange(3, device=cuda)
+    out = {}
+    for mode in ("f16", "text32"):
+        m = build(g, v, int(zf["seed"]), str(zf["profile"]), HF)[0]
+        m.set_precision(mode)
+        freeze_vit(m)
+        m.train()
+        m.bert_geometry.hidden_dropout_prob = m.bert_geometry.attention_probs_dropout_prob = 0.0
+        logits = m.img_txt_fusion(z_t, feats, caps)
+        F.cross_entropy(logits, gt).backward()
+        out[mode] = (logits.detach().clone(), dict(m.named_parameters())["cls_head.0.weight"].grad.clone(), m.precision)
+    assert out["text32"][2] == "text32" and torch.equal(out["f16"][0], out["text32"][0]) and torch.equal(out["f16"][1], out["text32"][1])

@@ -40,6 +40,7 @@ MODES = {
     "f16 | streams f16, fusion layers 3-11 text stream f32": (HF, None, HF, "same", 3),
     "f16 | ViT stream f16, text f32": (HF, None, F32, HF),
     "f16 | streams f32": (HF, None, F32, "same"),
+    "text32 (text side: fp32 rows, 3-product fp16 GEMMs, fp32 stream; ViT + cross block f16)": (F32, HF, F32, HF),
     "exact (fp32 everywhere, f32-input MFMA)": (F32, None, F32, "same"),
 }
 
@@ -54,7 +55,7 @@ def apply(m, mode):
     if hasattr(m, "set_text_stream32_from"):                       # (the stage-I model has no two-branch encoder)
         m.set_text_stream32_from(MODES[mode][4] if len(MODES[mode]) > 4 else None)
     if dt == F32:
-        return m.set_precision("exact")
+        return m.set_precision("exact" if idt is None else "text32")
     if m.compute_dtype == F32:
         m.set_precision("f16")
     m.set_compute_dtype(dt, idt)
