@@ -854,8 +854,8 @@ def main():
     precision = None
     if world == 1 and not args.no_precision_table and not args.no_cpu_baseline:
         precision = {f"{args.dtype}+{args.stream_dtype}_stream": round(total_cand * args.steps / elapsed, 1)}
-        for od, sd_ in (("f16", "f16"), ("f16", "split"), ("f16", "f32"), ("mixed", "f16"), ("bf16", "f16"), ("bf16", "f32")):
-            if (od, sd_) == (args.dtype, args.stream_dtype):
+        for od, sd_ in (("f16", "f16"), ("f16", "split"), ("f16", "f32"), ("mixed", "f16"), ("bf16", "f16"), ("bf16", "f32"), ("text32", "split")):
+            if (od, sd_) == (args.dtype, args.stream_dtype) or od == args.dtype == "text32":
                 continue
             apply_precision(m2, od, sd_); apply_precision(m1, od, sd_)
             images_v = images.to(m2.token_dtype)
@@ -871,7 +871,7 @@ def main():
             precision[f"{od}+{sd_}_stream"] = round(n_cand * 3 / (time.perf_counter() - tv), 1)
             del images_v
         precision["note"] = ("triplets/s of the same step at each operand mode + residual-stream storage (3 steps each; split = text side fp32, "
-                             "ViT fp16).  Rank fidelity of every mode against the reference's fp32 outputs: profiles/r5_precision_modes.json, "
+                             "ViT fp16; text32 = text side on fp32 rows as 3-product fp16 GEMMs over the fp16 ViT / cross block).  Rank fidelity of every mode against the reference's fp32 outputs: profiles/r5_precision_modes.json, "
                              "DESIGN.md section 2")
 
     if rank == 0:
