@@ -466,3 +466,32 @@ def test_three_product_gemm_holds_twenty_bits(m, n, k, batch):
     assert isinstance(f, ops.SplitOperand)
     ref_f = F.gelu(a.double() @ w.double().transpose(-1, -2) + b.double().unsqueeze(-2))
     assert ((f.hi.double() + f.lo.double()) - ref_f).abs().max().item() < 8e-6 * max(1.0, ref_f.abs().max().item())   # (the product's 4e-6 through GELU' <= 1.13, plus the pair's own 2^-21)
+
+
+def test_text32_with_the_kv_bank_and_graphs(text32_models):
+    """The text32 mode through the other two scoring routes: candidates out of a per-image K/V bank (`build_kv_bank`; needs the query-side
+    fold off: that route is the projected path) and small calls as a captured HIP graph - both agree with the direct call."""
+    from candidate_reranking_cir_amd import ops
+    z, m2, m1, bank = text32_models
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    q_n, k, l = 2, 12, 9
+    zt = torch.randn((q_n, l, 768), generator=g).to(dev)
+    ids = torch.randint(1000, 20000, (q_n, l), generator=g).to(dev)
+    mask = torch.ones_like(ids)
+    rows = torch.randint(0, bank.shape[0], (q_n * k,), generator=g).to(dev)
+    qidx = torch.arange(q_n, device=dev).repeat_interleave(k)
+    cand = ops.gather_rows(bank.view(bank.shape[0], -1), rows, bank.dtype).view(q_n * k, *bank.shape[1:])
+    direct = m2.score(zt, ids, mask, cand, qidx)
+    graphed = m2.enable_graphs(64).score(zt, ids, mask, cand, qidx)
+    m2.enable_graphs(0)
+    assert torch.equal(direct, graphed)
+    eng = m2.engines()[1]
+    eng.fold_cross_kv = False                                     # the bank route = the projected K|V path
+    try:
+        projected = m2.score(zt, ids, mask, cand, qidx)
+        banked = m2.score(zt, ids, mask, None, qidx, kv_bank=m2.build_kv_bank(bank), cand_rows=rows)
+    finally:
+        eng.fold_cross_kv = True
+    assert torch.equal(projected, banked)                         # same kernels on the same K / V values
+    assert (direct - projected).abs().max().item() < 2e-3         # folded against projected cross-attention: fp16 roundings apart
