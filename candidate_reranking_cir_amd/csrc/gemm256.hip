@@ -792,7 +792,10 @@ void launch_gemm256(const GemmArgs& a_in, int in_dtype, int out_kind, hipStream_
     // the activation is a compile-time constant where the path runs at scale: operand-type C with none / GELU (QKV, K|V,
     // cross-Q / fc1), residual-stream C with none (proj, fc2, merge); every other combination reads a.act at run time
 #define CIR_DISPATCH256(T)                                                                                                     \
-    if (out_kind == 1) { if (res) CIR_LAUNCH256(T, true, true); else CIR_LAUNCH256(T, true, false); }                          \
+    if (out_kind == 1) {                                                                                                       \
+        if (a.act == CIR_ACT_NONE) { if (res) CIR_LAUNCH256(T, true, true, float, CIR_ACT_NONE); else CIR_LAUNCH256(T, true, false, float, CIR_ACT_NONE); } \
+        else { if (res) CIR_LAUNCH256(T, true, true); else CIR_LAUNCH256(T, true, false); }                                    \
+    }                                                                                                                          \
     else if (out_kind == 2) {                                                                                                  \
         if (a.act == CIR_ACT_NONE) { if (res) CIR_LAUNCH256(T, false, true, _Float16, CIR_ACT_NONE); else CIR_LAUNCH256(T, false, false, _Float16, CIR_ACT_NONE); } \
         else { if (res) CIR_LAUNCH256(T, false, true, _Float16); else CIR_LAUNCH256(T, false, false, _Float16); }              \
