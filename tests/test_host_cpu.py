@@ -95,3 +95,30 @@ def test_bank_rows_are_validated_on_the_host():
     ds.group_index = np.array([[0, 1, 2, 3, -1]] * 2)
     with pytest.raises(IndexError, match="group_index holds row -1"):
         V._check_bank_rows(ds, 10)
+
+
+def test_layernorm_fold_and_operand_split_packings():
+    """Host-side packings of round 5 (pure torch, no GPU): `ops.ln_fold_pack` - LayerNorm(x) W^T + b equals
+    rstd (x Wg^T - mean colsum) + b' exactly on the packed (fp16-rounded) Wg - and `ops.split_weight` - rows [W_hi | W_hi | W_lo] whose
+    hi + lo reconstructs the fp32 weight to 2^-21 (fp16 subnormals included)."""
+    import torch
+    from candidate_reranking_cir_amd import ops
+    g = torch.Generator().manual_seed(0)
+    k, n, m = 96, 40, 17
+    w, b = torch.randn((n, k), generator=g) * 0.05, torch.randn((n,), generator=g)
+    gamma, beta = 1 + 0.3 * torch.randn((k,), generator=g), 0.2 * torch.randn((k,), generator=g)
+    x = (torch.randn((m, k), generator=g) * 2 + 0.5).half().double()
+    wg, colsum, bias = ops.ln_fold_pack(w, b, gamma, beta)
+    assert wg.dtype == torch.float16 and colsum.dtype == bias.dtype == torch.float32
+    mean, var = x.mean(1, keepdim=True), x.var(1, unbiased=False, keepdim=True)
+    rstd = (var + 1e-6).rsqrt()
+    folded = rstd * (x @ wg.double().t() - mean * colsum.double()) + bias.double()
+    direct = ((x - mean) * rstd) @ wg.double().t() + (b.double() + w.double() @ beta.double())     # LayerNorm with gamma inside Wg
+    assert (folded - direct).abs().max().item() < 1e-5                     # colsum / bias are stored in fp32
+    ref = torch.nn.functional.layer_norm(x, (k,), gamma.double(), beta.double(), 1e-6) @ w.double().t() + b.double()
+    assert (folded - ref).abs().max().item() < 2e-3 * ref.abs().max().item()                         # Wg's fp16 rounding
+    w32 = torch.cat([w, w * 1e-3], dim=0).contiguous()                                               # second half: lo terms land in fp16's subnormals
+    cat = ops.split_weight(w32)._split3
+    assert cat.shape == (2 * n, 3 * k) and cat.dtype == torch.float16 and torch.equal(cat[:, :k], cat[:, k:2 * k])
+    rec = cat[:, :k].double() + cat[:, 2 * k:].double()
+    assert ((rec - w32.double()).abs() <= w32.double().abs() * 2.0 ** -21 + 2.0 ** -25).all()
