@@ -157,3 +157,22 @@ def test_train_mode_line():
     assert set(d["legs_ms"]) == {"vit", "z_t", "fusion_forward", "backward", "adamw"} and all(v > 0 for v in d["legs_ms"].values())
     assert 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
     assert 0 < d["loss"] < 10
+
+
+def test_text32_and_latency_lines():
+    """Round 5: `--dtype text32` (its rank_fidelity against the exact mode must beat a 16-bit run's by a wide margin even on 2 queries) and
+    `--mode latency` (one query launch by launch against one captured HIP graph: identical logits)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dtype", "text32", "--steps", "1", "--warmup", "1", "--queries", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["dtype"] == "text32" and d["value"] > 0 and d["config"]["residual_stream"] == "split" and d["config"]["precision_mode"].startswith("fp32 operands")
+    assert d["rank_fidelity"]["kendall_tau"] > 0.99 and d["rank_fidelity"]["max_abs_dlogit"] < 2e-3
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "latency", "--k", "20", "--steps", "20", "--warmup", "3"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["identical_logits"] is True and d["higher_is_better"] is False and d["latency_ms"]["hip_graph"]["p50_ms"] > 0
+    assert d["latency_ms"]["hip_graph"]["p50_ms"] <= d["latency_ms"]["launches_from_python"]["p50_ms"] * 1.1
