@@ -19,6 +19,8 @@ python bench.py --mode bank --steps 10 --warmup 3 > $O/bench_bank_mode.json 2>> 
 python bench.py --mode loop > $O/bench_loop_mode.json 2>> $O/err.txt
 python bench.py --mode loop --loop-queries 4181 --query-batch 64 > $O/bench_loop_cirr_val_4181.json 2>> $O/err.txt                               # the whole CIRR val split, K = 100 + 5, metrics included
 python bench.py --mode loop --k 50 --subset 0 --loop-queries 2017 --query-batch 64 > $O/bench_loop_fiq_dress_2017.json 2>> $O/err.txt            # FashionIQ dress, K = 50
+python bench.py --mode loop --k 100 --subset 0 --loop-queries 6016 --query-batch 64 > $O/bench_loop_config3_fiq_all_6016.json 2>> $O/err.txt   # BASELINE configs[3] whole (all three FashionIQ splits' query count) on ONE GPU
+python bench.py --mode loop --k 200 --subset 5 --loop-queries 512 --query-batch 64 > $O/bench_loop_config4_k200_512.json 2>> $O/err.txt          # BASELINE configs[4] whole on ONE GPU
 python bench.py --dtype text32 --steps 10 --warmup 3 --no-cpu-baseline --no-precision-table > $O/bench_text32.json 2>> $O/err.txt   # round 5: the factories' mode for real weights
 python bench.py --mode latency --k 100 --steps 40 --warmup 5 > $O/bench_latency_k100.json 2>> $O/err.txt                         # one query, launch by launch vs one HIP graph
 CIR_VIT_LNFOLD=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-precision-table --no-rank-fidelity > $O/bench_lnfold_off.json 2>> $O/err.txt
