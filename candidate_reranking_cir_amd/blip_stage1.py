@@ -48,7 +48,7 @@ class BLIP_Retrieval(_EngineHost):
             sd = self.state_dict()
             f32 = lambda k: sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()
             self._engines = (MedEngine(sd, self.bert_geometry, self.compute_dtype, dev, stream_dtype=self.stream_dtype, cross_dtype=self.token_dtype,
-                                       split3=self.text_split3 and self.precision == "text32"),
+                                       split3=self.text_split3 if self.precision == "text32" else 0),
                              VitEngine(sd, self.vit_geometry, self.token_dtype, dev, stream_dtype=self.vit_stream_dtype),
                              dict(vw=f32("vision_proj.weight"), vb=f32("vision_proj.bias"), tw=f32("text_proj.weight"), tb=f32("text_proj.bias")))
         return self._engines

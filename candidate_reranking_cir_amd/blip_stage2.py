@@ -84,8 +84,10 @@ class _EngineHost(nn.Module):
         self.image_dtype = None                # operand type of the ViT and the cross-attention block (None: = compute_dtype)
         self._stream_dtype = None              # None = automatic (see `stream_dtype`)
         self._vit_stream_dtype = None          # the ViT's own residual-stream storage (None = automatic)
-        self.text_split3 = True                # text32 mode: the text side's fp32 Linears as three fp16-MFMA products of (hi, lo) term pairs
-                                               # (ops.split_weight / cir_split16) instead of the f32-input MFMA; False = the f32-input MFMA
+        self.text_split3 = 8                   # text32 mode, arithmetic of the text side's fp32 Linears: 8 = "split8" rows - one fp16 MFMA product + two
+                                               # block-scaled fp8 correction products, operands written by the producing kernels (round 6;
+                                               # cir_gemm_split8); 3 / True = three fp16 products on [hi | lo | hi] rows (round 5; cir_split16);
+                                               # 0 / False = the f32-input MFMA
         self.text_stream32_from = None         # two-branch encoder: layers >= this index keep their residual stream in fp32 (None: `stream_dtype`
                                                # everywhere) - `set_text_stream32_from`
         self.graph_candidates = 0              # `score` calls with at most this many candidate rows replay a captured HIP graph per
@@ -227,7 +229,7 @@ class BLIP_NLVR(_EngineHost):
             sd = self.state_dict()
             self._engines = (VitEngine(sd, self.vit_geometry, self.token_dtype, dev, stream_dtype=self.vit_stream_dtype),
                              NlvrEngine(sd, self.bert_geometry, self.compute_dtype, dev, fold_merge=self.fold_merge and self.compute_dtype != torch.float32, stream_dtype=self.stream_dtype,
-                                        cross_dtype=self.token_dtype, split3=self.text_split3 and self.precision == "text32"))
+                                        cross_dtype=self.token_dtype, split3=self.text_split3 if self.precision == "text32" else 0))
             self._engines[1].stream32_from = self.text_stream32_from
             self._text_stale = False
             self._packed_epoch = _lib.PARAM_EPOCH[0]
@@ -244,7 +246,7 @@ class BLIP_NLVR(_EngineHost):
             # after training steps (the forward marks it; every cir_adamw_step launch moves lib.PARAM_EPOCH, so an eval call made
             # between backward() and step() cannot leave the engine on the pre-step weights): repack the two-branch encoder only (the ViT is frozen there),
             self._engines = (self._engines[0], NlvrEngine(self.state_dict(), self.bert_geometry, self.compute_dtype, self.device,
-                                                          fold_merge=self.fold_merge and self.compute_dtype != torch.float32, stream_dtype=self.stream_dtype, cross_dtype=self.token_dtype, split3=self.text_split3 and self.precision == "text32"))
+                                                          fold_merge=self.fold_merge and self.compute_dtype != torch.float32, stream_dtype=self.stream_dtype, cross_dtype=self.token_dtype, split3=self.text_split3 if self.precision == "text32" else 0))
             self._engines[1].stream32_from = self.text_stream32_from
             self._text_stale = False           # and only when a caller needs it (`text`): img_embed between steps does not
             self._packed_epoch = _lib.PARAM_EPOCH[0]

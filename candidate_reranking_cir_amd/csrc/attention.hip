@@ -614,6 +614,33 @@ extern "C" int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t 
     CIR_LAUNCH_RESULT();
 }
 
+extern "C" int cir_attention_split8(const float* q, int64_t q_s1, int64_t q_s0, int64_t q_rs, const float* k, int64_t k_s1, int64_t k_s0, int64_t k_rs,
+                                   const float* v, int64_t v_s1, int64_t v_s0, int64_t v_rs, const float* mask, int64_t m_s1, int64_t m_s0,
+                                   void* out, int64_t o_s1_bytes, int64_t o_s0_bytes, int64_t o_rs_bytes, int B1, int B0, int H, int Lq, int Lk,
+                                   float scale, void* stream) {
+    using namespace cir;
+    CIR_CHECK_PTR(q); CIR_CHECK_PTR(k); CIR_CHECK_PTR(v); CIR_CHECK_PTR(out);
+    if (B1 <= 0 || B0 <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return CIR_EINVAL;
+    const int64_t strides[] = {q_s1, q_s0, q_rs, k_s1, k_s0, k_rs, v_s1, v_s0, v_rs};
+    for (int64_t s : strides)
+        if (s % 4) return CIR_EALIGN;
+    if (o_s1_bytes % 16 || o_s0_bytes % 16 || o_rs_bytes % 16 || o_rs_bytes < 4 * (int64_t)H * 64) return CIR_EALIGN;
+    if (!cir_aligned16(q) || !cir_aligned16(k) || !cir_aligned16(v) || !cir_aligned16(out)) return CIR_EALIGN;
+    AttnArgs a;
+    a.q = q; a.q_s1 = q_s1; a.q_s0 = q_s0; a.q_rs = q_rs;
+    a.k = k; a.k_s1 = k_s1; a.k_s0 = k_s0; a.k_rs = k_rs;
+    a.v = v; a.v_s1 = v_s1; a.v_s0 = v_s0; a.v_rs = v_rs;
+    a.mask = mask; a.m_s1 = m_s1; a.m_s0 = m_s0;
+    a.kv_index = nullptr;
+    a.out = out; a.o_s1 = o_s1_bytes; a.o_s0 = o_s0_bytes; a.o_rs = o_rs_bytes;
+    a.B0 = B0; a.H = H; a.Lq = Lq; a.Lk = Lk; a.nqt = (Lq + 31) / 32;
+    a.total = (int64_t)B1 * B0 * H * a.nqt;
+    a.scale = scale;
+    a.wide_store = 0;
+    a.out_split = 1;
+    return launch_attention_f32(a, reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" int cir_cls_cross_attention(const void* x, int64_t x_s1, const int64_t* x_index, const void* qp, void* out, int T, int Lk, int D,
                                        float scale, int dtype, void* stream) {
     using namespace cir;

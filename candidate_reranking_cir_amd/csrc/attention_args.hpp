@@ -15,6 +15,7 @@ struct AttnArgs {
     int wide_store;            // attn_shared_kernel: one tile per wave, 16-byte-aligned output rows and room in LDS -> whole-row stores through LDS
     int64_t total;
     float scale;
+    int out_split = 0;         // attn_f32_kernel: `out` receives "split8" rows (common.hpp; o_s1 / o_s0 / o_rs in BYTES) instead of fp32
 };
 
 constexpr float kLog2e = 1.4426950408889634f;

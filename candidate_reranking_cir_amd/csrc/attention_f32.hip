@@ -18,7 +18,10 @@
 
 namespace cir {
 
-template <bool MASKED>
+// SPLIT (round 6): the context rows leave as "split8" operand rows [D x fp16 | D x e4m3 lo | D x e4m3 hi] (common.hpp) - what the
+// self-attention output projection of the text32 mode reads - instead of fp32: the two half-waves exchange 4-element groups
+// (v_permlane32_swap) so that a lane holds 8 consecutive features and stores 16 + 8 + 8 bytes per group.
+template <bool MASKED, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const AttnArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -115,6 +118,30 @@ __global__ __launch_bounds__(256, 2) void attn_f32_kernel(const AttnArgs a) {
         }
         if (kt + 1 < nkt) load_v(kt + 1, vf);
     }
+    if constexpr (SPLIT) {
+        const float inv = 1.0f / l_run;
+        const int d_model = a.H * 64;
+        char* row = reinterpret_cast<char*>(a.out) + b1 * a.o_s1 + b0 * a.o_s0 + (int64_t)min(q0 + r, a.Lq - 1) * a.o_rs;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                float lo4[4], hi4[4];          // own groups qd = 2p (features 8 qd + 4 hh + j) and qd = 2p + 1
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { lo4[j] = o[dt][(2 * p) * 4 + j] * inv; hi4[j] = o[dt][(2 * p + 1) * 4 + j] * inv; }
+                // swap: lanes 0-31 end with (own group 2p | partner's group 2p) = 8 consecutive features at 8 (2p); lanes 32-63 with
+                // (partner's group 2p+1 | own group 2p+1) = 8 consecutive features at 8 (2p+1)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo4[j]), "+v"(hi4[j]));
+                const int f0 = h * 64 + dt * 32 + 8 * (2 * p + hh);
+                const Split4 s0 = split8_x4(lo4), s1 = split8_x4(hi4);
+                if (q0 + r < a.Lq) {
+                    *reinterpret_cast<u32x4*>(row + 2 * f0) = u32x4{s0.h01, s0.h23, s1.h01, s1.h23};
+                    *reinterpret_cast<u32x2*>(row + 2 * d_model + f0) = u32x2{s0.lo8, s1.lo8};
+                    *reinterpret_cast<u32x2*>(row + 3 * d_model + f0) = u32x2{s0.hi8, s1.hi8};
+                }
+            }
+    } else
     if (q0 + r < a.Lq) {
         const float inv = 1.0f / l_run;
         float* op = reinterpret_cast<float*>(a.out) + b1 * a.o_s1 + b0 * a.o_s0 + (int64_t)(q0 + r) * a.o_rs + h * 64 + 4 * hh;
@@ -131,7 +158,10 @@ int launch_attention_f32(const AttnArgs& a, hipStream_t s) {
     const int64_t nblk = (a.total + 3) / 4;
     if (nblk > 0x7fffffff) return CIR_ESHAPE;
     dim3 grid((unsigned)nblk), block(256);
-    if (a.mask) hipLaunchKernelGGL((attn_f32_kernel<true>), grid, block, 0, s, a);
+    if (a.out_split) {
+        if (a.mask) hipLaunchKernelGGL((attn_f32_kernel<true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((attn_f32_kernel<false, true>), grid, block, 0, s, a);
+    } else if (a.mask) hipLaunchKernelGGL((attn_f32_kernel<true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((attn_f32_kernel<false>), grid, block, 0, s, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? CIR_OK : (int)e;

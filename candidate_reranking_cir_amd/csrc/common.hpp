@@ -164,6 +164,53 @@ __device__ __forceinline__ void gelu_erf8(float (&v)[8]) {
     for (int j = 0; j < 4; ++j) { const f32x2 y = x[j] * t[j]; v[2 * j] = y.x; v[2 * j + 1] = y.y; }
 }
 
+// ---- "split8" operand rows (round 6) ------------------------------------------------------------------------------------------------
+// A fp32 value y travels to a GEMM as three terms: hi = fp16(y), lo8 = e4m3((y - hi) * 2^12), hi8 = e4m3(hi); a row of K values is stored
+// as [K x hi (2 K bytes) | K x lo8 | K x hi8] = 4 K bytes.  Against weight rows [W_hi | e4m3(W_hi 2^e1) | e4m3(W_lo 2^e2)] one GEMM forms
+//     A_hi W_hi^T   on v_mfma_f32_16x16x32_f16            (K / 64 K-tiles of 128 bytes)
+//   + A_lo W_hi^T   on v_mfma_scale_f32_16x16x128_f8f6f4  (K / 128 K-tiles of 128 bytes; E8M0 scales 2^-12, 2^-e1)
+//   + A_hi W_lo^T   on the same instruction               (K / 128 K-tiles; scales 1, 2^-e2)
+// in ONE fp32 accumulator: the two correction products are 2^-11 of the result, so e4m3's 4 significant bits per factor leave an error
+// of ~2^-16 of the result - at twice the fp16 MFMA rate (the three-product fp16 form of round 5 costs 3 K / 64 tiles, this one 2 K / 64).
+// e4m3 has no infinity and v_cvt_pk_fp8_f32 does not saturate (480 -> NaN, measured: tools/f8_probe.hip): both fp8 terms are clamped to
+// +-448 first (a clamped element loses correction accuracy, never correctness of the leading product).
+constexpr float kSplitLoScale = 4096.0f;    // 2^12
+constexpr int kSplitLoExp = 12;
+__device__ __forceinline__ float clamp_e4m3(float x) { return __builtin_amdgcn_fmed3f(x, -448.0f, 448.0f); }
+// four values -> 4 halves (two dwords), 4 lo8 bytes, 4 hi8 bytes (element j in byte j)
+struct Split4 { unsigned h01, h23, lo8, hi8; };
+__device__ __forceinline__ Split4 split8_x4(const float (&y)[4]) {
+    float hf[4], lf[4];
+    _Float16 hh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v = y[j];
+        asm volatile("" : "+v"(v));          // ONE value of y feeds both terms (a re-evaluation under another contraction can cross a rounding tie)
+        hh[j] = (_Float16)v;
+        float f = (float)hh[j];
+        asm volatile("" : "+v"(f));
+        hf[j] = clamp_e4m3(f);
+        lf[j] = clamp_e4m3((v - f) * kSplitLoScale);
+    }
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    Split4 r;
+    r.h01 = __builtin_bit_cast(unsigned, h2{hh[0], hh[1]});
+    r.h23 = __builtin_bit_cast(unsigned, h2{hh[2], hh[3]});
+    unsigned l = 0, h = 0;
+    l = __builtin_amdgcn_cvt_pk_fp8_f32(lf[0], lf[1], l, false);
+    l = __builtin_amdgcn_cvt_pk_fp8_f32(lf[2], lf[3], l, true);
+    h = __builtin_amdgcn_cvt_pk_fp8_f32(hf[0], hf[1], h, false);
+    h = __builtin_amdgcn_cvt_pk_fp8_f32(hf[2], hf[3], h, true);
+    r.lo8 = l;
+    r.hi8 = h;
+    return r;
+}
+// c += A B on the block-scaled fp8 MFMA, IN PLACE (32 e4m3 values of k per lane and operand; sa / sb: E8M0 scale bytes, replicated)
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+__device__ __forceinline__ void mfma_f8_acc(f32x4& c, i32x8 a, i32x8 b, int sa, int sb) {
+    asm("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+}
+
 // ---- counter-based dropout of the fused training kernels (train_attn.hip, train_fused.hip) ---------------------------------------
 // Element (row, col) of a launch is DROPPED iff its 16 random bits are below round(p * 65536).  One 32-bit hash gives the bits of the
 // two adjacent columns (2j, 2j + 1) of a row: bits = hash32(row_key ^ j), row_key = a Weyl sequence over the rows offset by the seed -

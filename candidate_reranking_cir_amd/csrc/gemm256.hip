@@ -97,11 +97,19 @@ constexpr int kDbuf = 4 * kHalf;   // A0 A1 B0 B1
 // v_dot2_f32_f16 per dword (sum and sum of squares in fp32; the four waves that hold the same 64 rows take one 16-row block each =
 // 16 VALU ops per phase, in the issue gaps behind the MFMAs), are reduced over the four k-groups of lanes at the end of the tile and
 // exchanged through LDS.  No LayerNorm pass, no normalised copy of x in HBM (vit.py:107-109: norm1 / norm2 of every block).
-template <typename T, bool OUT_F32, bool HAS_RES, typename ST = float, int ACT = -1, bool LNF = false>
+// MIX ("split8" operands, round 6; common.hpp): A and W rows are byte rows [K fp16 | K e4m3 | K e4m3]; the K loop walks the same 128-byte
+// K-tiles through the same staging, reads and barriers, and only the MFMA of a K-tile pair changes: pairs of the leading segment run the
+// 32 fp16 MFMAs per phase, pairs of the two correction segments 16 block-scaled fp8 MFMAs (v_mfma_scale_f32_16x16x128_f8f6f4: the lane's
+// two 16-byte chunks of a row taken together as 32 e4m3 values of k - both operands in the same chunk order) of twice the duration each:
+// a K-tile costs the same matrix-pipe time and carries twice the depth.  OSPL (with MIX): C is written as split8 rows of act(acc + bias)
+// - the next GEMM's operand (fc1 -> fc2) - through the fp32 epilogue's 256-byte staging rows: 128 bytes of fp16 + 64 + 64 bytes of e4m3.
+template <typename T, bool OUT_F32, bool HAS_RES, typename ST = float, int ACT = -1, bool LNF = false, bool MIX = false, bool OSPL = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     constexpr bool FAST16 = !__is_same(ST, float);        // 16-bit residual-stream output (and residual)
     static_assert(!(FAST16 && OUT_F32), "the stream type is written by the 16-bit epilogue");
     static_assert(!LNF || (__is_same(T, _Float16) && !OUT_F32 && !HAS_RES && !FAST16), "LNF: fp16 stream rows in, operand-type C out");
+    static_assert(!MIX || (__is_same(T, _Float16) && OUT_F32 && !LNF), "MIX: split8 operand rows in, fp32 accumulators out through the fp32-layout epilogue");
+    static_assert(!OSPL || (MIX && !HAS_RES), "OSPL: split8 rows out of a MIX GEMM without a residual");
     using OT = typename std::conditional<FAST16, ST, T>::type;   // element type the 16-bit epilogue packs to
     using X8 = typename Elem<T>::x8;
     __shared__ __attribute__((aligned(16))) char smem[2 * kDbuf + 8 * 1024 + 4 * 4096];   // two K-tiles + a 1-KiB bias slot per wave + epilogue staging for waves 4-7
@@ -242,6 +250,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
     MM4(MH, 0) PLACE(P0) MM4(MH, 4) MM(MH, 8) PLACE(P1) MM(MH, 9) MM(MH, 10) MM(MH, 11) MM4(MH, 12) PLACE(P2)            \
     MM4(MH, 16) MM(MH, 20) PLACE(P3) MM(MH, 21) MM(MH, 22) MM(MH, 23) MM(MH, 24) PLACE(P4) MM(MH, 25) MM(MH, 26)         \
     MM(MH, 27) MM(MH, 28) PLACE(P5) MM(MH, 29) MM(MH, 30) MM(MH, 31)
+// MIX: the 16 block-scaled fp8 MFMAs of a phase (one per accumulator: the two chunks a lane read of a row are ONE 32-value operand);
+// each lasts two fp16 MFMAs, so the refill pieces keep their places in time.  sc_w / sc_a: the E8M0 scale words of the pair's segment.
+[[maybe_unused]] int sc_a = 0, sc_w = 0;
+#define CAT8(X) __builtin_bit_cast(i32x8, __builtin_shufflevector((X)[0], (X)[1], 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15))
+#define MF(MH, J) if constexpr (MIX) { mfma_f8_acc(acc[MH][((J) & 7) >> 1][(J) >> 3][(J) & 1], CAT8(wf[(J) >> 3][(J) & 1]), CAT8(af[((J) & 7) >> 1]), sc_w, sc_a); }
+#define MF2(MH, J) MF(MH, J) MF(MH, (J) + 1)
+#define MFMAS8_2(MH, P0, P1, P2, P3, P4, P5)                                                                             \
+    MF2(MH, 0) MF2(MH, 2) PLACE(P0) MF2(MH, 4) MF2(MH, 6) MF2(MH, 8) PLACE(P1) MF2(MH, 10) MF2(MH, 12) MF2(MH, 14)
+#define MFMAS8_6(MH, P0, P1, P2, P3, P4, P5)                                                                             \
+    MF2(MH, 0) PLACE(P0) MF2(MH, 2) MF(MH, 4) PLACE(P1) MF(MH, 5) MF2(MH, 6) PLACE(P2) MF2(MH, 8) MF(MH, 10) PLACE(P3)   \
+    MF(MH, 11) MF(MH, 12) PLACE(P4) MF(MH, 13) MF(MH, 14) PLACE(P5) MF(MH, 15)
 // LNF: row statistics.  The four waves of a row group hold the same 64 rows; each takes one 16-row block (its column index wc) and
 // reads that block's two fragments of the K-tile a SECOND time into registers of their own (sf) - a wave-dependent choice among the
 // af registers is either a branch chain in the MFMA stream (measured: +29 % kernel time, and the compiler's merge of the arms lost
@@ -274,10 +293,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         ST1(MH, 0) ST1(MH, 1) ST1(MH, 2) ST1(MH, 3) ST1(MH, 4) ST1(MH, 5) ST1(MH, 6) ST1(MH, 7)        \
         __builtin_amdgcn_sched_barrier(0);                                                             \
     }
-#define COMPUTE(MH, NDMA, P0, P1, P2, P3, P4, P5) \
+#define COMPUTE(KIND, MH, NDMA, P0, P1, P2, P3, P4, P5) \
     SYNC();                                      \
     __builtin_amdgcn_s_setprio(1);               \
-    MFMAS_##NDMA(MH, P0, P1, P2, P3, P4, P5)     \
+    MFMAS##KIND##_##NDMA(MH, P0, P1, P2, P3, P4, P5)     \
     __builtin_amdgcn_s_setprio(0);               \
     SYNC();
 // Counted waits, one per half of a K-tile, each in the read segment ONE phase before the half is first read (behind a
@@ -431,17 +450,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
             }                                                                                                                \
             __builtin_amdgcn_sched_barrier(0);                                                                               \
         }
-#define KTILE_D0(PA1, PA2, PW2)                                                                                         \
+#define KTILE_D0(KIND, PA1, PA2, PW2)                                                                                   \
         READ_S(0, 0) READ_B(0, 0) READ_A(0, 0) STATS(0, 12) READ_B(1, 0) WAIT_PRO(6)                                                               \
-            COMPUTE(0, 2, PIECE_A(1, 1, PA1, 0), PIECE_A(1, 1, PA1, 1), , , , )                         /* phase a0 */   \
+            COMPUTE(KIND, 0, 2, PIECE_A(1, 1, PA1, 0), PIECE_A(1, 1, PA1, 1), , , , )                   /* phase a0 */   \
         READ_S(1, 0) READ_A(1, 0) STATS(1, 8) WAIT_PRO(2)                                                                                        \
-            COMPUTE(1, 6, PIECE_A(0, 0, PA2, 0), PIECE_B(0, 0, PW2, 0), PIECE_B(1, 0, PW2, 0),                           \
+            COMPUTE(KIND, 1, 6, PIECE_A(0, 0, PA2, 0), PIECE_B(0, 0, PW2, 0), PIECE_B(1, 0, PW2, 0),                     \
                     PIECE_A(0, 0, PA2, 1), PIECE_B(0, 0, PW2, 1), PIECE_B(1, 0, PW2, 1))                /* phase b0 */
-#define KTILE_D1(PA2, PA3, PW3, HOOK)                                                                                         \
+#define KTILE_D1(KIND, PA2, PA3, PW3, HOOK)                                                                                   \
         READ_S(0, 1) READ_B(0, 1) READ_A(0, 1) STATS(0, 12) READ_B(1, 1) WAIT_A1()                                                                \
-            COMPUTE(0, 2, PIECE_A(1, 0, PA2, 0), PIECE_A(1, 0, PA2, 1), , , , )                         /* phase a1 */   \
+            COMPUTE(KIND, 0, 2, PIECE_A(1, 0, PA2, 0), PIECE_A(1, 0, PA2, 1), , , , )                   /* phase a1 */   \
         READ_S(1, 1) READ_A(1, 1) STATS(1, 8) HOOK WAIT_ABB()                                                                                         \
-            COMPUTE(1, 6, PIECE_A(0, 1, PA3, 0), PIECE_B(0, 1, PW3, 0), PIECE_B(1, 1, PW3, 0),                           \
+            COMPUTE(KIND, 1, 6, PIECE_A(0, 1, PA3, 0), PIECE_B(0, 1, PW3, 0), PIECE_B(1, 1, PW3, 0),                     \
                     PIECE_A(0, 1, PA3, 1), PIECE_B(0, 1, PW3, 1), PIECE_B(1, 1, PW3, 1))                /* phase b1 */
         // K-tiles past the end of this tile: the next tile's first two when the seam streams, else this tile's last one
         const char* const A_e0 = stream ? A_nx : A_z + (nk - 1) * 128;
@@ -452,17 +471,40 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
             const char* pa = A_z;
             const char* pw = W_z;
             bool skip = true;                            // first K-tile pair of the tile (see WAIT_PRO)
-            for (int it = 1; it < (nk >> 1); ++it) {     // all K-tile pairs but the last: refills stay inside the tile
-                KTILE_D0(pa + 128, pa + 256, pw + 256)
-                KTILE_D1(pa + 256, pa + 384, pw + 384, )
+            // MIX: pairs 1 .. k16 / 2 are the fp16 segment, the next k16 / 4 pairs A_lo x W_hi8, the rest (the peeled last pair
+            // included) A_hi8 x W_lo8 - a wave-uniform branch per pair around two copies of the same schedule
+            [[maybe_unused]] const int p16 = a.k16 >> 1, p_seg2 = p16 + (a.k16 >> 2);
+            // (two loops in sequence, not a branch inside one: with both schedules in one loop body the register allocator spilled 140
+            //  registers - accumulators among them - although each schedule alone fits)
+            int it = 1;
+            for (; it < (MIX ? p16 + 1 : (nk >> 1)); ++it) {     // all K-tile pairs but the last: refills stay inside the tile
+                KTILE_D0(, pa + 128, pa + 256, pw + 256)
+                KTILE_D1(, pa + 256, pa + 384, pw + 384, )
                 pa += 256;
                 pw += 256;
                 skip = false;
                 STAMP_PAIR(it - 1)
             }
+            if constexpr (MIX) {
+                for (; it < (nk >> 1); ++it) {
+                    sc_a = it <= p_seg2 ? a.sc_a1 : a.sc_a2;
+                    sc_w = it <= p_seg2 ? a.sc_w1 : a.sc_w2;
+                    KTILE_D0(8, pa + 128, pa + 256, pw + 256)
+                    KTILE_D1(8, pa + 256, pa + 384, pw + 384, )
+                    pa += 256;
+                    pw += 256;
+                }
+            }
             // last pair (the dispatcher sends only K % 128 == 0 here): its refills are the K-tiles past the end
-            KTILE_D0(pa + 128, A_e0, W_e0)
-            KTILE_D1(A_e0, A_e1, W_e1, PUBLISH_STATS())
+            if constexpr (MIX) {
+                sc_a = a.sc_a2;
+                sc_w = a.sc_w2;
+                KTILE_D0(8, pa + 128, A_e0, W_e0)
+                KTILE_D1(8, A_e0, A_e1, W_e1, )
+            } else {
+                KTILE_D0(, pa + 128, A_e0, W_e0)
+                KTILE_D1(, A_e0, A_e1, W_e1, PUBLISH_STATS())
+            }
         }
         STAMP(4)
         if (wr == 0) { SYNC(); }   // pair the trailing barrier of the staggered group: all LDS reads of this tile are done
@@ -481,6 +523,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
         [[maybe_unused]] const int r15e = lane_e & 15, ge = lane_e >> 4;
         const int rr = lane_e / LPR, sl = lane_e % LPR;
         const int ncol = cn0 + wc * 64 + sl * (OUT_F32 ? 4 : 8);
+        // OSPL: slot sl of a 256-byte staging row is 16 bytes of the fp16 segment (sl < 8: features 8 sl ..), of the lo8 segment
+        // (8 <= sl < 12: features 16 (sl - 8) ..) or of the hi8 segment (sl >= 12) of the wave's 64 features
+        [[maybe_unused]] const int64_t spl_colb = sl < 8 ? 2 * (int64_t)(cn0 + wc * 64) + 16 * sl
+                                                         : (int64_t)(sl < 12 ? 2 : 3) * a.n_logical + cn0 + wc * 64 + 16 * (sl & 3);
+        [[maybe_unused]] const bool spl_col_ok = sl < 8 ? cn0 + wc * 64 + 8 * sl + 8 <= a.N : cn0 + wc * 64 + 16 * (sl & 3) + 16 <= a.N;
         // fp32 residual, fetched in the SAME row-contiguous layout the stores use (1 KiB = 4 rows x 256 B per
         // instruction, whole lines) RD passes ahead; loading it in the accumulator layout (16 rows x 32-byte pieces
         // per instruction) costs ~8 us of address processing per tile.
@@ -595,11 +642,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                         _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) v[ni * 4 + jj] = acc[(PS) / (NPASS / 2)][mi][nh][ni][jj]; \
                     const int act_ = ACT >= 0 ? ACT : a.act;                                                                 \
                     if (act_ == CIR_ACT_GELU) {                                                                              \
-                        gelu_erf8(v);   /* four interleaved packed chains */                                                 \
+                        if constexpr (MIX) { _Pragma("unroll") for (int q = 0; q < 8; ++q) v[q] = gelu_erf_as(v[q]); }  /* erf to 1.5e-7: the split8 path keeps ~20 bits */ \
+                        else gelu_erf8(v);   /* four interleaved packed chains */                                            \
                     } else if (act_ == CIR_ACT_RELU) {                                                                       \
                         _Pragma("unroll") for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);                               \
                     }                                                                                                        \
-                    if constexpr (OUT_F32) {                                                                                 \
+                    if constexpr (OSPL) {   /* [nh][0] = 8 halves, [nh][1] = {lo8 x 8, hi8 x 8} */                           \
+                        const float qa_[4] = {v[0], v[1], v[2], v[3]}, qb_[4] = {v[4], v[5], v[6], v[7]};                     \
+                        const Split4 sa_ = split8_x4(qa_), sb_ = split8_x4(qb_);                                             \
+                        wd[nh * 2 + 0] = u32x4{sa_.h01, sa_.h23, sb_.h01, sb_.h23};                                          \
+                        wd[nh * 2 + 1] = u32x4{sa_.lo8, sb_.lo8, sa_.hi8, sb_.hi8};                                          \
+                    } else if constexpr (OUT_F32) {                                                                          \
                         wd[nh * 2 + 0] = __builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]});                           \
                         wd[nh * 2 + 1] = __builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]});                           \
                     } else {                                                                                                 \
@@ -611,7 +664,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
             }
             // registers -> LDS staging tile: slot = 16-byte chunk of the row, XOR-swizzled with the row
 #define WRITE_STAGE()                                                                                                        \
-            if constexpr (OUT_F32) {                                                                                         \
+            if constexpr (OSPL) {   /* row r15: fp16 features at bytes 0-127 (slot nh*4 + g), lo8 at 128-191, hi8 at 192-255 (8-byte pieces) */ \
+                _Pragma("unroll") for (int nh = 0; nh < 2; ++nh) {                                                           \
+                    const unsigned rb_ = stg_addr + r15 * ROWB;                                                              \
+                    const unsigned ah_ = rb_ + (((nh * 4 + g) ^ (r15 & 7)) << 4);                                            \
+                    const unsigned al_ = rb_ + (((8 + nh * 2 + (g >> 1)) ^ (r15 & 7)) << 4) + (g & 1) * 8;                   \
+                    const unsigned a8_ = rb_ + (((12 + nh * 2 + (g >> 1)) ^ (r15 & 7)) << 4) + (g & 1) * 8;                  \
+                    const u32x2 lo_ = {wd[nh * 2 + 1].x, wd[nh * 2 + 1].y}, hi_ = {wd[nh * 2 + 1].z, wd[nh * 2 + 1].w};      \
+                    asm volatile("ds_write_b128 %0, %3\n\tds_write_b64 %1, %4\n\tds_write_b64 %2, %5"                        \
+                                 :: "v"(ah_), "v"(al_), "v"(a8_), "v"(wd[nh * 2 + 0]), "v"(lo_), "v"(hi_) : "memory");       \
+                }                                                                                                            \
+            } else if constexpr (OUT_F32) {                                                                                  \
                 _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
                     const int slot = (i >> 1) * 8 + g * 2 + (i & 1);                                                         \
                     const unsigned ad = stg_addr + r15 * ROWB + ((slot ^ (r15 & 7)) << 4);                                   \
@@ -687,6 +750,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                     if (a.dbg & 0x200) m = blockIdx.x * 16 + (m & 15);   // experiment: every store of a workgroup into the same 16 rows (no HBM write stream)
                     if ((a.dbg & 0x100) && dd[j][0] != 0x12345u) continue;   // experiment: no global stores (LDS + VALU part of the epilogue alone)
 #endif
+                    if constexpr (OSPL) {
+                        if (full || (m < a.M && spl_col_ok)) {
+                            u32x4* cp = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.C) + cz * a.sC + m * a.ldc + spl_colb);   // ldc / sC in bytes
+                            STORE_C(cp, dd[j])
+                        }
+                    } else
                     if (full || (m < a.M && ncol + (OUT_F32 ? 4 : 8) <= a.N)) {
                         u32x4* cp;
                         if constexpr (OUT_F32) cp = reinterpret_cast<u32x4*>(reinterpret_cast<float*>(a.C) + cz * a.sC + m * a.ldc + ncol);
@@ -804,6 +873,36 @@ void launch_gemm256(const GemmArgs& a_in, int in_dtype, int out_kind, hipStream_
     else CIR_LAUNCH256(T, false, false);
     if (in_dtype == CIR_BF16) { CIR_DISPATCH256(__bf16) } else { CIR_DISPATCH256(_Float16) }
 #undef CIR_DISPATCH256
+#undef CIR_LAUNCH256
+}
+
+void launch_gemm256_split8(const GemmArgs& a_in, int out_split, hipStream_t s) {
+    GemmArgs a = a_in;
+    a.dbg = 0;
+    a.tiles_m = (int)((a.M + T256 - 1) / T256);
+    a.tiles_n = (a.N + T256 - 1) / T256;
+    const int64_t ntiles = (int64_t)a.tiles_m * a.tiles_n * a.batch;
+    int gw = 1;
+    float best = 1e30f;
+    for (int d = 1; d <= a.tiles_n && d <= 12; ++d) {
+        const float cost = d + 32.0f / d + (a.tiles_n % d ? 1.5f : 0.f);
+        if (cost < best) { best = cost; gw = d; }
+    }
+    if (const int v = g_tune[CIR_TUNE_GEMM_GROUP_W]; v > 0) gw = v < a.tiles_n ? v : a.tiles_n;
+    a.group_w = gw;
+    const int64_t g = persistent_grid();
+    dim3 grid((unsigned)(ntiles < g ? ntiles : g)), block(512);
+#define CIR_LAUNCH256(...) hipLaunchKernelGGL((gemm256_kernel<__VA_ARGS__>), grid, block, 0, s, a)
+    if (out_split) {
+        if (a.act == CIR_ACT_GELU) CIR_LAUNCH256(_Float16, true, false, float, CIR_ACT_GELU, false, true, true);
+        else CIR_LAUNCH256(_Float16, true, false, float, -1, false, true, true);
+    } else if (a.R != nullptr) {
+        CIR_LAUNCH256(_Float16, true, true, float, CIR_ACT_NONE, false, true, false);      // (the dispatcher admits a residual only without an activation)
+    } else if (a.act == CIR_ACT_NONE) {
+        CIR_LAUNCH256(_Float16, true, false, float, CIR_ACT_NONE, false, true, false);
+    } else {
+        CIR_LAUNCH256(_Float16, true, false, float, -1, false, true, false);
+    }
 #undef CIR_LAUNCH256
 }
 

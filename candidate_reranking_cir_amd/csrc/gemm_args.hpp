@@ -15,6 +15,13 @@ struct GemmArgs {
     int group_w;   // gemm256: tiles are walked in column groups of this many n-panels (weights stay L2-resident)
     const float* colsum = nullptr;   // gemm256 with the LayerNorm folded in (out_kind 3): s_n = sum_k W'[n,k]
     float ln_eps = 0.f;
+    // "split8" operands (cir_gemm_split8; common.hpp): A / W rows are BYTE rows [K fp16 | K e4m3 | K e4m3] (lda / ldw / sA / sW in units of
+    // 2 bytes like every 16-bit operand; K = the depth in 128-byte K-tiles x 64 = 2 x the logical depth).  K-tiles [0, k16) run on the fp16
+    // MFMA, [k16, k16 + k16 / 2) = A_lo x W_hi8 and the rest = A_hi8 x W_lo8 on the block-scaled fp8 MFMA with these E8M0 scale words
+    // (the byte replicated four times): activation side 2^-12 / 1, weight side 2^-e1 / 2^-e2.
+    int k16 = 0;
+    int sc_a1 = 0, sc_w1 = 0, sc_a2 = 0, sc_w2 = 0;
+    int n_logical = 0;               // split8 OUTPUT rows: C rows are [N fp16 | N e4m3 | N e4m3] with ldc / sC in BYTES
 };
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -22,5 +29,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // 256x256x64 tiles, 8 waves, staggered 8-phase schedule (gemm256.hip)
 void launch_gemm256(const GemmArgs& a, int in_dtype, int out_kind, hipStream_t s);
+// the same kernel on split8 operands (out_split: 0 = fp32 C (+ fp32 R), 1 = split8 rows of act(.))
+void launch_gemm256_split8(const GemmArgs& a, int out_split, hipStream_t s);
 
 }  // namespace cir

@@ -179,6 +179,68 @@ __global__ __launch_bounds__(256) void layernorm_h16_kernel(const _Float16* x, i
     }
 }
 
+// LayerNorm of fp32 stream rows with the GEMM operand written as "split8" rows (common.hpp) next to the fp32 stream copy: the text32 mode's
+// LayerNorms feed a split8 GEMM (qkv, fc1), and a separate split pass would read the stream copy back (4 bytes per element more, and a launch).
+// One wave per row; per 4-element chunk a lane stores 16 B of stream, 8 B of fp16 terms and 2 x 4 B of e4m3 terms.
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_split8_kernel(const float* x, int64_t sX, const float* res, int64_t sR, const float* gamma,
+                                                               const float* beta, int64_t sG, float* ys, int64_t sY, char* sp, int64_t ld_sp,
+                                                               int64_t s_sp, int64_t rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = blockIdx.y;
+    const float* xr = x + b * sX + row * cols;
+    const float* rr = res ? res + b * sR + row * cols : nullptr;
+    float4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = (lane + c * 64) * 4;
+        if (col < cols) {
+            v[c] = *reinterpret_cast<const float4*>(xr + col);
+            if (rr) {
+                const float4 r4 = *reinterpret_cast<const float4*>(rr + col);
+                v[c].x += r4.x; v[c].y += r4.y; v[c].z += r4.z; v[c].w += r4.w;
+            }
+            s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+        } else {
+            v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float mean = wave_sum(s) / (float)cols;        // the same two-pass statistics, in the same order, as ln_row: the stream copies agree bit for bit
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+        if ((lane + c * 64) * 4 < cols) {
+            const float dx = v[c].x - mean, dy = v[c].y - mean, dz = v[c].z - mean, dw = v[c].w - mean;
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+    const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+    const float* gp = gamma + b * sG;
+    const float* bp = beta + b * sG;
+    float* yr = ys ? ys + b * sY + row * cols : nullptr;
+    char* spr = sp + b * s_sp + row * ld_sp;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = (lane + c * 64) * 4;
+        if (col < cols) {
+            const float4 g4 = *reinterpret_cast<const float4*>(gp + col);
+            const float4 b4 = *reinterpret_cast<const float4*>(bp + col);
+            float o[4];
+            o[0] = (v[c].x - mean) * rstd * g4.x + b4.x;
+            o[1] = (v[c].y - mean) * rstd * g4.y + b4.y;
+            o[2] = (v[c].z - mean) * rstd * g4.z + b4.z;
+            o[3] = (v[c].w - mean) * rstd * g4.w + b4.w;
+            if (yr) *reinterpret_cast<float4*>(yr + col) = make_float4(o[0], o[1], o[2], o[3]);
+            const Split4 t = split8_x4(o);
+            *reinterpret_cast<u32x2*>(spr + 2 * col) = u32x2{t.h01, t.h23};
+            *reinterpret_cast<unsigned*>(spr + 2 * cols + col) = t.lo8;
+            *reinterpret_cast<unsigned*>(spr + 3 * cols + col) = t.hi8;
+        }
+    }
+}
+
 template <typename T, typename OS, int NCH>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* ids, const float* word, const float* pos,
                                                        const float* gamma, const float* beta, OS* y32, T* y16,
@@ -281,6 +343,28 @@ extern "C" int cir_layernorm(const void* x, int x_dtype, int64_t strideX, const 
     if (dtype16 == CIR_BF16) CIR_LN(__bf16);
     CIR_LN(_Float16);
 #undef CIR_LN
+}
+
+extern "C" int cir_layernorm_split8(const float* x, int64_t strideX, const float* residual, int64_t strideR, const float* gamma, const float* beta,
+                                    int64_t strideG, float* y_stream, int64_t strideY, void* y_split, int64_t ld_split_bytes,
+                                    int64_t stride_split_bytes, int64_t rows, int cols, int batch, float eps, void* stream) {
+    CIR_CHECK_PTR(x); CIR_CHECK_PTR(gamma); CIR_CHECK_PTR(beta); CIR_CHECK_PTR(y_split);
+    if (rows <= 0 || cols <= 0 || batch <= 0) return CIR_EINVAL;
+    if (cols % 16 != 0 || cols > 1024 || ld_split_bytes < 4 * (int64_t)cols) return CIR_ESHAPE;
+    if (!cir_aligned16(x) || !cir_aligned16(gamma) || !cir_aligned16(beta) || (residual && !cir_aligned16(residual)) ||
+        (y_stream && !cir_aligned16(y_stream)) || !cir_aligned16(y_split) || strideX % 4 || strideR % 4 || strideG % 4 || strideY % 4 ||
+        ld_split_bytes % 16 || stride_split_bytes % 16)
+        return CIR_EALIGN;
+    dim3 grid((unsigned)((rows + 3) / 4), (unsigned)batch), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    char* sp = reinterpret_cast<char*>(y_split);
+    switch ((cols + 255) / 256) {
+        case 1: hipLaunchKernelGGL((cir::layernorm_split8_kernel<1>), grid, block, 0, s, x, strideX, residual, strideR, gamma, beta, strideG, y_stream, strideY, sp, ld_split_bytes, stride_split_bytes, rows, cols, eps); break;
+        case 2: hipLaunchKernelGGL((cir::layernorm_split8_kernel<2>), grid, block, 0, s, x, strideX, residual, strideR, gamma, beta, strideG, y_stream, strideY, sp, ld_split_bytes, stride_split_bytes, rows, cols, eps); break;
+        case 3: hipLaunchKernelGGL((cir::layernorm_split8_kernel<3>), grid, block, 0, s, x, strideX, residual, strideR, gamma, beta, strideG, y_stream, strideY, sp, ld_split_bytes, stride_split_bytes, rows, cols, eps); break;
+        default: hipLaunchKernelGGL((cir::layernorm_split8_kernel<4>), grid, block, 0, s, x, strideX, residual, strideR, gamma, beta, strideG, y_stream, strideY, sp, ld_split_bytes, stride_split_bytes, rows, cols, eps); break;
+    }
+    CIR_LAUNCH_RESULT();
 }
 
 extern "C" int cir_embed_layernorm(const int64_t* ids, const float* word, const float* pos, const float* gamma,

@@ -400,7 +400,33 @@ __global__ __launch_bounds__(256) void split16_kernel(const float* __restrict__ 
     *reinterpret_cast<f16x8*>(lo + r * ldo + c) = l;
     if (hi2 != nullptr) *reinterpret_cast<f16x8*>(hi2 + r * ldo + c) = h;
 }
+// fp32 rows -> "split8" operand rows [hi fp16 | lo8 | hi8] (common.hpp), optionally through an activation: the stand-alone producer
+// (the LayerNorm, the fp32 attention and the GEMM epilogue emit the same rows themselves).  8 elements per thread.
+template <int ACT>
+__global__ __launch_bounds__(256) void split8_kernel(const float* __restrict__ x, int64_t ldx, char* __restrict__ out, int64_t ldo, int64_t rows, int cols) {
+    const int64_t per_row = cols >> 3;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * per_row) return;
+    const int64_t r = i / per_row;
+    const int c = (int)(i - r * per_row) * 8;
+    const float4 v0 = *reinterpret_cast<const float4*>(x + r * ldx + c), v1 = *reinterpret_cast<const float4*>(x + r * ldx + c + 4);
+    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (ACT == CIR_ACT_GELU) v[j] = gelu_erf_as(v[j]);
+        else if (ACT == CIR_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+    }
+    const float a[4] = {v[0], v[1], v[2], v[3]}, b[4] = {v[4], v[5], v[6], v[7]};
+    const Split4 sa = split8_x4(a), sb = split8_x4(b);
+    const u32x4 h = {sa.h01, sa.h23, sb.h01, sb.h23};
+    const u32x2 l8 = {sa.lo8, sb.lo8}, h8 = {sa.hi8, sb.hi8};
+    char* row = out + r * ldo;
+    *reinterpret_cast<u32x4*>(row + 2 * c) = h;
+    *reinterpret_cast<u32x2*>(row + 2 * cols + c) = l8;
+    *reinterpret_cast<u32x2*>(row + 3 * cols + c) = h8;
+}
 }  // namespace cir
+
 
 extern "C" int cir_split16(const float* x, int64_t ldx, void* hi, void* lo, void* hi2, int64_t ldo, int64_t rows, int cols, int act, void* stream) {
     using namespace cir;
@@ -419,6 +445,24 @@ extern "C" int cir_split16(const float* x, int64_t ldx, void* hi, void* lo, void
     if (act == CIR_ACT_GELU) hipLaunchKernelGGL((split16_kernel<CIR_ACT_GELU>), grid, block, 0, s, x, ldx, h, l, h2, ldo, rows, cols);
     else if (act == CIR_ACT_RELU) hipLaunchKernelGGL((split16_kernel<CIR_ACT_RELU>), grid, block, 0, s, x, ldx, h, l, h2, ldo, rows, cols);
     else hipLaunchKernelGGL((split16_kernel<CIR_ACT_NONE>), grid, block, 0, s, x, ldx, h, l, h2, ldo, rows, cols);
+    CIR_LAUNCH_RESULT();
+}
+
+extern "C" int cir_split8(const float* x, int64_t ldx, void* out, int64_t ldo_bytes, int64_t rows, int cols, int act, void* stream) {
+    using namespace cir;
+    CIR_CHECK_PTR(x); CIR_CHECK_PTR(out);
+    if (rows <= 0 || cols <= 0) return CIR_EINVAL;
+    if (cols % 8 || ldx % 4 || ldo_bytes % 16 || ldo_bytes < 4 * (int64_t)cols) return CIR_ESHAPE;
+    if (act < CIR_ACT_NONE || act > CIR_ACT_RELU) return CIR_EINVAL;
+    if (!cir_aligned16(x) || !cir_aligned16(out) || cols % 16) return CIR_EALIGN;     // the three segments of a row start 16-byte aligned
+    const int64_t n = rows * (cols / 8);
+    if (n > 0x7fffffffLL * 256) return CIR_ESHAPE;
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    char* o = reinterpret_cast<char*>(out);
+    if (act == CIR_ACT_GELU) hipLaunchKernelGGL((split8_kernel<CIR_ACT_GELU>), grid, block, 0, s, x, ldx, o, ldo_bytes, rows, cols);
+    else if (act == CIR_ACT_RELU) hipLaunchKernelGGL((split8_kernel<CIR_ACT_RELU>), grid, block, 0, s, x, ldx, o, ldo_bytes, rows, cols);
+    else hipLaunchKernelGGL((split8_kernel<CIR_ACT_NONE>), grid, block, 0, s, x, ldx, o, ldo_bytes, rows, cols);
     CIR_LAUNCH_RESULT();
 }
 

@@ -40,14 +40,25 @@ def _f32(t: torch.Tensor, device) -> torch.Tensor:
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
-def _mark_split3(layers, *extra):
-    """text32 mode: every fp32 weight matrix of the text side (keys w*) takes the 3-product fp16 path of `ops.gemm` (ops.split_weight)."""
+def _mark_split(mode: int, layers, *extra):
+    """text32 mode: every fp32 weight matrix of the text side (keys w*) takes a multi-product path of `ops.gemm`: mode 3 = three fp16
+    products on [hi | lo | hi] rows (ops.split_weight, round 5), mode 8 = one fp16 product + two block-scaled fp8 correction products on
+    "split8" rows (ops.split_weight8, round 6: 2 instead of 3 fp16-equivalents of matrix-pipe time, operands produced by the LayerNorm /
+    attention / fc1 kernels themselves)."""
+    mark = ops.split_weight8 if mode == 8 else ops.split_weight
     for ly in layers:
         for k, v in ly.items():
             if k.startswith("w") and torch.is_tensor(v) and v.dtype == torch.float32 and v.dim() >= 2:
-                ops.split_weight(v)
+                mark(v)
     for w in extra:
-        ops.split_weight(w)
+        mark(w)
+
+
+def _split_mode(split3, dtype) -> int:
+    """engine argument `split3` (kept name): False / 0 = the f32-input MFMA, True / 3 = three fp16 products, 8 = split8 rows"""
+    if dtype != torch.float32 or not split3:
+        return 0
+    return 8 if split3 == 8 else 3
 
 
 def _auto_stream(dtype: torch.dtype, stream_dtype: Optional[torch.dtype]) -> torch.dtype:
@@ -56,8 +67,11 @@ def _auto_stream(dtype: torch.dtype, stream_dtype: Optional[torch.dtype]) -> tor
     return stream_dtype if stream_dtype is not None else torch.float16
 
 
-def _ln(x, gamma, beta, eps, dt, sdt, residual=None, need_stream=True):
-    """LayerNorm -> (stream copy in `sdt` or None, operand copy in `dt`).  One tensor serves as both when dt == sdt."""
+def _ln(x, gamma, beta, eps, dt, sdt, residual=None, need_stream=True, split8=False):
+    """LayerNorm -> (stream copy in `sdt` or None, operand copy in `dt`).  One tensor serves as both when dt == sdt.
+    `split8`: fp32 stream copy + the operand as split8 rows, written by the LayerNorm kernel itself (text32 mode)."""
+    if split8:
+        return ops.layernorm_split8(x, gamma, beta, eps, residual=residual)
     if (dt == sdt and need_stream) or dt == torch.float32:      # fp32 operands ("exact" mode): the fp32 stream copy IS the operand
         y, _ = ops.layernorm(x, gamma, beta, eps, residual=residual, want32=True, dtype16=None, stream_dtype=sdt)
         return y, y
@@ -108,7 +122,8 @@ class VitEngine:
             for i, blk in enumerate(self.blocks):
                 b = f"{p}blocks.{i}."
                 blk["qkv_f"] = ops.ln_fold_pack(sd[b + "attn.qkv.weight"].to(device), sd[b + "attn.qkv.bias"].to(device), blk["g1"], blk["b1"])
-                blk["fc1_f"] = ops.ln_fold_pack(sd[b + "mlp.fc1.weight"].to(device), sd[b + "mlp.fc1.bias"].to(device), blk["g2"], blk["b2"])
+                if self.ln_fold >= 2:     # norm2 -> fc1 only on request (measured slower: 57 MB of packed weights nobody reads otherwise)
+                    blk["fc1_f"] = ops.ln_fold_pack(sd[b + "mlp.fc1.weight"].to(device), sd[b + "mlp.fc1.bias"].to(device), blk["g2"], blk["b2"])
 
     def forward(self, image: torch.Tensor, want32: bool = False, chunk: int = 4096, out32: Optional[torch.Tensor] = None,
                 out16: Optional[torch.Tensor] = None):
@@ -147,7 +162,7 @@ class VitEngine:
             ops.attention(qkv[:, :, 0].unsqueeze(1), qkv[:, :, 1].unsqueeze(1), qkv[:, :, 2].unsqueeze(1),
                           ctx.unsqueeze(1), scale)                             # vit.py:73-83
             ops.gemm(ctx.view(bsz * n, d), blk["wo"], blk["bo"], residual=x, out_dtype=sdt, out=x)  # :84,:108
-            if self.ln_fold >= 2:
+            if self.ln_fold >= 2 and "fc1_f" in blk:
                 f = ops.gemm_ln(x, *blk["fc1_f"], geo.layer_norm_eps, act=ops.ACT_GELU)   # vit.py:109 + :36-37
             else:
                 _, xb = _ln(x, blk["g2"], blk["b2"], geo.layer_norm_eps, dt, sdt, need_stream=False)
@@ -185,7 +200,8 @@ class MedEngine:
                  stream_dtype: Optional[torch.dtype] = None, cross_dtype: Optional[torch.dtype] = None, split3: bool = False):
         geo.validate()
         self.geo, self.dtype, self.device, self.stream_dtype = geo, dtype, device, _auto_stream(dtype, stream_dtype)
-        self.split3 = split3 and dtype == torch.float32
+        self.split = _split_mode(split3, dtype)
+        self.split3 = self.split != 0
         self.xdtype = xdt = cross_dtype or dtype       # operand type of the image-facing block (module docstring)
         e = prefix + "embeddings."
         self.word, self.posemb = _f32(sd[e + "word_embeddings.weight"], device), _f32(sd[e + "position_embeddings.weight"], device)
@@ -207,8 +223,8 @@ class MedEngine:
                 w1=_w16(sd[p + "intermediate.dense.weight"], dtype, device), c1=_f32(sd[p + "intermediate.dense.bias"], device),
                 w2=_w16(sd[p + "output.dense.weight"], dtype, device), c2=_f32(sd[p + "output.dense.bias"], device),
                 g3=_f32(sd[p + "output.LayerNorm.weight"], device), b3=_f32(sd[p + "output.LayerNorm.bias"], device)))
-        if self.split3:
-            _mark_split3(self.layers)
+        if self.split:
+            _mark_split(self.split, self.layers)
 
     def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, enc16: torch.Tensor,
                 enc_mask: Optional[torch.Tensor] = None):
@@ -223,21 +239,28 @@ class MedEngine:
         smask = additive_self_mask(attention_mask).view(q_n, 1, l)
         emask = additive_encoder_mask(enc_mask).view(q_n, 1, n) if enc_mask is not None else None
         enc2 = enc16.reshape(q_n * n, enc16.shape[2])
-        ctx = torch.empty((q_n, 1, l, d), dtype=dt, device=hs.device)
-        ctx_x = ctx if xdt == dt else torch.empty((q_n, 1, l, d), dtype=xdt, device=hs.device)
+        s8 = self.split == 8       # text32 on split8 rows: the LayerNorm / attention / fc1 kernels write the next GEMM's operand themselves
+        ctx = None if s8 else torch.empty((q_n, 1, l, d), dtype=dt, device=hs.device)
+        ctx_x = ctx if (xdt == dt and not s8) else torch.empty((q_n, 1, l, d), dtype=xdt, device=hs.device)
         for ly in self.layers:
             qkv = ops.gemm(h16, ly["wqkv"], ly["bqkv"]).view(q_n, 1, l, 3 * d)
-            ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], ctx, scale, smask)       # med.py:158-240
-            t = ops.gemm(ctx.view(r, d), ly["wo"], ly["bo"], residual=hs, out_dtype=sdt)
+            if s8:
+                ctx_op = ops.attention_split8(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], scale, smask).view(r)
+            else:
+                ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], ctx, scale, smask)   # med.py:158-240
+                ctx_op = ctx.view(r, d)
+            t = ops.gemm(ctx_op, ly["wo"], ly["bo"], residual=hs, out_dtype=sdt)
             a_s, a16 = _ln(t, ly["g1"], ly["b1"], eps, xdt, sdt)                                       # med.py:250-253 (operand copy feeds cross-Q only)
             qc = ops.gemm(a16, ly["wq"], ly["bq"]).view(q_n, 1, l, d)
             kv = ops.gemm(enc2, ly["wkv"], ly["bkv"]).view(q_n, 1, n, 2 * d)
             ops.attention(qc, kv[..., :d], kv[..., d:], ctx_x, scale, emask)                           # med.py:361-376
             t = ops.gemm(ctx_x.view(r, d), ly["wco"], ly["bco"], residual=a_s, out_dtype=sdt)
-            c_s, c16 = _ln(t, ly["g2"], ly["b2"], eps, dt, sdt)
+            c_s, c16 = _ln(t, ly["g2"], ly["b2"], eps, dt, sdt, split8=s8)
             f = ops.gemm(c16, ly["w1"], ly["c1"], act=ops.ACT_GELU)                                    # med.py:319-322
             t = ops.gemm(f, ly["w2"], ly["c2"], residual=c_s, out_dtype=sdt)
-            hs, h16 = _ln(t, ly["g3"], ly["b3"], eps, dt, sdt)                                         # med.py:331-335
+            hs, h16 = _ln(t, ly["g3"], ly["b3"], eps, dt, sdt, split8=s8)                              # med.py:331-335
+        if s8:
+            h16 = hs
         h32 = hs if hs.dtype == torch.float32 else ops.gather_rows(hs, None, torch.float32)            # API: fp32 last_hidden_state
         return h32.view(q_n, l, d), h16.view(q_n, l, d)
 
@@ -260,7 +283,8 @@ class NlvrEngine:
                  stream_dtype: Optional[torch.dtype] = None, cross_dtype: Optional[torch.dtype] = None, split3: bool = False):
         geo.validate()
         self.geo, self.dtype, self.device, self.fold_merge, self.stream_dtype = geo, dtype, device, fold_merge, _auto_stream(dtype, stream_dtype)
-        self.split3 = split3 and dtype == torch.float32
+        self.split = _split_mode(split3, dtype)
+        self.split3 = self.split != 0
         self.xdtype = xdt = cross_dtype or dtype   # operand type of the cross-attention block = type of the candidate tokens (module docstring)
         self.trim_last = True   # last layer: per-token work on the CLS rows only (results identical for the rows that are used)
         self.kv_chunk = 0       # candidates per K|V + cross-attention chunk (0 = all at once; attribute, for A/B runs)
@@ -339,8 +363,8 @@ class NlvrEngine:
                 bv=_f32(torch.cat(bv).view(2 * h_n, 64), device), qp={})
         self.wc0, self.bc0 = _w16(sd["cls_head.0.weight"], dtype, device), _f32(sd["cls_head.0.bias"], device)
         self.wc2, self.bc2 = _w16(sd["cls_head.2.weight"], dtype, device), _f32(sd["cls_head.2.bias"], device)
-        if self.split3:
-            _mark_split3(self.layers, self.wc0)
+        if self.split:
+            _mark_split(self.split, self.layers, self.wc0)
 
     # ---------------------------------------------------------------------------------------------
     def _self_block(self, ly, h32, h16, items, l, smask, sdt=None):
@@ -350,9 +374,13 @@ class NlvrEngine:
         sdt = sdt or self.stream_dtype
         r = items * l
         qkv = ops.gemm(h16, ly["wqkv"], ly["bqkv"]).view(2, items, l, 3 * d)
-        ctx = torch.empty((2, items, l, d), dtype=dt, device=h32.device)
-        ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], ctx, 64 ** -0.5, smask.unsqueeze(0).expand(2, items, l))
-        t = ops.gemm(ctx.view(2, r, d), ly["wo"], ly["bo"], residual=h32, out_dtype=sdt)
+        if self.split == 8:       # the fp32 attention writes the output projection's split8 operand itself
+            ctx_op = ops.attention_split8(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], 64 ** -0.5, smask.unsqueeze(0).expand(2, items, l)).view(2, r)
+        else:
+            ctx = torch.empty((2, items, l, d), dtype=dt, device=h32.device)
+            ops.attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], ctx, 64 ** -0.5, smask.unsqueeze(0).expand(2, items, l))
+            ctx_op = ctx.view(2, r, d)
+        t = ops.gemm(ctx_op, ly["wo"], ly["bo"], residual=h32, out_dtype=sdt)
         return _ln(t, ly["g1"], ly["b1"], eps, self.xdtype, sdt)
 
     @torch.no_grad()
@@ -378,15 +406,22 @@ class NlvrEngine:
         return out
 
     def forward_graphed(self, input_ids, attention_mask, z_t32, cand16, qidx) -> torch.Tensor:
-        """`forward` through a captured HIP graph per problem shape (ScoreGraph); at most 8 shapes are kept (oldest dropped)."""
+        """`forward` through a captured HIP graph per problem shape (ScoreGraph); at most 8 are kept (least recently used dropped).
+        A capture freezes every host-side branch of `forward`: the attributes that decide one (live A/B switches) are part of the key, so
+        changing one takes a new capture instead of replaying the old path.  Replays share the graph's static buffers: one stream at a
+        time.  With bench.py's per-launch event profiling on (ops.PROFILE_*) nothing is captured - events would be recorded inside."""
+        if ops.PROFILE_GEMM is not None or ops.PROFILE_ATTN is not None:
+            return self.forward(input_ids, attention_mask, z_t32, cand16, qidx)
         graphs = self.__dict__.setdefault("_graphs", {})
         z_t32 = z_t32.float().contiguous()
-        key = (tuple(input_ids.shape), tuple(cand16.shape), cand16.dtype)
-        g = graphs.get(key)
+        key = (tuple(input_ids.shape), tuple(cand16.shape), cand16.dtype, self.kv_chunk, self.trim_last, self.fold_cls_kv, self.fold_cross_kv,
+               getattr(self, "stream32_from", None))
+        g = graphs.pop(key, None)
         if g is None:
             if len(graphs) >= 8:
                 graphs.pop(next(iter(graphs)))
-            g = graphs[key] = ScoreGraph(self, input_ids.contiguous(), attention_mask.contiguous(), z_t32, cand16.contiguous(), qidx.contiguous())
+            g = ScoreGraph(self, input_ids.contiguous(), attention_mask.contiguous(), z_t32, cand16.contiguous(), qidx.contiguous())
+        graphs[key] = g                                   # (re-)inserted last: the dict's order is the recency order
         return g(input_ids, attention_mask, z_t32, cand16, qidx)
 
     def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, z_t32: torch.Tensor, cand16: Optional[torch.Tensor],
@@ -427,6 +462,7 @@ class NlvrEngine:
         cand2 = cand16.reshape(t_n * n, cand16.shape[2]) if kv_bank is None else None
         cc = torch.empty((t_n, l, 2, d), dtype=xdt, device=z_t32.device)
         h32 = h16 = None
+        s8 = self.split == 8      # text32 on split8 rows: LayerNorm / attention / fc1 kernels write the next GEMM's operand themselves
         last = len(self.layers) - 1
         for i, ly in enumerate(self.layers):
             # Only the two CLS rows of the last layer reach cls_head (nlvr_encoder.py:906-908): after its self-attention
@@ -437,9 +473,13 @@ class NlvrEngine:
             rq = t_n * lq
             if cls_only:
                 qkv = ops.gemm(h16, ly["wqkv"], ly["bqkv"]).view(2, t_n, l, 3 * d)
-                ctx = torch.empty((2, t_n, 1, d), dtype=dt, device=h32.device)
-                ops.attention(qkv[:, :, :1, :d], qkv[..., d:2 * d], qkv[..., 2 * d:], ctx, scale, smask.unsqueeze(0).expand(2, t_n, l))
-                t = ops.gemm(ctx.view(2, t_n, d), ly["wo"], ly["bo"], residual=h32.view(2, t_n, l, d)[:, :, 0, :], out_dtype=sdt)
+                if s8:
+                    ctx_op = ops.attention_split8(qkv[:, :, :1, :d], qkv[..., d:2 * d], qkv[..., 2 * d:], scale, smask.unsqueeze(0).expand(2, t_n, l)).view(2, t_n)
+                else:
+                    ctx = torch.empty((2, t_n, 1, d), dtype=dt, device=h32.device)
+                    ops.attention(qkv[:, :, :1, :d], qkv[..., d:2 * d], qkv[..., 2 * d:], ctx, scale, smask.unsqueeze(0).expand(2, t_n, l))
+                    ctx_op = ctx.view(2, t_n, d)
+                t = ops.gemm(ctx_op, ly["wo"], ly["bo"], residual=h32.view(2, t_n, l, d)[:, :, 0, :], out_dtype=sdt)
                 a32, a16 = _ln(t, ly["g1"], ly["b1"], eps, xdt, sdt)
             elif i > 0:
                 a32, a16 = self._self_block(ly, h32, h16, t_n, l, smask, sdt)
@@ -484,16 +524,17 @@ class NlvrEngine:
                 m = ops.gemm(dd.view(rq, 2 * d), ly["wm"], ly["bm"], out_dtype=sdt)
             else:
                 m = ops.gemm(ccl.view(rq, 2 * d), ly["wm"], ly["bm"], out_dtype=sdt)                     # :252-260
-            x32, x16 = _ln(m, ly["g2"], ly["b2"], eps, dt, sdt, residual=a32)                            # LayerNormA/B(m + att_b)
-            f = ops.gemm(x16.view(2 * rq, d), ly["w1"], ly["c1"], act=ops.ACT_GELU)                       # shared FFN :469-476
+            x32, x16 = _ln(m, ly["g2"], ly["b2"], eps, dt, sdt, residual=a32, split8=s8)                 # LayerNormA/B(m + att_b)
+            f = ops.gemm(x16.view(2 * rq, d) if not s8 else x16.view(2 * rq), ly["w1"], ly["c1"], act=ops.ACT_GELU)   # shared FFN :469-476
             t = ops.gemm(f, ly["w2"], ly["c2"], residual=x32.view(2 * rq, d), out_dtype=sdt)
-            h32, h16 = _ln(t, ly["g3"], ly["b3"], eps, dt, sd(i + 1))
-            h32, h16 = h32.view(2, rq, d), h16.view(2, rq, d)
+            h32, h16 = _ln(t, ly["g3"], ly["b3"], eps, dt, sd(i + 1), split8=s8)
+            h32, h16 = h32.view(2, rq, d), (h16.view(2, rq, d) if not s8 else h16.view(2, rq))
             if taps is not None:
                 hv = h32.view(2, t_n, lq, d)
                 taps.append((hv[0, :, 0, :8].float(), hv[1, :, 0, :8].float()))
         l = 1 if (self.trim_last and last > 0) else l
-        hid = h16.view(2, t_n, l, d)[:, :, 0, :].permute(1, 0, 2).reshape(t_n, 2 * d)                     # cat(CLS_0, CLS_1) :906-908
+        hcls = h32 if s8 else h16                                                                         # (split8: the fp32 stream copy holds the same values)
+        hid = hcls.view(2, t_n, l, d)[:, :, 0, :].permute(1, 0, 2).reshape(t_n, 2 * d)                    # cat(CLS_0, CLS_1) :906-908
         y = ops.gemm(hid, self.wc0, self.bc0, act=ops.ACT_RELU)                                           # blip_stage2.py:50-52
         return ops.small_linear(y, self.wc2, self.bc2)                                                    # blip_stage2.py:53
 

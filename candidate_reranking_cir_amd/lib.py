@@ -33,12 +33,19 @@ SIGNATURES = {
     "cir_gemm_ln_bias_act": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                                      c_int64, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "cir_split16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "cir_split8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "cir_gemm_split8": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+                                c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "cir_layernorm_split8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+                                     c_int64, c_int, c_int, c_float, c_void_p]),
     "cir_layernorm": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p,
                               c_int64, c_int64, c_int, c_int, c_float, c_int, c_void_p]),
     "cir_attention": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
                               c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                               c_void_p, c_int64, c_int64, c_int64,
                               c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "cir_attention_split8": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
+                                     c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "cir_cls_cross_attention": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "cir_cross_attention_folded": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
                                            c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),

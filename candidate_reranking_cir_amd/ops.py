@@ -115,12 +115,133 @@ def _gemm_split3(a, w_cat, bias, residual, act, out):
     (the exact-erf activation rides in the split pass that forms the next GEMM's operand)."""
     sa = a if isinstance(a, SplitOperand) else split16(a)
     assert act == ACT_NONE or residual is None, "activation and residual do not meet on this path"
+    n_rec = len(PROFILE_GEMM) if PROFILE_GEMM is not None else 0
     s_ = gemm(sa.cat, w_cat, bias, residual=residual, out_dtype=torch.float32, out=out)
+    if PROFILE_GEMM is not None and len(PROFILE_GEMM) > n_rec:      # record the USEFUL flops (2 m n k, not the 3 k deep launch) under a name of its own
+        fl, e0, e1, nbytes, name = PROFILE_GEMM[-1]
+        PROFILE_GEMM[-1] = (fl / 3.0, e0, e1, nbytes, name.replace("cir::", "cir::split3:"))
     if act == ACT_GELU:
         return split16(s_, ACT_GELU)
     if act == ACT_RELU:
         s_.relu_()
     return s_
+
+
+class Split8Operand:
+    """An fp32 matrix held as "split8" rows (include/cirrank.h: cir_split8): `.rows` is a uint8 tensor (..., 4K) =
+    [K x fp16(y) | K x e4m3((y - hi) 2^12) | K x e4m3(hi)] - the A operand of `cir_gemm_split8`.  Produced by `split8`, by the LayerNorm /
+    fp32-attention kernels' split outputs and by a split8 GEMM with a GELU (fc1 -> fc2: the FFN's intermediate never exists in fp32)."""
+    dtype = torch.float32
+
+    def __init__(self, rows: torch.Tensor, k: int):
+        assert rows.dtype == torch.uint8 and rows.shape[-1] == 4 * k and rows.stride(-1) == 1
+        self.rows, self.k, self.shape, self.device = rows, k, rows.shape[:-1] + (k,), rows.device
+
+    def dim(self):
+        return self.rows.dim()
+
+    def view(self, *lead) -> "Split8Operand":
+        """the same rows under other leading dimensions, e.g. (2, R, K) <-> (2 R, K)"""
+        return Split8Operand(self.rows.view(*lead, 4 * self.k), self.k)
+
+    def float(self) -> torch.Tensor:
+        """hi + lo as fp32 (diagnostics / tests: what the GEMM's first two terms see of the matrix)."""
+        k = self.k
+        hi = self.rows[..., :2 * k].contiguous().view(torch.float16).float()
+        lo = self.rows[..., 2 * k:3 * k].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** -12
+        return hi + lo
+
+
+def split8(x: torch.Tensor, act: int = ACT_NONE, out: Optional[torch.Tensor] = None) -> Split8Operand:
+    """fp32 (..., K) with contiguous rows and ONE row stride -> Split8Operand of act(x) (cir_split8)."""
+    _need_cuda(x, out)
+    assert x.dtype == torch.float32 and x.stride(-1) == 1
+    k = x.shape[-1]
+    x2 = x if x.dim() == 2 else x.reshape(-1, k) if x.is_contiguous() else None
+    if x2 is None:
+        if x.dim() == 3 and x.stride(0) == x.shape[1] * x.stride(1):
+            x2 = x.as_strided((x.shape[0] * x.shape[1], k), (x.stride(1), 1))
+        else:
+            x2 = x.contiguous().view(-1, k)
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (4 * k,), dtype=torch.uint8, device=x.device)
+    assert out.is_contiguous() and out.dtype == torch.uint8 and out.numel() == x2.shape[0] * 4 * k
+    _lib.check(_lib.load().cir_split8(x2.data_ptr(), x2.stride(0), out.data_ptr(), 4 * k, x2.shape[0], k, act, _stream()), "cir_split8")
+    return Split8Operand(out, k)
+
+
+def _e4m3(x: torch.Tensor) -> torch.Tensor:
+    """round-to-nearest-even e4m3 bytes of a clamped fp32 tensor (on the CPU when the device build lacks the cast)"""
+    x = x.clamp(-448.0, 448.0)
+    try:
+        return x.to(torch.float8_e4m3fn).view(torch.uint8)
+    except (RuntimeError, TypeError):
+        return x.cpu().to(torch.float8_e4m3fn).view(torch.uint8).to(x.device)
+
+
+def split_weight8(w32: torch.Tensor) -> torch.Tensor:
+    """Mark an fp32 weight (.., N, K) for the split8 path: rows [W_hi fp16 | e4m3(W_hi 2^e1) | e4m3(W_lo 2^e2)] with per-tensor exponents
+    that bring the largest |W_hi| / |W_lo| to [112, 224) (e4m3's top binades, clear of its 448 ceiling)."""
+    import math
+    hi = w32.to(torch.float16)
+    lo = w32 - hi.float()
+    e1 = int(math.floor(math.log2(224.0 / max(float(hi.float().abs().max()), 1e-30))))
+    e2 = int(math.floor(math.log2(224.0 / max(float(lo.abs().max()), 1e-30))))
+    e1, e2 = max(min(e1, 60), -60), max(min(e2, 60), -60)
+    rows = torch.cat([hi.contiguous().view(torch.uint8), _e4m3(hi.float() * 2.0 ** e1), _e4m3(lo * 2.0 ** e2)], dim=-1).contiguous()
+    w32._split8 = (rows, e1, e2)
+    return w32
+
+
+def _gemm_split8(a, wpack, bias, residual, act, out):
+    """act(a w^T + bias) (+ residual) on split8 operands (cir_gemm_split8): fp32 out, or - with a GELU - split8 rows out."""
+    rows_w, e1, e2 = wpack
+    sa = a if isinstance(a, Split8Operand) else split8(a)
+    _need_cuda(sa.rows, rows_w, bias, residual, out)
+    k = sa.k
+    batched = sa.rows.dim() == 3
+    a3 = sa.rows if batched else sa.rows.unsqueeze(0)
+    w3 = rows_w if rows_w.dim() == 3 else rows_w.unsqueeze(0)
+    nb, m, _ = a3.shape
+    n = w3.shape[1]
+    assert w3.shape[0] == nb and w3.shape[2] == 4 * k and a3.stride(2) == 1 and w3.stride(2) == 1
+    assert act == ACT_NONE or residual is None, "activation and residual do not meet on this path"
+    out_split = act == ACT_GELU
+    if out_split:
+        assert out is None
+        res = torch.empty((nb, m, 4 * n) if batched else (m, 4 * n), dtype=torch.uint8, device=a3.device)
+        o3 = res if batched else res.unsqueeze(0)
+        ldc, sc = o3.stride(1), o3.stride(0)
+    else:
+        if out is None:
+            out = torch.empty((nb, m, n) if batched else (m, n), dtype=torch.float32, device=a3.device)
+        res = out
+        o3 = out if out.dim() == 3 else out.unsqueeze(0)
+        assert o3.shape == (nb, m, n) and o3.stride(2) == 1 and o3.dtype == torch.float32
+        ldc, sc = o3.stride(1), o3.stride(0)
+    sb = 0
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.stride(-1) == 1
+        sb = bias.stride(0) if bias.dim() == 2 else 0
+    ldr = sr = 0
+    if residual is not None:
+        r3 = residual if residual.dim() == 3 else residual.unsqueeze(0)
+        assert r3.shape == (nb, m, n) and r3.stride(2) == 1 and r3.dtype == torch.float32
+        ldr, sr = r3.stride(1), r3.stride(0)
+    if PROFILE_GEMM is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    code = _lib.load().cir_gemm_split8(a3.data_ptr(), a3.stride(1), a3.stride(0), w3.data_ptr(), w3.stride(1), w3.stride(0), _ptr(bias), sb,
+                                       _ptr(residual), ldr, sr, o3.data_ptr(), ldc, sc, m, n, k, nb, act, int(out_split), e1, e2, _stream())
+    if PROFILE_GEMM is not None:
+        ev1.record()     # USEFUL flops (2 m n k): the two correction products are this path's overhead, not work done
+        alg_bytes = nb * ((m * k + n * k) * 4 + m * n * 4 + (m * n * 4 if residual is not None else 0) + (n * 4 if bias is not None else 0))
+        nblk256 = -(-m // 256) * -(-n // 256) * nb
+        name = "cir::gemm256_kernel<split8%s>" % (",split8-out" if out_split else (",residual" if residual is not None else "")) \
+            if (n >= 256 and nblk256 >= 192) else "cir::gemm_split8_kernel"
+        PROFILE_GEMM.append((2.0 * nb * m * n * k, ev0, ev1, float(alg_bytes), name))
+    _lib.check(code, "cir_gemm_split8")
+    return Split8Operand(res, n) if out_split else res
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
@@ -129,6 +250,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     mode on the f32-input MFMA - with contiguous rows (any row stride); w (N,K) / (B,N,K); bias fp32 (N) / (B,N); out in a.dtype (operand copy), fp32 or fp16 (residual
     stream, also from bf16 operands); residual shaped like out: fp32 (out in a.dtype or fp32) or fp16 (with an fp16 out; the only
     residual an fp16 out from bf16 operands takes)."""
+    if isinstance(a, Split8Operand) or (not isinstance(a, SplitOperand) and a.dtype == torch.float32 and getattr(w, "_split8", None) is not None):
+        assert out_dtype in (None, torch.float32) and getattr(w, "_split8", None) is not None
+        return _gemm_split8(a, w._split8, bias, residual, act, out)
     if isinstance(a, SplitOperand) or (a.dtype == torch.float32 and getattr(w, "_split3", None) is not None):
         assert out_dtype in (None, torch.float32) and getattr(w, "_split3", None) is not None
         return _gemm_split3(a, w._split3, bias, residual, act, out)
@@ -245,6 +369,57 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
                                      float(eps), d16, _stream())
     _lib.check(code, "cir_layernorm")
     return out32, out16
+
+
+def layernorm_split8(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, residual: Optional[torch.Tensor] = None,
+                     want_stream: bool = True):
+    """LayerNorm of fp32 stream rows -> (fp32 stream copy or None, Split8Operand of the same values): cir_layernorm_split8.  Shapes and
+    broadcasting as `layernorm` (x / residual (rows, cols) or (B, rows, cols), gamma / beta (cols) or (B, cols))."""
+    _need_cuda(x, gamma, beta, residual)
+    x3 = x if x.dim() == 3 else x.unsqueeze(0)
+    nb = max(x3.shape[0], gamma.shape[0] if gamma.dim() == 2 else 1, (residual.shape[0] if residual is not None and residual.dim() == 3 else 1))
+    rows, cols = x3.shape[1], x3.shape[2]
+    assert x3.dtype == torch.float32 and x3.stride(2) == 1 and x3.stride(1) == cols
+    shape = (nb, rows) if (x.dim() == 3 or nb > 1) else (rows,)
+    ys = torch.empty(shape + (cols,), dtype=torch.float32, device=x.device) if want_stream else None
+    sp = torch.empty(shape + (4 * cols,), dtype=torch.uint8, device=x.device)
+    sx = x3.stride(0) if x3.shape[0] > 1 else 0
+    sr = 0
+    if residual is not None:
+        r3 = residual if residual.dim() == 3 else residual.unsqueeze(0)
+        assert r3.dtype == torch.float32 and r3.stride(2) == 1 and r3.stride(1) == cols
+        sr = r3.stride(0) if r3.shape[0] > 1 else 0
+    sg = gamma.stride(0) if gamma.dim() == 2 else 0
+    code = _lib.load().cir_layernorm_split8(x3.data_ptr(), sx, _ptr(residual), sr, gamma.data_ptr(), beta.data_ptr(), sg, _ptr(ys), rows * cols,
+                                            sp.data_ptr(), 4 * cols, rows * 4 * cols, rows, cols, nb, float(eps), _stream())
+    _lib.check(code, "cir_layernorm_split8")
+    return ys, Split8Operand(sp, cols)
+
+
+def attention_split8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, mask: Optional[torch.Tensor] = None) -> Split8Operand:
+    """fp32 attention (the `attention` contract with fp32 tensors) whose context comes out as split8 rows: (B1, B0, Lq, H*64) Split8Operand."""
+    _need_cuda(q, k, v, mask)
+    b1, b0, lq, d = q.shape
+    lk = k.shape[2]
+    assert k.shape == (b1, b0, lk, d) and v.shape == k.shape and d % 64 == 0
+    assert q.dtype == k.dtype == v.dtype == torch.float32 and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
+    out = torch.empty((b1, b0, lq, 4 * d), dtype=torch.uint8, device=q.device)
+    ms1 = ms0 = 0
+    if mask is not None:
+        assert mask.dtype == torch.float32 and mask.shape == (b1, b0, lk) and mask.stride(2) == 1
+        ms1, ms0 = mask.stride(0), mask.stride(1)
+    if PROFILE_ATTN is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    code = _lib.load().cir_attention_split8(
+        q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), k.data_ptr(), k.stride(0), k.stride(1), k.stride(2),
+        v.data_ptr(), v.stride(0), v.stride(1), v.stride(2), _ptr(mask), ms1, ms0,
+        out.data_ptr(), out.stride(0), out.stride(1), out.stride(2), b1, b0, d // 64, lq, lk, float(scale), _stream())
+    if PROFILE_ATTN is not None:
+        ev1.record()
+        PROFILE_ATTN.append((4.0 * b1 * b0 * lq * lk * d, ev0, ev1, (lq, lk)))
+    _lib.check(code, "cir_attention_split8")
+    return Split8Operand(out, d)
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, scale: float,

@@ -27,10 +27,16 @@ from .train import _Lin, _LN, _Slab, _cast, _install_grads
 _P = "visual_encoder."
 
 
+def vit_train_dtype(model) -> torch.dtype:
+    """Operand type of the ViT's training step: the model's token type when it is 16-bit, fp16 under the exact mode (fp32 tokens) - the
+    same mapping `train.train_dtype` applies to the text side (the reference trains under fp16 autocast, stage2_train.py:210-218)."""
+    return model.token_dtype if model.token_dtype in (torch.float16, torch.bfloat16) else torch.float16
+
+
 class VitTrainer:
     def __init__(self, model):
         self.model, self.geo = model, model.vit_geometry
-        self.dtype = model.token_dtype
+        self.dtype = vit_train_dtype(model)
         self._scale = 64 ** -0.5                                                    # vit.py:50 (head dimension 64)
         self.seed, self.step_no = 0, 0
 
@@ -225,7 +231,7 @@ class _VitTrainFn(torch.autograd.Function):
 def vit_train(model, image: torch.Tensor) -> torch.Tensor:
     """(B, N, D) fp32 image tokens of `img_embed` in training mode, differentiable w.r.t. the model's visual_encoder parameters."""
     tr = getattr(model, "_vit_trainer", None)
-    if tr is None or tr.dtype != model.token_dtype:
+    if tr is None or tr.dtype != vit_train_dtype(model):
         tr = model._vit_trainer = VitTrainer(model)
         tr.anchor = torch.zeros((1,), device=model.device, requires_grad=True)
     return _VitTrainFn.apply(tr.anchor, tr, image.to(model.device))

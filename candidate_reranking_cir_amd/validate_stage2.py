@@ -142,8 +142,9 @@ def generate_val_predictions(blip_model, model_stage1, ds: RelativeValSet, index
     # a checkpoint whose pre-LayerNorm sums exceed 65504 would turn into inf -> NaN logits instead of an error.
     bad = ~torch.isfinite(logits).all() if glogits is None else ~(torch.isfinite(logits).all() & torch.isfinite(glogits).all())
     if bool(bad):
-        raise FloatingPointError("non-finite logits: the residual stream overflowed its storage format - call "
-                                 "model.set_stream_dtype(torch.float32) on both models (DESIGN.md section 2)")
+        raise FloatingPointError("non-finite logits: a value left fp16's range (65504) - in the 16-bit modes the residual stream's storage: call "
+                                 "model.set_stream_dtype(torch.float32) on both models; in 'text32' (fp32 stream already) an fp16 operand term of "
+                                 "the text side: call model.set_precision('exact') on both models (DESIGN.md section 2)")
     return (logits, glogits) if glogits is not None else logits
 
 

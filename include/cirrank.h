@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CIR_ABI_VERSION 13
+#define CIR_ABI_VERSION 14
 
 enum { CIR_BF16 = 0, CIR_F16 = 1, CIR_F32 = 2 };
 enum { CIR_ACT_NONE = 0, CIR_ACT_GELU = 1, CIR_ACT_RELU = 2 };
@@ -118,6 +118,57 @@ int cir_gemm_ln_bias_act(const void* X, int64_t ldx, const void* Wg, int64_t ldw
  *   three products approximate).
  */
 int cir_split16(const float* x, int64_t ldx, void* hi, void* lo, void* hi2, int64_t ldo, int64_t rows, int cols, int act, void* stream);
+
+/*
+ * "split8" operand rows (ABI v14, round 6): y = act(x) as three byte segments per row,
+ *     [ hi: cols x fp16 = fp16(y) | lo8: cols x e4m3 = e4m3((y - hi) 2^12) | hi8: cols x e4m3 = e4m3(hi) ]      = 4 cols bytes,
+ *   both e4m3 terms clamped to +-448 first (OCP e4m3 has no infinity; the conversion does not saturate).  x (rows, cols) fp32 with leading
+ *   dimension ldx (elements); out rows ldo_bytes apart.  act as cir_split16, GELU by an erf good to 1.5e-7.  cols % 16 == 0, 16-byte aligned.
+ *   The A operand of cir_gemm_split8.  No reference counterpart (see there).
+ */
+int cir_split8(const float* x, int64_t ldx, void* out, int64_t ldo_bytes, int64_t rows, int cols, int act, void* stream);
+
+/*
+ * cir_attention on fp32 tensors (the CIR_F32 form: fp32 products, fp32 softmax) with the context written as split8 rows (ABI v14):
+ *   out row (b1, b0, query) = [H*64 x fp16 | H*64 x e4m3 lo | H*64 x e4m3 hi] at out + b1 o_s1_bytes + b0 o_s0_bytes + query o_rs_bytes.
+ *   Replaces BertSelfAttention.forward's core (nlvr_encoder.py:140-222, med.py:158-240) + the operand split in front of the attention
+ *   output projection (nlvr_encoder.py:230-236) in the "text32" precision mode.  Strides of q / k / v in elements (% 4), of out in bytes (% 16).
+ */
+int cir_attention_split8(const float* q, int64_t q_s1, int64_t q_s0, int64_t q_rs, const float* k, int64_t k_s1, int64_t k_s0, int64_t k_rs,
+                         const float* v, int64_t v_s1, int64_t v_s0, int64_t v_rs, const float* mask, int64_t m_s1, int64_t m_s0,
+                         void* out, int64_t o_s1_bytes, int64_t o_s0_bytes, int64_t o_rs_bytes, int B1, int B0, int H, int Lq, int Lk,
+                         float scale, void* stream);
+
+/*
+ * cir_layernorm on fp32 stream rows with the operand copy written as split8 rows (ABI v14): y_stream (fp32, may be NULL) as cir_layernorm
+ *   writes it (bit for bit), y_split (batch, rows) rows of 4 cols bytes [fp16 | e4m3 lo | e4m3 hi] ld_split_bytes / stride_split_bytes apart.
+ *   x / residual / y_stream strides per batch item in elements; gamma / beta (cols) or per batch item (strideG).  cols % 16 == 0, cols <= 1024.
+ *   Replaces LayerNorm + the operand split in front of the text side's qkv and fc1 Linears (nlvr_encoder.py:262-264 / 469-476 -> :105-107 / 399).
+ */
+int cir_layernorm_split8(const float* x, int64_t strideX, const float* residual, int64_t strideR, const float* gamma, const float* beta,
+                         int64_t strideG, float* y_stream, int64_t strideY, void* y_split, int64_t ld_split_bytes, int64_t stride_split_bytes,
+                         int64_t rows, int cols, int batch, float eps, void* stream);
+
+/*
+ * C[b] = act(A[b] W[b]^T + bias[b]) (+ residual[b]) for a fp32 Linear whose operands travel as split8 rows (ABI v14; replaces the
+ *   torch.nn.Linear calls of the text side - nlvr_encoder.py:105-107 / 230-236 / 399 / 411, med.py the same - in the "text32" precision
+ *   mode, where the reference computes in fp32: validate_stage2.py:140-141):
+ *     A (batch, M, K) rows [A_hi fp16 | e4m3(A_lo 2^12) | e4m3(A_hi)]           (cir_split8 / cir_layernorm_split8 / cir_attention_split8 /
+ *                                                                                 this function with out_split = 1)
+ *     W (batch, N, K) rows [W_hi fp16 | e4m3(W_hi 2^w_exp_hi) | e4m3(W_lo 2^w_exp_lo)],  W_hi = fp16(W), W_lo = W - W_hi
+ *   ONE launch forms  A_hi W_hi^T  on the fp16 MFMA  +  A_lo W_hi^T + A_hi W_lo^T  on the block-scaled fp8 MFMA
+ *   (v_mfma_scale_f32_16x16x128_f8f6f4, E8M0 scales 2^-12, 2^-w_exp_hi, 2^-w_exp_lo: twice the fp16 rate) in one fp32 accumulator that
+ *   starts at the bias: the corrections are 2^-11 of the result and keep 4 significant bits per factor -> ~2^-16 of the result, against
+ *   2^-11 for one fp16 product; cost 2 K / 64 K-tiles (three fp16 products: 3 K / 64; the f32-input MFMA: 16 K / 64).
+ *   lda / ldw / strides in BYTES (rows are 4 K bytes long), K % 256 == 0, N % 16 == 0, 16-byte aligned.
+ *   out_split 0: C (batch, M, N) fp32, ldc / strideC in elements, residual fp32 or NULL (only with CIR_ACT_NONE);
+ *   out_split 1: C = split8 rows of act(.) (the next GEMM's operand: fc1 -> fc2), ldc / strideC in BYTES (>= 4 N), N % 64 == 0, no residual.
+ *   The 128 x 128 and the persistent 256 x 256 kernel are chosen as in cir_gemm_bias_act and give the same bits.
+ */
+int cir_gemm_split8(const void* A, int64_t lda_bytes, int64_t strideA_bytes, const void* W, int64_t ldw_bytes, int64_t strideW_bytes,
+                    const float* bias, int64_t strideBias, const float* residual, int64_t ldr, int64_t strideR,
+                    void* C, int64_t ldc, int64_t strideC, int64_t M, int N, int K, int batch, int act, int out_split,
+                    int w_exp_hi, int w_exp_lo, void* stream);
 
 /*
  * y[b] = LayerNorm(x[b] (+ residual[b]); gamma[b], beta[b], eps) over the last dimension.

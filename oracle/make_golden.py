@@ -29,6 +29,8 @@ and `.weights`, so fixtures hold only seeds, small input checksums and the refer
                   reference's generate_cirr_val_predictions at K=100 (+5): what pins the fp16 residual stream (`make_golden.py outlier`).
   rank224_wide.npz / outlier224_wide.npz  the two rank fixtures regrown to >= 16 scored queries per case (`make_golden.py wide rank`,
                   `make_golden.py wide outlier`; round 5).
+  rank384.npz     rank fixture at the reference's OWN geometry (384 px, 577 tokens) through its extract_index_features and
+                  both prediction loops (`make_golden.py rank384`; round 6).
   vitl_tiny.npz   the reference's ViT-large encoder (depth 24, width 1024, 16 heads) at 64 px (`make_golden.py vitl`).
   bxb224.npz      training-mode surface `BLIP_NLVR.img_txt_fusion` (blip_stage2.py:65-99) in eval mode: B=4 ragged
                   captions (padding='longest' -> real masks) -> (B,B) logits (`make_golden.py rank`).
@@ -446,6 +448,89 @@ def rank_goldens(R, ref_val, full_bert):
     print("bxb224 logits", bxb.numpy().round(4))
 
 
+class FakeClassicScene(FakeClassic):
+    """'classic' mode dataset of STRUCTURED images (synthetic.scene_image), for extract_index_features."""
+
+    def __getitem__(self, i):
+        return self.names[i], synthetic.scene_image(int(self.names[i][3:]), self.size)
+
+
+def rank384_goldens(R, ref_utils, ref_val, full_bert):
+    """tests/golden/rank384.npz (round 6): a rank fixture at the REFERENCE'S OWN geometry - 384 px, 577 image tokens
+    (validate_stage2.py:327-331; utils.py:46 hard-codes the 577).  A 128-image bank of structured images goes through the
+    reference's `extract_index_features` (utils.py:25-55, its DataLoader included); `generate_cirr_val_predictions` scores 3 queries
+    at K = 100 (+5 subset; one of them skipped) and `generate_fiq_val_predictions` 4 queries at K = 50 (two captions joined by the
+    reference, validate_stage2.py:97-100); targets sit on candidates whose Recall@k membership is decided by a margin, and the
+    reference's own `compute_*_val_metrics` give the recall tuples.  `make_golden.py rank384`, ~8 minutes of CPU."""
+    m2, m1, g, v = build_reference_models(R, full_bert, dict(image_size=384, width=768, depth=12, num_heads=12), seed=21, profile="test")
+    n_index = 128
+    names = ["img%04d" % i for i in range(n_index)]
+    bank, index_names = ref_utils.extract_index_features(FakeClassicScene(names, 384), m2, blip_stage2=True)
+    assert list(index_names) == names and tuple(bank.shape) == (n_index, 577, 768)
+    rng = np.random.RandomState(384)
+    margin = 4 * RANK_TOL
+    out = dict(seed=21, profile="test", n_index=n_index, tol_unit=RANK_TOL, bank_slice=bank[:, :3, :8].numpy(), bank_sum=bank.double().sum().item())
+    saved = (ref_val.generate_fiq_val_predictions, ref_val.generate_cirr_val_predictions)
+    # ---- CIRR style, K = 100 (+5 subset): two scored queries and one skipped row (pass 1 picks margin-decided targets, pass 2 is the fixture)
+    n_q, k, want = 3, 100, (2, 30, None)
+    refs = rng.randint(0, n_index, n_q)
+    cand = np.stack([rng.permutation(n_index)[:k] for _ in range(n_q)])
+    groups = np.stack([np.array([j for j in rng.permutation(n_index) if j != refs[q] and j not in cand[q]][:5]) for q in range(n_q)])
+    caps = [synthetic.caption_text(3840 + q, 30) for q in range(n_q)]
+    ds = FakeCIRR(names, refs, cand[:, 0], caps, cand, np.ones((n_q, k), dtype=bool), groups)
+    logits, glogits, *_ = ref_val.generate_cirr_val_predictions(m2, m1, ds, names, bank)
+    logits, glogits = logits.numpy(), glogits.numpy()
+    labels = np.zeros((n_q, k), dtype=bool)
+    targets = np.zeros(n_q, dtype=np.int64)
+    for q in range(n_q):
+        slot = q % 5
+        if want[q] is None:
+            targets[q] = groups[q][_pick_robust(glogits[q], 1, margin, (1, 2, 3))]
+            continue
+        ci = _pick_robust(logits[q], want[q], margin, (1, 5, 10, 50), also=lambda i: _robust(glogits[q], logits[q][i], slot, margin, (1, 2, 3)))
+        labels[q, ci] = True
+        targets[q] = cand[q, ci]
+        groups[q, slot] = cand[q, ci]
+    ds = FakeCIRR(names, refs, targets, caps, cand, labels, groups)
+    logits2, glogits2, _, tnames, gnames = ref_val.generate_cirr_val_predictions(m2, m1, ds, names, bank)
+    l2, g2 = logits2.numpy(), glogits2.numpy()
+    for q in range(n_q):
+        gi = int(np.where(groups[q] == targets[q])[0][0])
+        assert _robust(g2[q], g2[q][gi], gi, margin, (1, 2, 3))
+        if labels[q].any():
+            ci = int(labels[q].argmax())
+            assert _robust(l2[q], l2[q][ci], ci, margin, (1, 5, 10, 50)) and abs(l2[q][ci] - g2[q][gi]) < 1e-5
+        else:
+            assert np.all(l2[q] == np.float32(-99999.99))
+    ref_val.generate_cirr_val_predictions = lambda *a, **kw: (logits2, glogits2, None, tnames, gnames)
+    try:
+        metrics = ref_val.compute_cirr_val_metrics(ds, None, None, None, None)
+    finally:
+        ref_val.generate_cirr_val_predictions = saved[1]
+    out.update(c100_refs=refs, c100_cand=cand, c100_groups=groups, c100_caps=np.array(caps), c100_labels=labels, c100_targets=targets,
+               c100_logits=l2, c100_group_logits=g2, c100_metrics=np.array(metrics))
+    print(f"rank384 c100: metrics {np.round(metrics, 2)}  logit std {l2[labels.any(1)].std():.4f}")
+    # ---- FashionIQ style, K = 50, 4 queries -------------------------------------------------------------------------
+    n_q, k = 4, 50
+    refs = rng.randint(0, n_index, n_q)
+    cand = np.stack([rng.permutation(n_index)[:k] for _ in range(n_q)])
+    fcaps = [(synthetic.caption_text(3900 + q, 14) + ".", "  " + synthetic.caption_text(3950 + q, 15) + "?") for q in range(n_q)]
+    ds = FakeFIQ(names, refs, cand[:, 0], fcaps, cand, np.ones((n_q, k), dtype=bool))
+    logits, _ = ref_val.generate_fiq_val_predictions(m2, m1, ds, names, bank)
+    labels = np.zeros((n_q, k), dtype=bool)
+    for q, w in enumerate((1, 6, 20, 40)):
+        labels[q, _pick_robust(logits.numpy()[q], w, margin, (10, 50))] = True
+    ds = FakeFIQ(names, refs, cand[np.arange(n_q), labels.argmax(1)], fcaps, cand, labels)
+    ref_val.generate_fiq_val_predictions = lambda *a, **kw: (logits, None)
+    try:
+        fmetrics = ref_val.compute_fiq_val_metrics(ds, None, None, None, None)
+    finally:
+        ref_val.generate_fiq_val_predictions = saved[0]
+    out.update(f50_refs=refs, f50_cand=cand, f50_caps=np.array(fcaps), f50_labels=labels, f50_logits=logits.numpy(), f50_metrics=np.array(fmetrics))
+    print(f"rank384 f50: metrics {np.round(fmetrics, 2)}  logit std {logits.numpy().std():.4f}")
+    np.savez_compressed(os.path.join(OUT, "rank384.npz"), **out)
+
+
 def outlier_goldens(R, ref_val, full_bert):
     """tests/golden/outlier224.npz: the benchmark geometry with the OUTLIER weight profile (weights._apply_outliers: the
     reference's ViT residual stream reaches 1e2..1e3 in three channels, its BERT LayerNorms carry 6x / +-4 channels)
@@ -858,6 +943,14 @@ def main():
         _, ref_val = _import_reference_scripts()
         full_bert = json.load(open(os.path.join(ref_shim.REFERENCE_ROOT, "configs", "med_config.json")))
         return wide_goldens(R, ref_val, full_bert, sys.argv[2])
+    if len(sys.argv) > 1 and sys.argv[1] == "rank384":  # only the 384-px rank fixture (round 6)
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        R = ref_shim.load_reference_modules()
+        _install_torchvision_stub()
+        ref_utils, ref_val = _import_reference_scripts()
+        full_bert = json.load(open(os.path.join(ref_shim.REFERENCE_ROOT, "configs", "med_config.json")))
+        return rank384_goldens(R, ref_utils, ref_val, full_bert)
     if len(sys.argv) > 1 and sys.argv[1] == "rank":     # only the rank-order / B x B fixtures
         torch.manual_seed(0)
         torch.set_num_threads(8)

@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_symbol():
     cdll = lib.load()
     for name in _declared():
         assert hasattr(cdll, name), name
-    assert cdll.cir_version() == 13
+    assert cdll.cir_version() == 14
     assert b"aligned" in cdll.cir_strerror(-3)
 
 

@@ -40,7 +40,8 @@ MODES = {
     "f16 | streams f16, fusion layers 3-11 text stream f32": (HF, None, HF, "same", 3),
     "f16 | ViT stream f16, text f32": (HF, None, F32, HF),
     "f16 | streams f32": (HF, None, F32, "same"),
-    "text32 (text side: fp32 rows, 3-product fp16 GEMMs, fp32 stream; ViT + cross block f16)": (F32, HF, F32, HF),
+    "text32 (text side: fp32 rows as split8 - fp16 + 2 scaled-fp8 products, fp32 stream; ViT + cross block f16)": (F32, HF, F32, HF, None, 8),
+    "text32x3 (round 5: text side as three fp16 products on [hi|lo|hi] rows)": (F32, HF, F32, HF, None, 3),
     "exact (fp32 everywhere, f32-input MFMA)": (F32, None, F32, "same"),
 }
 
@@ -55,6 +56,7 @@ def apply(m, mode):
     if hasattr(m, "set_text_stream32_from"):                       # (the stage-I model has no two-branch encoder)
         m.set_text_stream32_from(MODES[mode][4] if len(MODES[mode]) > 4 else None)
     if dt == F32:
+        m.text_split3 = MODES[mode][5] if len(MODES[mode]) > 5 else 8
         return m.set_precision("exact" if idt is None else "text32")
     if m.compute_dtype == F32:
         m.set_precision("f16")
