@@ -38,7 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2516.6, "f16": 2516.6, "mixed": 2516.6, "text32": 2516.6,  # dense 16-bit MFMA peak, 256 CU x 2.4 GHz x 4096 flop/clk/CU (MI355X_MICROARCH.md); text32: the 16-bit peak too (a mixed path: its text side runs on the f32-input MFMA)
+PEAK_TFLOPS = {"bf16": 2516.6, "f16": 2516.6, "mixed": 2516.6, "text32": 2516.6, "text32x3": 2516.6,  # dense 16-bit MFMA peak, 256 CU x 2.4 GHz x 4096 flop/clk/CU (MI355X_MICROARCH.md); text32: the 16-bit peak too (its algorithmic flops are priced as 16-bit work; the fp8 correction products are overhead, not credit)
                "exact": 157.3}                                  # f32-input MFMA: 256 CU x 2.4 GHz x 256 flop/clk/CU (same guide: 1/16 of the 16-bit rate)
 _STREAMS = {"f16": ("f16", "f16"), "f32": ("f32", "f32"), "split": ("f32", "f16")}     # name -> (text-side storage, ViT storage)
 
@@ -47,7 +47,7 @@ def apply_precision(model, dtype: str, stream: str):
     """`dtype`: operand precision mode (BLIP_NLVR.set_precision: bf16 / f16 / mixed); `stream`: residual-stream storage -
     auto (the library's rule), f16, f32, or split (text side fp32, ViT fp16).  Returns the model."""
     model.set_precision(dtype)
-    if dtype in ("exact", "text32"):     # the streams follow the mode (set_precision did it): fp32 everywhere / fp32 text side over an fp16 ViT
+    if dtype in ("exact", "text32", "text32x3"):     # the streams follow the mode (set_precision did it): fp32 everywhere / fp32 text side over an fp16 ViT
         return model
     if stream == "auto":
         return model.set_stream_dtype(None, vit=None)
@@ -64,8 +64,10 @@ PRECISION_NOTE = {"f16": "fp16 MFMA operands everywhere, fp32 accumulate (the li
                   "bf16": "bf16 MFMA operands everywhere, fp32 accumulate",
                   "exact": "fp32 everywhere like the reference (model.float()): f32-input MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32), fp32 streams, erf GELU, "
                            "no algebraic folds - the mode that holds the reference's rank order (DESIGN.md section 2)",
-                  "text32": "fp32 operands (f32-input MFMA), fp32 stream and erf GELU for the text side (self-attention, FFN, cls_head of both text encoders); fp16 ViT and "
-                            "cross-attention block - most of the exact mode's rank fidelity at 3.7 x its throughput (DESIGN.md section 2)",
+                  "text32": "text side (self-attention, FFN, cls_head of both text encoders) on fp32 rows carried as split8 operands - one fp16 MFMA product + two block-scaled "
+                            "fp8 correction products per Linear in one fp32 accumulator (~16 bits), fp32 stream, fp32 self-attention, erf GELU; fp16 ViT and cross-attention block - "
+                            "what the factories set for real weights (DESIGN.md section 2)",
+                  "text32x3": "round 5's form of text32: the text side's Linears as three fp16 MFMA products on [hi | lo | hi] rows (~20 bits); fp16 ViT and cross-attention block",
                   "mixed": "bf16 operands for the ViT and the cross-attention block, fp16 for text-side self-attention / FFN / cls_head; fp32 accumulate"}
 D, H, F, LAYERS = 768, 12, 3072, 12
 
@@ -143,7 +145,7 @@ def cpu_baseline(threads: int, per_query: int = 105):
                       % (reps, n_img, t_vit, n_q, t_s1, n_fq, k, t_fuse, per_query)}
 
 
-def rank_fidelity_block(scored, scored_x, active, k, ns, exact_ms, n_cand, recs_x):
+def rank_fidelity_block(scored, scored_x, active, k, ns, exact_ms=None, n_cand=0, recs_x=None):
     """This run's logits against the EXACT mode's on the same step (same pixels, ids, weights): per scored query the fraction of
     sorted top-K positions that hold the same candidate, Kendall's tau, the top-10 overlap and top-1 agreement; likewise for the
     5-member subsets.  The exact mode is fp32 on the f32-input MFMA and is pinned to the reference's own outputs (logits 2e-6, sorted
@@ -178,6 +180,8 @@ def rank_fidelity_block(scored, scored_x, active, k, ns, exact_ms, n_cand, recs_
         ex, tau, ov, t1 = stats(sub_rows, min(3, ns))
         out["subset"] = {"queries": len(sub_rows), "exact_positions": round(float(np.mean(ex)), 4), "kendall_tau": round(float(np.mean(tau)), 5),
                          "top3_overlap": round(float(np.mean(ov)), 4), "top1_agree": round(float(np.mean(t1)), 4)}
+    if exact_ms is None:
+        return out
     gf = sum(r[0] for r in recs_x); gms = sum(r[1].elapsed_time(r[2]) for r in recs_x)
     out["exact_mode"] = {"triplets_per_s": round(n_cand / (exact_ms * 1e-3), 1), "ms_per_step": round(exact_ms, 1),
                          "gemm_kernel": "cir::gemm_kernel<float,1> (v_mfma_f32_16x16x4_f32)", "gemm_tflops": round(gf / (gms * 1e-3) / 1e12, 1),
@@ -621,7 +625,7 @@ def main():
     ap.add_argument("--skip-rate", type=float, default=0.0, help="fraction of queries without a positive in their top-K (skip rule)")
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--tokens", type=int, default=32)
-    ap.add_argument("--dtype", default=DEFAULT_DTYPE, choices=["bf16", "f16", "mixed", "text32", "exact"],
+    ap.add_argument("--dtype", default=DEFAULT_DTYPE, choices=["bf16", "f16", "mixed", "text32", "text32x3", "exact"],
                     help="MFMA operand precision (fp32 accumulate in all): exact = fp32 everywhere on the f32-input MFMA (the reference's precision), f16, bf16, or mixed = bf16 for the ViT and the cross-attention "
                          "block, fp16 for the text-side self-attention / FFN / cls_head (DESIGN.md section 2: rank fidelity per mode)")
     ap.add_argument("--stream-dtype", default="auto", choices=["auto", "f16", "f32", "split"],
@@ -834,6 +838,13 @@ def main():
     fidelity = None
     if world == 1 and not args.no_rank_fidelity and args.dtype != "exact":
         ref_scored = step().clone()
+        t32_scored = None
+        if args.dtype not in ("text32", "text32x3"):                  # the mode the factories set for real weights, on the same step and referee
+            apply_precision(m2, "text32", "auto"); apply_precision(m1, "text32", "auto")
+            toks = m2.img_embed16(images.to(m2.token_dtype))
+            z = m1.z_t(toks[:q_n], ids, mask)
+            t32_scored = m2.score(z.last_hidden_state, ids, mask, toks[q_n:], qidx).clone()
+            del toks, z
         apply_precision(m2, "exact", "auto"); apply_precision(m1, "exact", "auto")
         images_x = images.float()                                      # the same (16-bit-rounded) pixel values, as fp32 tensors
         def xstep():
@@ -845,6 +856,9 @@ def main():
         tx = time.perf_counter(); scored_x = xstep(); torch.cuda.synchronize(); exact_ms = (time.perf_counter() - tx) * 1e3
         recs_x, ops.PROFILE_GEMM = ops.PROFILE_GEMM, None
         fidelity = rank_fidelity_block(ref_scored, scored_x, active, k, ns, exact_ms, n_cand, recs_x)
+        if t32_scored is not None:
+            fidelity["text32"] = rank_fidelity_block(t32_scored, scored_x, active, k, ns)
+            fidelity["text32"]["mode"] = PRECISION_NOTE["text32"]
         del images_x, scored_x
         apply_precision(m2, args.dtype, args.stream_dtype); apply_precision(m1, args.dtype, args.stream_dtype)
         m2.engines(); m1.engines()
@@ -854,9 +868,10 @@ def main():
     precision = None
     if world == 1 and not args.no_precision_table and not args.no_cpu_baseline:
         precision = {f"{args.dtype}+{args.stream_dtype}_stream": round(total_cand * args.steps / elapsed, 1)}
-        for od, sd_ in (("f16", "f16"), ("f16", "split"), ("f16", "f32"), ("mixed", "f16"), ("bf16", "f16"), ("bf16", "f32"), ("text32", "split")):
-            if (od, sd_) == (args.dtype, args.stream_dtype) or od == args.dtype == "text32":
+        for od, sd_ in (("f16", "f16"), ("f16", "split"), ("f16", "f32"), ("mixed", "f16"), ("bf16", "f16"), ("bf16", "f32"), ("text32", "split"), ("text32x3", "split")):
+            if (od, sd_) == (args.dtype, args.stream_dtype) or od == args.dtype:
                 continue
+            n_steps = args.steps if od == "text32" else 3             # the real-weights mode at the headline's step count
             apply_precision(m2, od, sd_); apply_precision(m1, od, sd_)
             images_v = images.to(m2.token_dtype)
             def vstep():
@@ -865,14 +880,14 @@ def main():
                 return m2.score(z.last_hidden_state, ids, mask, toks[q_n:], qidx)
             vstep(); torch.cuda.synchronize()
             tv = time.perf_counter()
-            for _ in range(3):
+            for _ in range(n_steps):
                 vstep()
             torch.cuda.synchronize()
-            precision[f"{od}+{sd_}_stream"] = round(n_cand * 3 / (time.perf_counter() - tv), 1)
+            precision[f"{od}+{sd_}_stream"] = round(n_cand * n_steps / (time.perf_counter() - tv), 1)
             del images_v
-        precision["note"] = ("triplets/s of the same step at each operand mode + residual-stream storage (3 steps each; split = text side fp32, "
-                             "ViT fp16; text32 = text side on fp32 rows as 3-product fp16 GEMMs over the fp16 ViT / cross block).  Rank fidelity of every mode against the reference's fp32 outputs: profiles/r5_precision_modes.json, "
-                             "DESIGN.md section 2")
+        precision["note"] = (f"triplets/s of the same step at each operand mode + residual-stream storage (3 steps each, text32 - what the factories set for real weights - {args.steps} steps "
+                             "like the headline; split = text side fp32, ViT fp16; text32 = text side on split8 rows (fp16 + 2 scaled-fp8 products), text32x3 = three fp16 products, both over the "
+                             "fp16 ViT / cross block).  Rank fidelity of every mode against the reference's fp32 outputs: profiles/r6_precision_modes.json, DESIGN.md section 2")
 
     if rank == 0:
         n_tok = (args.image_size // 16) ** 2 + 1
@@ -891,7 +906,7 @@ def main():
         # HBM bytes per launch of the dominant kernel: offline PMC passes of this same command (tools/collect_profiles.sh); the
         # summary names the workload and the hash of the kernel sources it was measured on - any other build reports null
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r5_pmc_summary.json")
+        tpath = os.path.join(ROOT, "profiles", "r6_pmc_summary.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             same = (tj.get("csrc_sha16") == csrc_sha16() and tj.get("queries") == q_n and tj.get("k") == k and tj.get("subset") == ns
@@ -900,7 +915,7 @@ def main():
             ent = tj.get("by_kernel", {}).get(dom_name) if same else None
             if ent:
                 traffic = round(ent["hbm_bytes_per_launch"])
-                traffic_src = ("profiles/r5_pmc_summary.json: offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these "
+                traffic_src = ("profiles/r6_pmc_summary.json: offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these "
                                "kernel sources (csrc_sha16 matches; not this run)")
         line = {
             "metric": "query-candidate triplets scored/sec at K=100", "value": round(value, 2), "unit": "triplets/s",

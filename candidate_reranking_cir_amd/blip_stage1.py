@@ -98,10 +98,7 @@ def blip_stage1(pretrained: str = "", **kwargs) -> BLIP_Retrieval:
         model, msg = load_stage1_checkpoint(model, pretrained)      # blip.py:215-237 semantics
         print("missing keys:")
         print(msg.missing_keys)
-        # Real weights: "text32" (round 5) - the text side on fp32 rows as 3-product fp16 GEMMs (~20 bits), fp32 text stream, erf GELU; ViT and
-        # cross-attention block fp16.  Pretrained checkpoints carry outlier channels: on the fixture that mimics them the all-fp16 path holds
-        # tau 0.81 of the reference's order and the split-stream setting of round 4 0.86, this mode 0.99 (0.98 / 0.95 / 0.99 of the K = 100 /
-        # 200 / 50 positions exactly) at 0.67 x the default's throughput.  Random-init models and the benchmark keep
-        # the all-fp16 default; `set_precision("f16")` returns to it.
+        # Real weights: "text32" - the text side on fp32 rows as split8 operands (fp16 + two scaled-fp8 correction products), fp32 text
+        # stream, fp32 self-attention, erf GELU; ViT and cross-attention block fp16 (blip_stage2.blip_stage2 has the numbers).
         model.set_precision("text32")
     return model

@@ -147,7 +147,7 @@ class _EngineHost(nn.Module):
         self.graph_candidates = int(max_candidates)
         return self
 
-    PRECISIONS = ("bf16", "f16", "mixed", "text32", "exact")
+    PRECISIONS = ("bf16", "f16", "mixed", "text32", "text32x3", "exact")
 
     def set_precision(self, mode: str):
         """"bf16" / "f16": one operand type everywhere.  "mixed": bf16 operands for the ViT and the cross-attention block
@@ -166,12 +166,15 @@ class _EngineHost(nn.Module):
             return self.set_stream_dtype(torch.float32)
         if self.compute_dtype == torch.float32:        # leaving exact / text32: back to the automatic stream storage
             self.set_stream_dtype(None)
-        if mode == "text32":
-            # Round 5 (tools/text_fp32_probe.py): the TEXT side alone in the exact mode's arithmetic - fp32 operands on the f32-input MFMA,
-            # fp32 stream, erf GELU, unfolded merge layers for self-attention / FFN / cls_head of both text encoders - over the fp16 ViT and
-            # fp16 cross-attention block (folds kept).  The rank error of a 16-bit run enters through the text side: this mode holds 0.97 /
-            # 0.95 / 0.99 of the K = 100 / 200 / 50 positions and tau 0.993 on the outlier-channel fixture (split streams: 0.857) at 3.7 x
-            # the exact mode's throughput.
+        if mode in ("text32", "text32x3"):
+            # Rounds 5-6 (tools/text_fp32_probe.py): the TEXT side alone at fp32-like precision - fp32 rows and weights as multi-term 16 / 8-bit
+            # operands, fp32 stream, fp32 self-attention, erf GELU for self-attention / FFN / cls_head of both text encoders - over the fp16
+            # ViT and fp16 cross-attention block (folds kept).  The rank error of a 16-bit run enters through the text side: this mode holds
+            # 0.97 / 0.95 / 0.98 of the K = 100 / 200 / 50 positions of the reference's order where the all-fp16 default holds 0.90 / 0.81 / 0.95.
+            # "text32" (round 6): "split8" rows - one fp16 MFMA product + two block-scaled fp8 correction products per Linear, operand rows
+            # written by the producing kernels; "text32x3" (round 5): three fp16 products on [hi | lo | hi] rows (the last ~2 % of the order
+            # on outlier-channel weights, at 0.85 x the throughput).  `text_split3` holds the choice (8 / 3; 0 = the f32-input MFMA).
+            self.text_split3 = 8 if mode == "text32" else 3
             self.set_compute_dtype(torch.float32, torch.float16)
             return self.set_stream_dtype(None, vit=None)
         if mode == "mixed":
@@ -182,10 +185,18 @@ class _EngineHost(nn.Module):
     def precision(self) -> str:
         if self.image_dtype is not None:
             if (self.compute_dtype, self.image_dtype) == (torch.float32, torch.float16):
-                return "text32"
+                return "text32"            # (either arithmetic: `text_arithmetic` tells them apart)
             return "mixed" if (self.compute_dtype, self.image_dtype) == (torch.float16, torch.bfloat16) else \
                 f"{str(self.compute_dtype)[6:]}+{str(self.image_dtype)[6:]}"
         return {torch.bfloat16: "bf16", torch.float16: "f16", torch.float32: "exact"}[self.compute_dtype]
+
+    @property
+    def text_arithmetic(self) -> str:
+        """how the text side's Linears multiply in this mode (reporting)"""
+        if self.precision != "text32":
+            return {"exact": "f32-input MFMA"}.get(self.precision, "one 16-bit MFMA product")
+        return {8: "split8: fp16 MFMA + 2 block-scaled fp8 correction products", 3: "three fp16 MFMA products", True: "three fp16 MFMA products"}.get(
+            self.text_split3, "f32-input MFMA")
 
     @property
     def token_dtype(self) -> torch.dtype:
@@ -348,10 +359,11 @@ def blip_stage2(pretrained: str = "", **kwargs) -> BLIP_NLVR:
         model, msg = load_stage2_checkpoint(model, pretrained)
         print("missing keys:")
         print(msg.missing_keys)
-        # Real weights: "text32" (round 5) - the text side on fp32 rows as 3-product fp16 GEMMs (~20 bits), fp32 text stream, erf GELU; ViT and
-        # cross-attention block fp16.  Pretrained checkpoints carry outlier channels: on the fixture that mimics them the all-fp16 path holds
-        # tau 0.81 of the reference's order and the split-stream setting of round 4 0.86, this mode 0.99 (0.98 / 0.95 / 0.99 of the K = 100 /
-        # 200 / 50 positions exactly) at 0.67 x the default's throughput.  Random-init models and the benchmark keep
-        # the all-fp16 default; `set_precision("f16")` returns to it.
+        # Real weights: "text32" - the text side on fp32 rows as split8 operands (fp16 + two scaled-fp8 correction products, ~16 bits), fp32
+        # text stream, fp32 self-attention, erf GELU; ViT and cross-attention block fp16.  Pretrained checkpoints carry outlier channels: on
+        # the fixture that mimics them the all-fp16 path holds tau 0.68 of the reference's order, this mode 0.985 (0.97 / 0.95 / 0.98 of the
+        # K = 100 / 200 / 50 positions exactly on well-conditioned weights) at 0.8 x the default's throughput.
+        # `set_precision("text32x3")` is round 5's three-product form (tau 0.986, 0.85 x this mode's speed); random-init models and the
+        # benchmark's headline keep the all-fp16 default; `set_precision("f16")` returns to it.
         model.set_precision("text32")
     return model

@@ -164,6 +164,52 @@ __device__ __forceinline__ void gelu_erf8(float (&v)[8]) {
     for (int j = 0; j < 4; ++j) { const f32x2 y = x[j] * t[j]; v[2 * j] = y.x; v[2 * j + 1] = y.y; }
 }
 
+// eight erf-GELUs to ~fp32 accuracy (Abramowitz & Stegun 7.1.26: |erf error| <= 1.5e-7) as four interleaved packed chains - the form the
+// split8 path of the text32 mode uses everywhere (GEMM epilogues of both tile sizes and the stand-alone pass: one function, the same bits):
+//   t = 1 / (1 + p |x| / sqrt 2),  e = 1 - t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-x^2 / 2),  gelu = (x + |x| e) / 2
+__device__ __forceinline__ void gelu_erf_as8(float (&v)[8]) {
+    f32x2 x[4], t[4], p[4], q[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = f32x2{v[2 * j], v[2 * j + 1]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { t[j].x = fmaf(fabsf(x[j].x), 0.3275911f * 0.70710678118654752f, 1.0f); t[j].y = fmaf(fabsf(x[j].y), 0.3275911f * 0.70710678118654752f, 1.0f); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { t[j].x = __builtin_amdgcn_rcpf(t[j].x); t[j].y = __builtin_amdgcn_rcpf(t[j].y); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = x[j] * x[j];
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x2 a5 = {1.061405429f, 1.061405429f}, a4 = {-1.453152027f, -1.453152027f}, a3 = {1.421413741f, 1.421413741f};
+    const f32x2 a2 = {-0.284496736f, -0.284496736f}, a1 = {0.254829592f, 0.254829592f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = __builtin_elementwise_fma(a5, t[j], a4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = q[j] * f32x2{-0.72134752044448170f, -0.72134752044448170f};     // -x^2 / 2 in the log2 domain
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = __builtin_elementwise_fma(p[j], t[j], a3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { q[j].x = __builtin_amdgcn_exp2f(q[j].x); q[j].y = __builtin_amdgcn_exp2f(q[j].y); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = __builtin_elementwise_fma(p[j], t[j], a2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = __builtin_elementwise_fma(p[j], t[j], a1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = t[j] * q[j];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = __builtin_elementwise_fma(-p[j], t[j], f32x2{1.0f, 1.0f});          // e = 1 - poly t exp
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { p[j].x = fmaf(fabsf(x[j].x), p[j].x, x[j].x); p[j].y = fmaf(fabsf(x[j].y), p[j].y, x[j].y); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const f32x2 y = p[j] * f32x2{0.5f, 0.5f}; v[2 * j] = y.x; v[2 * j + 1] = y.y; }
+}
+
 // ---- "split8" operand rows (round 6) ------------------------------------------------------------------------------------------------
 // A fp32 value y travels to a GEMM as three terms: hi = fp16(y), lo8 = e4m3((y - hi) * 2^12), hi8 = e4m3(hi); a row of K values is stored
 // as [K x hi (2 K bytes) | K x lo8 | K x hi8] = 4 K bytes.  Against weight rows [W_hi | e4m3(W_hi 2^e1) | e4m3(W_lo 2^e2)] one GEMM forms

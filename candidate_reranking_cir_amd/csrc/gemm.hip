@@ -356,7 +356,14 @@ __global__ __launch_bounds__(256, 2) void gemm_split8_kernel(const GemmArgs a) {
             for (int jj = 0; jj < 4; ++jj) v[ni * 4 + jj] = acc[mi][ni][jj];
         if (a.act == CIR_ACT_GELU) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = gelu_erf_as(v[q]);
+            for (int q = 0; q < 16; q += 8) {      // the 256 x 256 kernel's packed evaluation: the same operations, the same bits
+                float w8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w8[e] = v[q + e];
+                gelu_erf_as8(w8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[q + e] = w8[e];
+            }
         } else if (a.act == CIR_ACT_RELU) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) v[q] = fmaxf(v[q], 0.f);

@@ -642,7 +642,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs a) {
                         _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) v[ni * 4 + jj] = acc[(PS) / (NPASS / 2)][mi][nh][ni][jj]; \
                     const int act_ = ACT >= 0 ? ACT : a.act;                                                                 \
                     if (act_ == CIR_ACT_GELU) {                                                                              \
-                        if constexpr (MIX) { _Pragma("unroll") for (int q = 0; q < 8; ++q) v[q] = gelu_erf_as(v[q]); }  /* erf to 1.5e-7: the split8 path keeps ~20 bits */ \
+                        if constexpr (MIX) gelu_erf_as8(v);   /* erf to 1.5e-7: the split8 path keeps ~16 bits */                 \
                         else gelu_erf8(v);   /* four interleaved packed chains */                                            \
                     } else if (act_ == CIR_ACT_RELU) {                                                                       \
                         _Pragma("unroll") for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);                               \

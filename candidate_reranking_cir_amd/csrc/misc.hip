@@ -411,10 +411,10 @@ __global__ __launch_bounds__(256) void split8_kernel(const float* __restrict__ x
     const int c = (int)(i - r * per_row) * 8;
     const float4 v0 = *reinterpret_cast<const float4*>(x + r * ldx + c), v1 = *reinterpret_cast<const float4*>(x + r * ldx + c + 4);
     float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    if (ACT == CIR_ACT_GELU) gelu_erf_as8(v);
+    else if (ACT == CIR_ACT_RELU) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if (ACT == CIR_ACT_GELU) v[j] = gelu_erf_as(v[j]);
-        else if (ACT == CIR_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
     }
     const float a[4] = {v[0], v[1], v[2], v[3]}, b[4] = {v[4], v[5], v[6], v[7]};
     const Split4 sa = split8_x4(a), sb = split8_x4(b);

@@ -76,6 +76,9 @@ def test_precision_flags_map_to_model_settings():
     b.apply_precision(m, "text32", "f32")
     assert (m.precision, m.compute_dtype, m.image_dtype, m.stream_dtype, m.vit_stream_dtype, m.token_dtype) == \
         ("text32", torch.float32, torch.float16, torch.float32, torch.float16, torch.float16) and b.stream_name(m) == "split"
+    assert m.text_split3 == 8 and m.text_arithmetic.startswith("split8")                     # round 6: fp16 + 2 scaled-fp8 products
+    b.apply_precision(m, "text32x3", "auto")                                                  # round 5's three fp16 products, same mode otherwise
+    assert m.precision == "text32" and m.text_split3 == 3 and m.text_arithmetic.startswith("three") and b.stream_name(m) == "split"
     b.apply_precision(m, "f16", "auto")
     assert (m.precision, m.stream_dtype, m.vit_stream_dtype) == ("f16", torch.float16, torch.float16)
-    assert set(b.PRECISION_NOTE) == {"f16", "bf16", "mixed", "text32", "exact"} == set(b.PEAK_TFLOPS) and b.PEAK_TFLOPS["exact"] == 157.3
+    assert set(b.PRECISION_NOTE) == {"f16", "bf16", "mixed", "text32", "text32x3", "exact"} == set(b.PEAK_TFLOPS) and b.PEAK_TFLOPS["exact"] == 157.3

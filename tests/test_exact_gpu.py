@@ -399,20 +399,27 @@ def test_partial_fp32_text_stream_sits_between_the_default_and_the_split_mode():
     assert e["split"] <= e["half"] * 1.25 and e["half"] <= e["default"] * 1.25, e
 
 
-TEXT32_FLOORS = {"c100": (0.95, 0.999), "c200": (0.92, 0.999), "f50": (0.97, 0.999)}      # measured 0.972 / 0.948 / 0.990, tau 0.9994-0.9996
+# (exact positions, tau) floors per arithmetic.  text32x3 (three fp16 products, round 5): measured 0.978 / 0.948 / 0.986, tau 0.9994-0.9995 - the
+# floors are the round-5 review's.  text32 (split8: fp16 + two scaled-fp8 correction products, round 6): measured 0.972 / 0.951 / 0.983, tau
+# 0.9991-0.9995 - within one rounding realisation of the three-product form on these well-conditioned weights (CPU emulation of both,
+# oracle/split8_probe.py: 0.975 against 0.979 the other way round); the outlier-channel fixture below is where the forms differ.
+TEXT32_FLOORS = {"text32": {"c100": (0.96, 0.999), "c200": (0.94, 0.999), "f50": (0.975, 0.999)},
+                 "text32x3": {"c100": (0.975, 0.999), "c200": (0.945, 0.999), "f50": (0.985, 0.999)}}
 
 
-@pytest.fixture(scope="module")
-def text32_models():
+@pytest.fixture(scope="module", params=["text32", "text32x3"])
+def text32_models(request):
     from candidate_reranking_cir_amd import synthetic, validate_stage2 as V
     from tests import helpers as H
     from tests.test_model_gpu import build_models
     z = H.load("rank224_wide.npz")
     g, v = H.geometry(H.FULL_BERT, dict(image_size=224))
     m2, m1 = build_models(g, v, int(z["seed"]), str(z["profile"]), torch.float16, torch.device("cuda"))
-    m2.set_precision("text32"); m1.set_precision("text32")
+    m2.set_precision(request.param); m1.set_precision(request.param)
     assert m2.precision == "text32" and m2.vit_stream_dtype == torch.float16 and m2.stream_dtype == torch.float32 and m2.token_dtype == torch.float16
+    assert m2.text_split3 == m1.text_split3 == (8 if request.param == "text32" else 3) and m2.engines()[1].split == m2.text_split3
     bank = V.extract_index_features(synthetic.scene_images(range(int(z["n_index"])), 224), m2, batch_size=128)
+    m2._arith = request.param
     return z, m2, m1, bank
 
 
@@ -438,8 +445,42 @@ def test_text32_mode_on_the_reference_rank_fixtures(text32_models, tag):
     stats = np.array([order_stats(logits[q], ref[q]) for q in np.where(active)[0]])
     exact, tau, top10 = stats.mean(0)
     err = np.abs(logits[active] - ref[active]).max()
-    print(f"\n[text32 {tag}] max|dlogit| {err:.2e} exact positions {exact:.3f} tau {tau:.4f} top-10 {top10:.3f}")
-    assert err < 8e-4 and exact >= TEXT32_FLOORS[tag][0] and tau >= TEXT32_FLOORS[tag][1] and top10 >= 0.99
+    fl = TEXT32_FLOORS[m2._arith][tag]
+    print(f"\n[{m2._arith} {tag}] max|dlogit| {err:.2e} exact positions {exact:.3f} tau {tau:.4f} top-10 {top10:.3f}")
+    assert err < 8e-4 and exact >= fl[0] and tau >= fl[1] and top10 >= 0.99
+
+
+# all 16 scored queries: (tau, top-10); the 10 well-conditioned ones: (tau, exact positions)
+TEXT32_OUTLIER_FLOORS = {"text32": ((0.980, 0.97), (0.985, 0.70)),       # measured tau 0.9845 / top-10 0.988; well-conditioned tau 0.9915, exact 0.780
+                         "text32x3": ((0.985, 0.98), (0.993, 0.85))}     # measured tau 0.9860 / top-10 0.988; well-conditioned tau 0.9959, exact 0.907
+
+
+@pytest.mark.parametrize("arith", ["text32", "text32x3"])
+def test_text32_on_the_outlier_channel_fixture(cuda, arith):
+    """What the text32 mode exists for: checkpoint-like weights with outlier channels (outlier224_wide.npz: the reference's own logits, 16
+    scored queries, logit sigma ~0.03 per query).  The all-fp16 default holds tau 0.68 of the reference's order there; text32 on split8
+    rows (fp16 + two scaled-fp8 correction products) 0.985, the three-product form 0.986 - and on the 10 queries whose reference logits
+    are themselves well-conditioned (fp32-vs-fp64 noise < 2e-5) 0.78 / 0.91 of the sorted positions exactly: the last 5 % of the text
+    side's fp16 rounding error, which e4m3's 4-bit factors leave in the correction products, is visible on these weights and only here."""
+    from candidate_reranking_cir_amd import validate_stage2 as V
+    from tests.test_model_gpu import build_models, order_stats
+    z = H.load("outlier224_wide.npz")
+    g, v = H.geometry(H.FULL_BERT, dict(image_size=224))
+    m2, m1 = build_models(g, v, int(z["seed"]), str(z["profile"]), torch.float16, cuda)
+    m2.set_precision(arith); m1.set_precision(arith)
+    bank = V.extract_index_features(synthetic.scene_images(range(int(z["n_index"])), 224), m2, batch_size=64)
+    ds = V.RelativeValSet(ref_index=z["refs"], cand_index=z["cand"], labels=z["labels"], captions=[str(c) for c in z["caps"]],
+                          group_index=z["groups"], target_index=z["targets"])
+    lt, _ = V.generate_cirr_val_predictions(m2, m1, ds, bank, query_batch=4)
+    logits, ref = lt.cpu().numpy(), z["logits"]
+    q_act = np.where(z["labels"].any(1))[0]
+    stats = np.array([order_stats(logits[q], ref[q]) for q in q_act])
+    well = np.abs(z["logits_f64"][q_act] - ref[q_act].astype(np.float64)).max(1) < 2e-5
+    (tau_min, top_min), (tau_w_min, exact_w_min) = TEXT32_OUTLIER_FLOORS[arith]
+    print(f"\n[{arith} outlier224_wide] all {len(q_act)}: exact {stats[:, 0].mean():.3f} tau {stats[:, 1].mean():.4f} top-10 {stats[:, 2].mean():.3f}; "
+          f"well-conditioned {int(well.sum())}: exact {stats[well, 0].mean():.3f} tau {stats[well, 1].mean():.4f}")
+    assert stats[:, 1].mean() >= tau_min and stats[:, 2].mean() >= top_min
+    assert stats[well, 1].mean() >= tau_w_min and stats[well, 0].mean() >= exact_w_min
 
 
 @pytest.mark.parametrize("m,n,k,batch", [(5000, 768, 768, 1), (3000, 3072, 768, 2), (777, 768, 3072, 1)])

@@ -143,6 +143,26 @@ def test_rank224_and_bxb224():
     assert int(zw["c100_labels"].any(1).sum()) == 16 and int(zw["c200_labels"].any(1).sum()) == 16 and int(zw["f50_labels"].any(1).sum()) == 16
 
 
+def test_rank384_subset():
+    """The oracle at the REFERENCE'S OWN geometry (384 px, 577 tokens) against rank384.npz (round 6: the reference's extract_index_features
+    + generate_cirr_val_predictions): the tokens of the images involved, and the CIRR subset logits of one query (6 images: ~20 s of CPU)."""
+    z = H.load("rank384.npz")
+    g, v = H.geometry(H.FULL_BERT, dict(image_size=384))
+    sd2, sd1 = H.state_dicts(g, v, int(z["seed"]), str(z["profile"]))
+    torch.set_num_threads(8)
+    q = 1
+    rows = [int(z["c100_refs"][q])] + [int(i) for i in z["c100_groups"][q]]
+    with torch.no_grad():
+        feats = O.img_embed(sd2, synthetic.scene_images(rows, 384))
+        assert feats.shape == (6, 577, 768)
+        np.testing.assert_allclose(feats[:, :3, :8].numpy(), z["bank_slice"][rows], atol=1e-4)
+        ids, mask = H.tokenize([str(z["c100_caps"][q])])
+        glog = O.img_txt_fusion_val(sd2, O.stage1_z_t(sd1, feats[:1], ids, mask), feats[1:], ids, mask)
+    np.testing.assert_allclose(glog.numpy(), z["c100_group_logits"][q], atol=2e-4)
+    assert int(z["c100_labels"].any(1).sum()) == 2 and not z["c100_labels"][2].any() and np.all(z["c100_logits"][2] == np.float32(-99999.99))
+    assert z["f50_logits"].shape == (4, 50)
+
+
 def test_outlier224():
     """The oracle on the OUTLIER-channel weights (tests/golden/outlier224.npz: residual stream 1e2..1e3 in three channels,
     the reference's generate_cirr_val_predictions at K = 100): image tokens incl. the outlier channels, the CIRR subset
