@@ -46,6 +46,21 @@
 //     kernel must move: neither the softmax chain nor the DRAM access pattern is the bound; a workgroup's life is load 82 KB ->
 //     compute -> store with two or three workgroups per CU to overlap, and the time is their sum, not their maximum.
 
+// Measured in round 6 (3392 images x 12 heads, 197 x 197, fp16; the staged kernel 1.20 ms in the step, 639 us per 1696 images alone):
+//   * the kernel's memory traffic ALONE in the same workgroup shape (tools/attn_mem_probe.hip: stage K / V, read Q, write the output tile; no
+//     MFMA, no softmax): 0.774 ms = 5.3 TB/s (loads only 0.505 ms, stores only 0.185 ms; LDS-DMA staging the same) - the access pattern is
+//     not the bound, the missing overlap of a workgroup's load / compute / store is.
+//   * a PERSISTENT, double-buffered form - one workgroup per CU, one wave per query tile, the next (image, head)'s K / V by LDS-DMA into the other
+//     half of LDS and its Q into registers while the current one computes, the output through a private staging tile (140 KiB of LDS): bit-
+//     identical, 696 us per 1696 images; with TWO key tiles per update (one reference / rescale / exchange per 64 keys, two chains of
+//     exponentials; 170 registers are free at this occupancy) 655 us.  The loads are hidden by construction there, so the 8 us per unit that
+//     remain are the tile updates themselves: 49 updates of ~600 issue cycles (4 + 4 MFMAs of 32 cycles, ~40 vector ops, 16 exponentials at
+//     quarter rate, two cross-lane steps) = 29 k SIMD-cycles per unit, 3.5 us even perfectly packed over four SIMDs - and 7 waves per CU pack
+//     them at ~45 %.  The staged kernel's two workgroups per CU (14 waves) pack them better and overlap loads by chance: both end at 7.5-8 us.
+//     Reaching the 4.8 us the memory path allows needs >= 14 resident waves AND asynchronous loads: two double-buffered workgroups do not fit
+//     160 KiB of LDS (2 x (2 x 57 + 28) KiB), and a register prefetch of the next K / V (+44 registers) drops the kernel below 4 waves per SIMD.
+//   * lazy rescale (softmax_tile): kept, -2 %.
+
 #include "attention_args.hpp"
 
 namespace cir {
@@ -98,7 +113,13 @@ __device__ __forceinline__ void softmax_tile(Softmax& st, f32x16& s, float sl, c
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     if constexpr (!MASKED) mx *= sl;
     const float m_new = fmaxf(st.m_run, mx);     // finite: every tile holds at least one valid key
-    if (!__all(m_new == st.m_run)) {             // skip the O-wide rescale when no row maximum moved
+    // LAZY rescale (round 6): the running maximum is a REFERENCE point of the exponentials, not their bound - it follows the true row
+    // maximum only when some row's maximum has grown by more than 2^kLazyLog2 (then every probability of that row would exceed 64 times
+    // the scale the sums were formed at); otherwise the tile is accumulated at the stale reference (p <= 64: exact in the fp32 sums,
+    // same relative rounding in the 16-bit P) and the 33 multiplies of the O / l rescale are skipped on almost every tile behind the
+    // first.  The result is the same softmax: l and O share the reference.  Measured: 654 -> 639 us per 1696 images (197 x 197).
+    constexpr float kLazyLog2 = 6.0f;
+    if (__any(mx > st.m_run + kLazyLog2)) {      // (first tile: m_run = -inf)
         const float alpha = __builtin_amdgcn_exp2f(st.m_run - m_new);
         st.l_run *= alpha;
 #pragma unroll

@@ -41,7 +41,9 @@ __device__ unsigned long long g_fold_stamps[8 * 64];        // [workgroup < 4][w
 #define FOLD_STAMP(K) do {} while (0)
 #endif
 
-template <typename T>
+// MASKED (round 6): an additive key mask per candidate (padded candidate token sets: (1 - attention_mask) * finfo.min, nlvr_encoder.py:863-868)
+// joins the logits in the softmax; the unmasked instantiation is unchanged.
+template <typename T, bool MASKED = false>
 __global__ __launch_bounds__(512, 2) void xattn_fold_kernel(const FoldArgs a) {
     using X8 = typename Elem<T>::x8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -223,19 +225,23 @@ __global__ __launch_bounds__(512, 2) void xattn_fold_kernel(const FoldArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = 16 * kb + 4 * g + r;
-                const float v = key < a.N ? S[kb][qb][r] : -INFINITY;
+                float v = key < a.N ? S[kb][qb][r] : -INFINITY;
+                if constexpr (MASKED) {   // log2-domain logit incl. the mask (finfo.min-style masks stay finite: all-masked rows uniform, like the reference)
+                    const float mk = a.mask[(int64_t)t * a.m_st + min(key, a.N - 1)];
+                    v = key < a.N ? fmaf(fmaxf(mk, -2.0e38f), 1.4426950408889634f, S[kb][qb][r] * sl) : -INFINITY;
+                }
                 S[kb][qb][r] = v;
                 m = fmaxf(m, v);
             }
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
-        const float ms = m * sl;
+        const float ms = MASKED ? m : m * sl;
         float sum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < kFoldKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(S[kb][qb][r], sl, -ms));
+                const float p = MASKED ? __builtin_amdgcn_exp2f(S[kb][qb][r] - ms) : __builtin_amdgcn_exp2f(fmaf(S[kb][qb][r], sl, -ms));
                 S[kb][qb][r] = p;
                 sum += p;
             }
@@ -373,8 +379,8 @@ __global__ __launch_bounds__(512, 2) void xattn_fold_kernel(const FoldArgs a) {
 }  // namespace cir
 
 extern "C" int cir_cross_attention_folded(const void* q, int64_t q_sb, int64_t q_rs, const void* x, int64_t x_s1, const void* wkt, const void* wvp,
-                                          int64_t w_sb, const float* bv, void* out, int64_t o_st, int64_t o_sr, int64_t o_sb, int T, int L, int N, int D,
-                                          int H, float scale, int dtype, void* stream) {
+                                          int64_t w_sb, const float* bv, const float* key_mask, int64_t mask_stride, void* out, int64_t o_st, int64_t o_sr,
+                                          int64_t o_sb, int T, int L, int N, int D, int H, float scale, int dtype, void* stream) {
     using namespace cir;
     CIR_CHECK_PTR(q); CIR_CHECK_PTR(x); CIR_CHECK_PTR(wkt); CIR_CHECK_PTR(wvp); CIR_CHECK_PTR(bv); CIR_CHECK_PTR(out);
     if (T <= 0 || L <= 0 || N <= 0) return CIR_EINVAL;
@@ -387,19 +393,21 @@ extern "C" int cir_cross_attention_folded(const void* q, int64_t q_sb, int64_t q
     FoldArgs a;
     a.q = q; a.q_sb = q_sb; a.q_rs = q_rs; a.x = x; a.x_s1 = x_s1; a.wkt = wkt; a.wvp = wvp; a.w_sb = w_sb; a.bv = bv;
     a.out = out; a.o_st = o_st; a.o_sr = o_sr; a.o_sb = o_sb; a.T = T; a.L = L; a.N = N; a.scale = scale;
+    a.mask = key_mask; a.m_st = mask_stride;
+    if (key_mask && mask_stride < N) return CIR_ESHAPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (N > 16 * kFoldKB) return launch_fold16(a, dtype, s);       // 225 .. 608 keys: the 16-rows-per-wave kernel (xattn_fold16.hip)
     const size_t lds = 2 * kFoldBuf + 32 * kStrideQ;
     dim3 grid((unsigned)(8 * ((T + 3) / 4))), block(512);
-    if (dtype == CIR_BF16) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fold_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((xattn_fold_kernel<__bf16>), grid, block, lds, s, a);
-    } else {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fold_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((xattn_fold_kernel<_Float16>), grid, block, lds, s, a);
-    }
+#define CIR_FOLD_LAUNCH(TT, MK)                                                                                                                   \
+    do {                                                                                                                                          \
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fold_kernel<TT, MK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return (int)e;                                                                                                       \
+        hipLaunchKernelGGL((xattn_fold_kernel<TT, MK>), grid, block, lds, s, a);                                                                  \
+    } while (0)
+    if (dtype == CIR_BF16) { if (key_mask) CIR_FOLD_LAUNCH(__bf16, true); else CIR_FOLD_LAUNCH(__bf16, false); }
+    else { if (key_mask) CIR_FOLD_LAUNCH(_Float16, true); else CIR_FOLD_LAUNCH(_Float16, false); }
+#undef CIR_FOLD_LAUNCH
     CIR_LAUNCH_RESULT();
 }
 

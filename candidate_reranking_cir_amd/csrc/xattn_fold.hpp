@@ -14,6 +14,7 @@ struct FoldArgs {
     void* out; int64_t o_st, o_sr, o_sb;        // element (t, tok, b, col) at out + t o_st + tok o_sr + b o_sb + col
     int T, L, N;
     float scale;
+    const float* mask = nullptr; int64_t m_st = 0;   // optional additive key mask (T, N) fp32, rows m_st apart (round 6): logits = S scale + mask
 };
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr_f;

@@ -17,7 +17,7 @@ constexpr int kBuf16 = 4096 * 16;            // one X-unit buffer: phase 2 needs
 constexpr int kStrideQ16 = 544;              // q rows in LDS: 4 heads x 64 x 2 B + 32 (136 dwords = 8 mod 64: conflict-free b128 fragment reads)
 constexpr int kStrideP2 = 96;                // phase 2's row stride
 
-template <typename T>
+template <typename T, bool MASKED = false>
 __global__ __launch_bounds__(512, 2) void xattn_fold16_kernel(const FoldArgs a) {
     using X8 = typename Elem<T>::x8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -129,19 +129,24 @@ __global__ __launch_bounds__(512, 2) void xattn_fold16_kernel(const FoldArgs a) 
     for (int kb = 0; kb < kKB16; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float v = (16 * kb + 4 * g + r) < a.N ? S[kb][r] : -INFINITY;
+            const int key = 16 * kb + 4 * g + r;
+            float v = key < a.N ? S[kb][r] : -INFINITY;
+            if constexpr (MASKED) {   // (as xattn_fold_kernel: log2-domain logits incl. the additive key mask)
+                const float mk = a.mask[(int64_t)t * a.m_st + min(key, a.N - 1)];
+                v = key < a.N ? fmaf(fmaxf(mk, -2.0e38f), 1.4426950408889634f, S[kb][r] * sl) : -INFINITY;
+            }
             S[kb][r] = v;
             m = fmaxf(m, v);
         }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    const float ms = m * sl;
+    const float ms = MASKED ? m : m * sl;
     float sum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < kKB16; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float p = __builtin_amdgcn_exp2f(fmaf(S[kb][r], sl, -ms));
+            const float p = MASKED ? __builtin_amdgcn_exp2f(S[kb][r] - ms) : __builtin_amdgcn_exp2f(fmaf(S[kb][r], sl, -ms));
             S[kb][r] = p;
             sum += p;
         }
@@ -235,15 +240,15 @@ int launch_fold16(const FoldArgs& a, int dtype, hipStream_t s) {
     const size_t lds = 2 * kBuf16 + 32 * kStrideQ16;
     const int64_t per_branch = 3 * (int64_t)a.T;
     dim3 grid((unsigned)(8 * ((per_branch + 3) / 4))), block(512);
-    if (dtype == CIR_BF16) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fold16_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((xattn_fold16_kernel<__bf16>), grid, block, lds, s, a);
-    } else {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fold16_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((xattn_fold16_kernel<_Float16>), grid, block, lds, s, a);
-    }
+#define CIR_FOLD16_LAUNCH(TT, MK)                                                                                                                 \
+    do {                                                                                                                                          \
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fold16_kernel<TT, MK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return (int)e;                                                                                                       \
+        hipLaunchKernelGGL((xattn_fold16_kernel<TT, MK>), grid, block, lds, s, a);                                                                \
+    } while (0)
+    if (dtype == CIR_BF16) { if (a.mask) CIR_FOLD16_LAUNCH(__bf16, true); else CIR_FOLD16_LAUNCH(__bf16, false); }
+    else { if (a.mask) CIR_FOLD16_LAUNCH(_Float16, true); else CIR_FOLD16_LAUNCH(_Float16, false); }
+#undef CIR_FOLD16_LAUNCH
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? CIR_OK : (int)e;
 }

@@ -292,9 +292,11 @@ class NlvrEngine:
                                                  # attention; the "exact" fp32 mode keeps the reference's order of operations)
         # Round 5: the OTHER layers' cross-attention with the K / V projections folded to the query side (cir_cross_attention_folded:
         # S = (q W_k) X^T, ctx = (P X) W_v^T + b_v - 614 instead of 969 MFLOP per candidate and layer, and no (T N, 4 D) K|V tensor).
-        # Taken when the geometry is the kernels' (D = Dv = 768, 12 heads, L <= 32, N <= 608: 224 px and the reference's 384 px), no key
-        # mask, no K/V bank; anything else keeps the projected path.
+        # Taken when the geometry is the kernels' (D = Dv = 768, 12 heads, L <= 32, N <= 608: 224 px and the reference's 384 px), with or
+        # without a key mask (round 6), no K/V bank; anything else keeps the projected path (captions of more than 32 tokens: `fold_fallbacks`
+        # counts those calls - the kernels' 48-row-per-wave tiling would run them as two passes, which the projected path beats below ~56 tokens).
         self.fold_cross_kv = xdt != torch.float32 and geo.hidden_size == 768 and geo.encoder_width == 768 and geo.num_attention_heads == 12
+        self.fold_fallbacks = 0      # forward calls whose captions (> 32 tokens) took the projected path although the fold is on: visible, not silent
         e = prefix + "embeddings."
         self.word, self.posemb = _f32(sd[e + "word_embeddings.weight"], device), _f32(sd[e + "position_embeddings.weight"], device)
         self.ge, self.be = _f32(sd[e + "LayerNorm.weight"], device), _f32(sd[e + "LayerNorm.bias"], device)
@@ -458,7 +460,8 @@ class NlvrEngine:
         a32 = ops.gather_rows(a_sq.view(2 * q_n, l * d), both, sdt).view(2, r, d)
         a16 = a32 if xdt == sdt else ops.gather_rows(a16q.view(2 * q_n, l * d), both, xdt).view(2, r, d)
         smask = ops.gather_rows(_pad8(smask_q), qidx, torch.float32)[:, :l]                             # (T, L) view
-        emask = additive_encoder_mask(cand_mask).view(t_n, 1, n).expand(t_n, 2, n) if cand_mask is not None else None
+        emask2d = additive_encoder_mask(cand_mask).view(t_n, n) if cand_mask is not None else None       # (T, N): the folded kernels' form
+        emask = emask2d.view(t_n, 1, n).expand(t_n, 2, n) if cand_mask is not None else None
         cand2 = cand16.reshape(t_n * n, cand16.shape[2]) if kv_bank is None else None
         cc = torch.empty((t_n, l, 2, d), dtype=xdt, device=z_t32.device)
         h32 = h16 = None
@@ -502,10 +505,16 @@ class NlvrEngine:
                     ops.gemm(q2[b].permute(1, 0, 2), f["wkt"][b], None, out=qp[:, b * h_n:(b + 1) * h_n, :].permute(1, 0, 2))
                 o = ops.cls_cross_attention(tok, qp, scale, x_index=None if kv_bank is None else cand_rows)
                 ops.gemm(o[:, :2 * h_n, :].permute(1, 0, 2), f["wv"], f["bv"], out=ccl.view(t_n, 2 * h_n, 64).permute(1, 0, 2))
-            elif (kv_bank is None and self.fold_cross_kv and "wkt" in ly and emask is None and not cls_only and l <= 32 and n <= 608
+            elif (kv_bank is None and self.fold_cross_kv and "wkt" in ly and not cls_only and l <= 32 and n <= 608
                   and cand16.shape[2] == d):
-                ops.cross_attention_folded(qraw, cand16, ly["wkt"], ly["wvp"], ly["bvf"], ccl, l, scale, heads=geo.num_attention_heads)
+                ops.cross_attention_folded(qraw, cand16, ly["wkt"], ly["wvp"], ly["bvf"], ccl, l, scale, heads=geo.num_attention_heads, mask=emask2d)
             elif kv_bank is None:
+                if self.fold_cross_kv and "wkt" in ly and l > 32 and i == 1:
+                    self.fold_fallbacks += 1
+                    if self.fold_fallbacks == 1:
+                        import warnings
+                        warnings.warn(f"captions of {l} tokens (> 32): the cross-attention runs the projected K|V path for this batch (~8 % of a step slower than "
+                                      "the query-side fold at 224 px); NlvrEngine.fold_fallbacks counts such calls", stacklevel=3)
                 # K|V projection + cross-attention, optionally in candidate chunks (`kv_chunk`; measured: no gain from
                 # keeping a chunk's K|V in the Infinity Cache, so the default is one launch each)
                 step_c = self.kv_chunk if self.kv_chunk > 0 else t_n

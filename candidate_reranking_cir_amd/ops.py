@@ -495,7 +495,7 @@ def fold_pack_value(wv: torch.Tensor) -> torch.Tensor:
 
 
 def cross_attention_folded(q: torch.Tensor, x: torch.Tensor, wkt: torch.Tensor, wvp: torch.Tensor, bv: torch.Tensor, out: torch.Tensor, l: int,
-                           scale: float, heads: int = 12) -> torch.Tensor:
+                           scale: float, heads: int = 12, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Folded two-branch cross-attention (cir_cross_attention_folded): q (2, T*L, D) cross-query projection, x (T, N, D) tokens, wkt (2, D, D) =
     fold_pack_key(key.weight), wvp (2, D, D) = fold_pack_value(value.weight), bv (2, D) fp32 -> out (T, L, 2, D) view (written, returned)."""
     _need_cuda(q, x, wkt, wvp, bv, out)
@@ -503,11 +503,15 @@ def cross_attention_folded(q: torch.Tensor, x: torch.Tensor, wkt: torch.Tensor, 
     assert q.shape == (2, t_n * l, d) and q.stride(2) == 1 and x.stride(2) == 1 and x.stride(1) == d
     assert wkt.shape == (2, d, d) and wvp.shape == (2, d, d) and wkt.is_contiguous() and wvp.is_contiguous() and bv.shape == (2, d) and bv.is_contiguous()
     assert out.shape == (t_n, l, 2, d) and out.stride(3) == 1 and q.dtype == x.dtype == wkt.dtype == wvp.dtype == out.dtype and bv.dtype == torch.float32
+    if mask is not None:       # additive fp32 key mask (T, N), shared by the two branches
+        _need_cuda(mask)
+        assert mask.dtype == torch.float32 and mask.shape == (t_n, n) and mask.stride(1) == 1
     if PROFILE_ATTN is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     code = _lib.load().cir_cross_attention_folded(q.data_ptr(), q.stride(0), q.stride(1), x.data_ptr(), x.stride(0), wkt.data_ptr(), wvp.data_ptr(), d * d,
-                                                  bv.data_ptr(), out.data_ptr(), out.stride(0), out.stride(1), out.stride(2), t_n, l, n, d, heads,
+                                                  bv.data_ptr(), _ptr(mask), mask.stride(0) if mask is not None else 0,
+                                                  out.data_ptr(), out.stride(0), out.stride(1), out.stride(2), t_n, l, n, d, heads,
                                                   float(scale), _DT[x.dtype], _stream())
     if PROFILE_ATTN is not None:
         ev1.record()      # executed flops: per (candidate, branch) 2 x (H L x 64 x D) projections + 2 x (H L x D x N) products

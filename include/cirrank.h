@@ -230,13 +230,15 @@ int cir_cls_cross_attention(const void* x, int64_t x_s1, const int64_t* x_index,
  * (u < D / 32 feature units, t < 2, s < 2, e < 4, h < 12; candidate_reranking_cir_amd/ops.py: fold_pack_key / fold_pack_value);
  * bv (2, D) fp32 value bias; out (T, L, 2, D)-shaped through strides.
  * D = 768, H = 12, L <= 32, N <= 608 (N <= 224: 48 query rows per wave, csrc/xattn_fold.hip; 225 .. 608 - the 384-px geometry's 577 tokens -: 16 rows per
- * wave, csrc/xattn_fold16.hip), no key mask (CIR_ESHAPE otherwise: use cir_gemm_bias_act + cir_attention).  16-bit operands, fp32
+ * wave, csrc/xattn_fold16.hip) (CIR_ESHAPE otherwise: use cir_gemm_bias_act + cir_attention).  key_mask (ABI v14; NULL = none): additive fp32
+ * mask (T, N), rows mask_stride apart, shared by both branches - the (1 - attention_mask) * finfo.min of padded candidate token sets
+ * (nlvr_encoder.py:863-868): logits = scores * scale + mask; masks below -2e38 are clamped there (all-masked rows stay uniform).  16-bit operands, fp32
  * accumulation and softmax; Q' = q W_k and C' = P X are rounded to the operand type where the projected path rounds K and V.
  * 614 MFLOP per (candidate, both branches) instead of 969 at 197 keys (3.0 instead of 5.7 GFLOP at 577), and no (T N, 4 D) K|V tensor.
  */
 int cir_cross_attention_folded(const void* q, int64_t q_sb, int64_t q_rs, const void* x, int64_t x_s1, const void* wkt, const void* wvp, int64_t w_sb,
-                               const float* bv, void* out, int64_t o_st, int64_t o_sr, int64_t o_sb, int T, int L, int N, int D, int H, float scale,
-                               int dtype, void* stream);
+                               const float* bv, const float* key_mask, int64_t mask_stride, void* out, int64_t o_st, int64_t o_sr, int64_t o_sb,
+                               int T, int L, int N, int D, int H, float scale, int dtype, void* stream);
 
 /*
  * BertEmbeddings.forward (nlvr_encoder.py:68-91, med.py:87-110):

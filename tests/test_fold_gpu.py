@@ -116,3 +116,79 @@ def test_folded_cross_attention_rejects_other_geometries(ops):
     x2 = torch.zeros((2, 609, D), dtype=torch.float16, device="cuda")
     with pytest.raises(CirrankError):       # N > 608 keeps the projected path (577 tokens - the 384-px geometry - run on the 16-rows-per-wave kernel)
         ops.cross_attention_folded(q[:, :64], x2, w, w, bv, torch.empty((2, 32, 2, D), dtype=torch.float16, device="cuda"), 32, 0.125)
+
+
+@pytest.mark.parametrize("t_n,l,n", [(4, 32, 197), (3, 13, 577), (2, 32, 224)])
+def test_folded_cross_attention_with_a_key_mask(ops, t_n, l, n):
+    """Round 6: an additive key mask per candidate (padded candidate token sets, nlvr_encoder.py:863-868: (1 - m) * finfo.min) in both folded
+    kernels - against fp64 with the same mask, an all-zero mask = the unmasked kernel bit for bit, and a fully masked candidate stays finite
+    (uniform attention, like the reference's softmax over equal finfo.min logits)."""
+    dtype = torch.float16
+    q = _rand((2, t_n * l, D), 1.0, 11, dtype)
+    x = _rand((t_n, n, D), 1.0, 12, dtype)
+    wk, wv = _rand((2, D, D), 0.03, 13, dtype), _rand((2, D, D), 0.03, 14, dtype)
+    bk, bv = _rand((2, D), 0.5, 15, torch.float32), _rand((2, D), 0.5, 16, torch.float32)
+    keep = torch.rand((t_n, n), generator=torch.Generator().manual_seed(17)) > 0.3
+    keep[:, 0] = True
+    keep[0, n // 2:] = False                                             # a candidate padded to half its tokens
+    mask = ((1.0 - keep.float()) * torch.finfo(torch.float32).min)
+    args = (q.cuda(), x.cuda(), ops.fold_pack_key(wk).cuda(), ops.fold_pack_value(wv).cuda(), bv.cuda())
+    out = torch.empty((t_n, l, 2, D), dtype=dtype, device="cuda")
+    ops.cross_attention_folded(*args, out, l, 0.125, mask=mask.cuda())
+    # fp64 reference with the mask
+    ref = torch.empty((t_n, l, 2, D), dtype=torch.float64)
+    for b in (0, 1):
+        k = (x.double() @ wk[b].double().T + bk[b].double()).view(t_n, n, H, 64).permute(0, 2, 1, 3)
+        v = (x.double() @ wv[b].double().T + bv[b].double()).view(t_n, n, H, 64).permute(0, 2, 1, 3)
+        qq = q[b].double().view(t_n, l, H, 64).permute(0, 2, 1, 3)
+        s = qq @ k.transpose(-1, -2) / 8.0 + mask.double().clamp(min=-1e30)[:, None, None, :]
+        ref[:, :, b] = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(t_n, l, D)
+    err = (out.cpu().double() - ref).abs().max().item()
+    print(f"\n[folded cross-attention, key mask, T {t_n} L {l} N {n}] max|err| vs fp64 {err:.2e}")
+    assert err < 6e-3
+    plain = torch.empty_like(out)
+    zero = torch.empty_like(out)
+    ops.cross_attention_folded(*args, plain, l, 0.125)
+    ops.cross_attention_folded(*args, zero, l, 0.125, mask=torch.zeros((t_n, n), device="cuda"))
+    assert (plain.float() - zero.float()).abs().max().item() < 2e-3      # (the masked form scales the scores before the maximum: one rounding apart)
+    allm = torch.empty_like(out)
+    ops.cross_attention_folded(*args, allm, l, 0.125, mask=torch.full((t_n, n), torch.finfo(torch.float32).min, device="cuda"))
+    assert bool(torch.isfinite(allm.float()).all())
+
+
+def test_engine_takes_the_fold_with_a_candidate_mask_and_counts_long_captions(ops):
+    """NlvrEngine: a padded candidate set (cand_mask) keeps the query-side fold (round 6) and agrees with the projected path; captions of more
+    than 32 tokens take the projected path - visibly (`fold_fallbacks`, one warning)."""
+    import warnings
+    from candidate_reranking_cir_amd import synthetic
+    from candidate_reranking_cir_amd.config import BertGeometry, VitGeometry
+    from candidate_reranking_cir_amd.blip_stage2 import BLIP_NLVR
+    dev = torch.device("cuda")
+    vit = VitGeometry(image_size=64, patch_size=16, width=768, depth=1, num_heads=12)
+    torch.manual_seed(0)
+    m = BLIP_NLVR(BertGeometry(num_hidden_layers=3), vit_geometry=vit, tokenizer=synthetic.HashTokenizer()).to(dev).eval()
+    eng = m.engines()[1]
+    g = torch.Generator(device="cpu").manual_seed(5)
+    q_n, k, l, n = 2, 6, 12, vit.num_tokens
+    z = torch.randn((q_n, l, 768), generator=g).to(dev)
+    ids = torch.randint(1000, 20000, (q_n, l), generator=g).to(dev)
+    mask = torch.ones_like(ids)
+    cand = (torch.randn((q_n * k, n, 768), generator=g) * 0.5).to(dev).half()
+    qidx = torch.arange(q_n, device=dev).repeat_interleave(k)
+    cmask = torch.ones((q_n * k, n), dtype=torch.int64, device=dev)
+    cmask[::2, n - 4:] = 0
+    folded = eng.forward(ids, mask, z, cand, qidx, cand_mask=cmask)
+    eng.fold_cross_kv = False
+    projected = eng.forward(ids, mask, z, cand, qidx, cand_mask=cmask)
+    eng.fold_cross_kv = True
+    unmasked = eng.forward(ids, mask, z, cand, qidx)
+    assert (folded - projected).abs().max().item() < 3e-3 and (folded - unmasked).abs().max().item() > 1e-4
+    assert eng.fold_fallbacks == 0
+    l2 = 40
+    z2 = torch.randn((q_n, l2, 768), generator=g).to(dev)
+    ids2 = torch.randint(1000, 20000, (q_n, l2), generator=g).to(dev)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        eng.forward(ids2, torch.ones_like(ids2), z2, cand, qidx)
+        eng.forward(ids2, torch.ones_like(ids2), z2, cand, qidx)
+    assert eng.fold_fallbacks == 2 and sum("projected" in str(x.message) for x in w) == 1

@@ -24,6 +24,14 @@ def canonical(name: str):
     """rocprofv3 prints some instantiations mangled and some through a lossy demangler: map both to bench.py's names."""
     if "cir" not in name:
         return None
+    m8 = re.search(r"gemm256_kernelIDF16_Lb1ELb([01])EfLi(n?)(\d)ELb0ELb1ELb([01])E", name)
+    if m8:                                                # "split8" operands (round 6): MIX instantiations, named as ops._gemm_split8 records them
+        return "cir::gemm256_kernel<split8%s>" % (",split8-out" if m8.group(4) == "1" else (",residual" if m8.group(1) == "1" else ""))
+    if "gemm_split8_kernel" in name:
+        return "cir::gemm_split8_kernel"
+    for short in ("layernorm_split8_kernel", "split8_kernel", "split16_kernel"):
+        if short in name:
+            return f"cir::{short}"
     m = re.search(r"gemm256_kernelI(DF16b|DF16_|Dh)Lb([01])ELb([01])E(f|DF16_|Dh)Li(n?)(\d)E(?:Lb([01])E)?", name)
     if m:                                                 # names as ops.gemm_kernel_name prints them (ACT: template constant or run time)
         t = "__bf16" if m.group(1) == "DF16b" else "_Float16"
@@ -113,7 +121,9 @@ def main():
                "counters_per_launch": {c: round(v, 1) for c, v in avg.items()}}
         if "GRBM_GUI_ACTIVE" in avg:
             cyc = avg["GRBM_GUI_ACTIVE"] / 8.0
-            row["effective_clock_ghz"] = round(cyc / (dur_us["GRBM_GUI_ACTIVE"] * 1e3), 3)
+            # GRBM_GUI_ACTIVE spans more than the kernel on short dispatches (the guide: the quotient reads high below ~0.3 ms - 3.6 / 5.4 GHz
+            # came out for 20-us kernels): no clock is quoted there, and the utilisation figures below are per GRBM cycle, not per kernel cycle
+            row["effective_clock_ghz"] = round(cyc / (dur_us["GRBM_GUI_ACTIVE"] * 1e3), 3) if dur_us["GRBM_GUI_ACTIVE"] >= 300.0 else None
             if "SQ_VALU_MFMA_BUSY_CYCLES" in avg:
                 row["mfma_pipe_utilisation"] = round(avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * cyc), 4)
             if "SQ_BUSY_CYCLES" in avg:
