@@ -869,7 +869,7 @@ def main():
     if world == 1 and not args.no_precision_table and not args.no_cpu_baseline:
         precision = {f"{args.dtype}+{args.stream_dtype}_stream": round(total_cand * args.steps / elapsed, 1)}
         for od, sd_ in (("f16", "f16"), ("f16", "split"), ("f16", "f32"), ("mixed", "f16"), ("bf16", "f16"), ("bf16", "f32"), ("text32", "split"), ("text32x3", "split")):
-            if (od, sd_) == (args.dtype, args.stream_dtype) or od == args.dtype:
+            if (od, sd_) == (args.dtype, args.stream_dtype) or (od == args.dtype and od.startswith("text32")):
                 continue
             n_steps = args.steps if od == "text32" else 3             # the real-weights mode at the headline's step count
             apply_precision(m2, od, sd_); apply_precision(m1, od, sd_)

@@ -429,6 +429,162 @@ __global__ __launch_bounds__(256) void attn_stream_kernel(const AttnArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
+// attn_split32_kernel (round 6): cir_attention_split8's kernel - fp32 q / k / v (the text side of the text32 mode: 32 x 32 self-attention per
+// head), fp32 softmax, context out as "split8" operand rows - with BOTH products on the fp16 MFMA as three-term sums of (hi, lo) fp16 pairs
+// formed in registers:  S = K_hi Q_hi + K_lo Q_hi + K_hi Q_lo,  O = V_hi P_hi + V_lo P_hi + V_hi P_lo  (each ~2^-21 of the product; the
+// MFMA keeps fp16 subnormals).  12 + 12 MFMAs of 32 cycles per 32-key tile instead of 32 + 32 f32-input MFMAs of 64 cycles: the fp32
+// kernel (attn_f32_kernel, still the exact mode's) spent 14 ms of a text32 step at half of the f32 matrix pipe's rate.
+// Structure = attn_stream_kernel: one wave per (item, head, 32 queries), K fragments straight from global memory, V through private LDS
+// tiles (one for the hi terms, one for the lo terms), next tile prefetched under the current tile's softmax.
+template <bool MASKED>
+__global__ __launch_bounds__(256) void attn_split32_kernel(const AttnArgs a) {
+    using X8 = f16x8;
+    __shared__ __attribute__((aligned(16))) char smem[4 * 2 * 4096];   // per wave: V_hi tile, V_lo tile (32 keys x 64 dh each)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+    if (unit >= a.total) return;
+    const int qt = (int)(unit % a.nqt);
+    int64_t t = unit / a.nqt;
+    const int h = (int)(t % a.H);
+    t /= a.H;
+    const int b0 = (int)(t % a.B0);
+    const int64_t b1 = t / a.B0;
+    const int r = lane & 31, hh = lane >> 5;
+    const int q0 = qt * 32;
+    const int qrow = min(q0 + r, a.Lq - 1);
+    const float* qp = reinterpret_cast<const float*>(a.q) + b1 * a.q_s1 + b0 * a.q_s0 + (int64_t)qrow * a.q_rs + h * 64 + 8 * hh;
+    const float* kb = reinterpret_cast<const float*>(a.k) + b1 * a.k_s1 + b0 * a.k_s0 + h * 64 + 8 * hh;
+    const float* vb = reinterpret_cast<const float*>(a.v) + b1 * a.v_s1 + b0 * a.v_s0 + h * 64;
+    const float* mp = MASKED ? a.mask + b1 * a.m_s1 + b0 * a.m_s0 : nullptr;
+
+    // eight consecutive fp32 values -> (hi, lo) fp16 fragments
+    auto split = [](const float4& x0, const float4& x1, X8& hi, X8& lo) {
+        const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const _Float16 hj = (_Float16)v[j];
+            hi[j] = hj;
+            lo[j] = (_Float16)(v[j] - (float)hj);
+        }
+    };
+    X8 qh[4], ql[4];
+#pragma unroll
+    for (int sx = 0; sx < 4; ++sx)
+        split(*reinterpret_cast<const float4*>(qp + 16 * sx), *reinterpret_cast<const float4*>(qp + 16 * sx + 4), qh[sx], ql[sx]);
+
+    char* vt_hi = smem + wave * 8192;
+    char* vt_lo = vt_hi + 4096;
+    int voff[2];
+    pv_lane_offsets(tr_lane_offset(lane), voff);
+    const float sl = a.scale * kLog2e;
+    const int nkt = (a.Lk + 31) >> 5;
+    const int vrow_l = lane >> 3, vch = lane & 7;
+    float4 kr[4][2], vr[4][2];
+    auto load_tile = [&](int kt) {
+        const int key0 = kt * 32;
+        const float* kp = kb + (int64_t)min(key0 + r, a.Lk - 1) * a.k_rs;
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx) { kr[sx][0] = *reinterpret_cast<const float4*>(kp + 16 * sx); kr[sx][1] = *reinterpret_cast<const float4*>(kp + 16 * sx + 4); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* vp = vb + (int64_t)min(key0 + vrow_l + 8 * i, a.Lk - 1) * a.v_rs + vch * 8;
+            vr[i][0] = *reinterpret_cast<const float4*>(vp);
+            vr[i][1] = *reinterpret_cast<const float4*>(vp + 4);
+        }
+    };
+    Softmax st;
+    st.init();
+    load_tile(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int key0 = kt * 32;
+        f32x16 s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx) {
+            X8 kh, kl;
+            split(kr[sx][0], kr[sx][1], kh, kl);
+            s = Elem<_Float16>::mfma32(kl, qh[sx], s);
+            s = Elem<_Float16>::mfma32(kh, ql[sx], s);
+            s = Elem<_Float16>::mfma32(kh, qh[sx], s);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            X8 vh, vl;
+            split(vr[i][0], vr[i][1], vh, vl);
+            const int row = vrow_l + 8 * i;
+            const int off = row * 128 + ((vch * 16) ^ (((row >> 1) & 1) << 6));
+            *reinterpret_cast<X8*>(vt_hi + off) = vh;
+            *reinterpret_cast<X8*>(vt_lo + off) = vl;
+        }
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        // ---- online softmax (log2 domain), probabilities kept in fp32 ----
+        float sv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            float x = s[i] * sl;
+            if constexpr (MASKED) x = fmaf(fmaxf(mp[min(key, a.Lk - 1)], -2.0e38f), kLog2e, x);
+            sv[i] = key < a.Lk ? x : -INFINITY;
+        }
+        float mx = sv[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sv[i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(st.m_run, mx);
+        const float alpha = exp2f(st.m_run - m_new);
+        st.m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            sv[i] = exp2f(sv[i] - m_new);
+            psum += sv[i];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        st.l_run = st.l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { st.o[0][i] *= alpha; st.o[1][i] *= alpha; }
+        X8 ph[2], pl[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const _Float16 hj = (_Float16)sv[8 * s2 + j];
+                ph[s2][j] = hj;
+                pl[s2][j] = (_Float16)(sv[8 * s2 + j] - (float)hj);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        pv_tile<_Float16>(st, vt_lo, voff, ph);
+        pv_tile<_Float16>(st, vt_hi, voff, pl);
+        pv_tile<_Float16>(st, vt_hi, voff, ph);
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- context / row sum -> split8 rows (as attn_f32_kernel's SPLIT epilogue: the half-waves exchange 4-element groups) ----
+    const float inv = 1.0f / st.l_run;
+    const int d_model = a.H * 64;
+    char* row = reinterpret_cast<char*>(a.out) + b1 * a.o_s1 + b0 * a.o_s0 + (int64_t)min(q0 + r, a.Lq - 1) * a.o_rs;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float lo4[4], hi4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { lo4[j] = st.o[dt][(2 * p) * 4 + j] * inv; hi4[j] = st.o[dt][(2 * p + 1) * 4 + j] * inv; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo4[j]), "+v"(hi4[j]));
+            const int f0 = h * 64 + dt * 32 + 8 * (2 * p + hh);
+            const Split4 s0 = split8_x4(lo4), s1 = split8_x4(hi4);
+            if (q0 + r < a.Lq) {
+                *reinterpret_cast<u32x4*>(row + 2 * f0) = u32x4{s0.h01, s0.h23, s1.h01, s1.h23};
+                *reinterpret_cast<u32x2*>(row + 2 * d_model + f0) = u32x2{s0.lo8, s1.lo8};
+                *reinterpret_cast<u32x2*>(row + 3 * d_model + f0) = u32x2{s0.hi8, s1.hi8};
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // cir_cls_cross_attention - cross-attention of ONE query row per (branch, head) over a candidate's image tokens, with the
 // K and V projections folded out of the token side (last fusion layer: only the two CLS rows reach cls_head,
 // nlvr_encoder.py:906-908, so per candidate there are 2 * H query vectors and N keys):
@@ -602,7 +758,7 @@ extern "C" int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t 
     const int lk_pad = (Lk + 31) & ~31;
     // K/V of a head are shared by its query tiles: stage them once per workgroup when there are several tiles
     // (up to 608 keys = 152 KiB of LDS: the 577-token ViT of the reference's 384-px scripts still fits one CU)
-    const int shared_max = g_tune[CIR_TUNE_ATTN_SHARED_MAX] == 0 ? 608 : g_tune[CIR_TUNE_ATTN_SHARED_MAX];   // (-1: never)
+    const int shared_max = (g_tune[CIR_TUNE_ATTN_SHARED_MAX] == 0 || g_tune[CIR_TUNE_ATTN_SHARED_MAX] == -2) ? 608 : g_tune[CIR_TUNE_ATTN_SHARED_MAX];   // (-1: never)
     const bool shared = a.nqt >= 2 && lk_pad <= shared_max;
     if (shared) {
         const int64_t nblk = (int64_t)B1 * B0 * H;
@@ -659,7 +815,14 @@ extern "C" int cir_attention_split8(const float* q, int64_t q_s1, int64_t q_s0, 
     a.scale = scale;
     a.wide_store = 0;
     a.out_split = 1;
-    return launch_attention_f32(a, reinterpret_cast<hipStream_t>(stream));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (g_tune[CIR_TUNE_ATTN_SHARED_MAX] == -2) return launch_attention_f32(a, s);   // (A/B and tests: the f32-input MFMA form of the same op)
+    const int64_t nblk = (a.total + 3) / 4;
+    if (nblk > 0x7fffffff) return CIR_ESHAPE;
+    dim3 grid((unsigned)nblk), block(256);
+    if (mask) hipLaunchKernelGGL((attn_split32_kernel<true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((attn_split32_kernel<false>), grid, block, 0, s, a);
+    CIR_LAUNCH_RESULT();
 }
 
 extern "C" int cir_cls_cross_attention(const void* x, int64_t x_s1, const int64_t* x_index, const void* qp, void* out, int T, int Lk, int D,

@@ -248,7 +248,7 @@ extern "C" int cir_set_tuning(int knob, int value) {
     switch (knob) {
         case CIR_TUNE_GEMM_TILE: if (value != 0 && value != 128 && value != 256) return CIR_EINVAL; break;
         case CIR_TUNE_GEMM_GROUP_W: if (value < 0 || value > 64) return CIR_EINVAL; break;
-        case CIR_TUNE_ATTN_SHARED_MAX: if (value != 0 && value != -1 && (value < 32 || value > 608)) return CIR_EINVAL; break;
+        case CIR_TUNE_ATTN_SHARED_MAX: if (value != 0 && value != -1 && value != -2 && (value < 32 || value > 608)) return CIR_EINVAL; break;
         default: return CIR_EINVAL;
     }
     cir::g_tune[knob] = value;

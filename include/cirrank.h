@@ -60,7 +60,8 @@ const char* cir_strerror(int code);
  *                             kernel where the shape allows it (cir_gemm_bias_act)
  *   CIR_TUNE_GEMM_GROUP_W     0 auto | 1..64    : n-panels per raster group of the 256x256 kernel
  *   CIR_TUNE_ATTN_SHARED_MAX  0 auto (608) | -1 never | 32..608 : largest padded key count for which
- *                             cir_attention stages a head's K/V once per workgroup in LDS
+ *                             cir_attention stages a head's K/V once per workgroup in LDS; -2: as 0, and cir_attention_split8
+ *                             runs on the f32-input MFMA (attn_f32_kernel) instead of its three-term fp16 form
  */
 enum { CIR_TUNE_GEMM_TILE = 0, CIR_TUNE_GEMM_GROUP_W = 1, CIR_TUNE_ATTN_SHARED_MAX = 2 };
 int cir_set_tuning(int knob, int value);

@@ -127,3 +127,28 @@ def test_vit_engine_with_and_without_the_fold(ops):
     err = {mode: (o - ref).abs().max().item() for mode, o in outs.items()}
     assert err[1] <= err[0] * 1.5 + 1e-4 and err[2] <= err[0] * 1.5 + 1e-4, err
     assert (outs[1] - outs[0]).abs().max().item() < 3e-2 and (outs[2] - outs[0]).abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize("mean,std,bound", [(3.0, 1.0, 1.0e-3), (50.0, 0.5, 4e-3)])
+def test_folded_layernorm_on_rows_with_a_large_common_offset(ops, mean, std, bound):
+    """Round-5 advisor finding: the folded form takes the row variance in ONE pass (E[x^2] - mean^2 over fp32 sums of the fp16 row), where the
+    LayerNorm pass subtracts the mean first.  Rows whose COMMON offset dwarfs their spread cancel: at |mean| / std = 100 the fp32 sum of
+    squares (1.9e6 per 768-wide row, ulp 0.125) carries the variance (0.25) less exactly - measured 1.5e-3 of the output's scale against 4.6e-4
+    for the LayerNorm pass + GEMM (bounded at 4e-3 here); for |mean| / std = 3 both forms sit at the fp16 output rounding (4.3e-4).  The ViT residual streams this kernel serves have row means within
+    a few sigma (their outlier CHANNELS raise the row's spread, not its mean: reference stream peak 344, row mean O(1)); a checkpoint whose rows
+    sit on a common offset of hundreds of sigma should run with `VitEngine.ln_fold = 0` (the LayerNorm pass)."""
+    m, n, k = 3000, 768, 768
+    g = torch.Generator(device="cpu").manual_seed(int(mean))
+    x = (torch.randn((m, k), generator=g) * std + mean).half().cuda()
+    w = (torch.randn((n, k), generator=g) * 0.03).cuda()
+    b = (torch.randn((n,), generator=g) * 0.1).cuda()
+    gamma = (1.0 + 0.2 * torch.randn((k,), generator=g)).cuda()
+    beta = (0.1 * torch.randn((k,), generator=g)).cuda()
+    wg, cs, bb = ops.ln_fold_pack(w, b, gamma, beta)
+    got = ops.gemm_ln(x, wg, cs, bb, 1e-6).double()
+    ref = _ref64(x, w, b, gamma, beta, 1e-6, False)
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    _, xb = ops.layernorm(x, gamma, beta, 1e-6, want32=False, dtype16=torch.float16, stream_dtype=torch.float16)
+    two = (ops.gemm(xb, w.half(), b).double() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"\n[LayerNorm fold, rows N({mean}, {std})] relative max error: folded {err:.2e}, LayerNorm pass + GEMM {two:.2e}")
+    assert err < bound

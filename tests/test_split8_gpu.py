@@ -196,7 +196,10 @@ def test_layernorm_split8_stream_and_rows(ops):
 
 @pytest.mark.parametrize("items,lq,lk,masked", [(300, 32, 32, True), (37, 1, 32, True), (5, 40, 77, False)])
 def test_attention_split8_rows(ops, items, lq, lk, masked):
-    """fp32 attention writing split8 rows = the fp32 attention's output through cir_split8, bit for bit (same products, same order)"""
+    """cir_attention_split8: fp32 q / k / v -> context as split8 rows.  Its kernel forms both products as three-term sums of (hi, lo) fp16 pairs
+    on the fp16 MFMA (attn_split32_kernel): within the rows' own 15 bits of the f32-input MFMA form and of fp64; the f32-input form of the same
+    entry point (tuning -2) writes exactly cir_split8 of cir_attention's fp32 output."""
+    from candidate_reranking_cir_amd import lib
     g = torch.Generator(device="cpu").manual_seed(items)
     d = 768
     qkv = torch.randn((2, items, max(lq, lk), 3 * d), generator=g).cuda()
@@ -209,4 +212,20 @@ def test_attention_split8_rows(ops, items, lq, lk, masked):
     ops.attention(q, k, v, out, 0.125, mask)
     sp = ops.attention_split8(q, k, v, 0.125, mask)
     assert sp.rows.shape == (2, items, lq, 4 * d)
-    assert torch.equal(sp.rows, ops.split8(out).rows)
+    lib.set_tuning(lib.TUNE_ATTN_SHARED_MAX, -2)
+    try:
+        sp32 = ops.attention_split8(q, k, v, 0.125, mask)
+    finally:
+        lib.set_tuning(lib.TUNE_ATTN_SHARED_MAX, 0)
+    assert torch.equal(sp32.rows, ops.split8(out).rows)
+    h = d // 64
+    qh, kh, vh = (t.double().reshape(2, items, -1, h, 64).permute(0, 1, 3, 2, 4) for t in (q, k, v))
+    sc = qh @ kh.transpose(-1, -2) * 0.125
+    if mask is not None:
+        sc = sc + mask.double()[:, :, None, None, :]
+    ref = (torch.softmax(sc, -1) @ vh).permute(0, 1, 3, 2, 4).reshape(2, items, lq, d)
+    got = sp.float().double()
+    assert bool(((got - ref).abs() <= 3.2e-5 * ref.abs() + 2e-6).all()), (got - ref).abs().max().item()
+    hi = sp.rows[..., :2 * d].contiguous().view(torch.float16).double()         # the fp16 terms alone: three-term products are far inside their rounding
+    assert (hi - ref).abs().max().item() <= (out.double() - ref).abs().max().item() + 1.1 * 2.0 ** -11 * ref.abs().max().item()
+    assert (got - out.double()).abs().max().item() < 5e-5 * max(1.0, ref.abs().max().item())
