@@ -7,7 +7,7 @@
 # The profiled program is `python3 bench.py ...` directly after `--` (no env / bash -c hop: the profiler's preloaded
 # library has initialised the GPU before the program starts).
 set -euo pipefail
-TAG=${1:-r5}
+TAG=${1:-r6}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
@@ -28,7 +28,12 @@ python3 tools/pmc_summary.py $OUT/${TAG}_train_pmc_summary.json $OUT/${TAG}_trai
 find $OUT/${TAG}_train_stats -name "*kernel_trace.csv" -delete
 python3 tools/kstats.py $OUT/${TAG}_train_stats 7 > $OUT/${TAG}_train_kstats.txt 2>&1      # 2 warm-up + 4 timed + 1 step with per-leg syncs
 # keep what travels back small: the per-dispatch kernel traces are not needed (the counter CSVs carry timestamps)
-find $OUT/${TAG}_stats $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write -name "*kernel_trace.csv" -delete
-python3 tools/kstats.py $OUT/${TAG}_stats 10 > $OUT/${TAG}_kstats.txt 2>&1
+python3 tools/kstats_trace.py $OUT/${TAG}_stats 2 6 > $OUT/${TAG}_kstats.txt 2>&1          # the 6 timed steps' launches only
+# the mode the factories set for real weights (text32: split8 operands), same command
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_text32_stats -o run -- python3 $ROOT/bench.py --dtype text32 --steps 6 --warmup 2 --no-cpu-baseline --no-precision-table --no-rank-fidelity > $OUT/${TAG}_text32_stats.json 2> $OUT/${TAG}_text32_stats.err
+cd $ROOT
+python3 tools/kstats_trace.py $OUT/${TAG}_text32_stats 2 6 > $OUT/${TAG}_text32_kstats.txt 2>&1
+find $OUT/${TAG}_stats $OUT/${TAG}_text32_stats $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write -name "*kernel_trace.csv" -delete
 python3 tools/pmc_summary.py $OUT/${TAG}_pmc_summary.json $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write > $OUT/${TAG}_pmc_summary.txt 2>&1
 du -sh $OUT/${TAG}_* | tail -12

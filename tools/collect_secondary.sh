@@ -2,7 +2,7 @@
 # Secondary-configuration bench lines, per-shape GEMM table, stand-alone kernel timings (GPU box; run through gpurun from
 # the repo root):   bash tools/collect_secondary.sh r3   -> gpurun_out/<tag>_sec/*.json|txt   (copy what is judged into profiles/)
 set -uo pipefail
-TAG=${1:-r5}
+TAG=${1:-r6}
 O=gpurun_out/${TAG}_sec
 mkdir -p $O
 python bench.py --steps 20 --warmup 5 > $O/bench_default_20steps.json 2> $O/err.txt                                   # the driver's command
@@ -21,7 +21,14 @@ python bench.py --mode loop --loop-queries 4181 --query-batch 64 > $O/bench_loop
 python bench.py --mode loop --k 50 --subset 0 --loop-queries 2017 --query-batch 64 > $O/bench_loop_fiq_dress_2017.json 2>> $O/err.txt            # FashionIQ dress, K = 50
 python bench.py --mode loop --k 100 --subset 0 --loop-queries 6016 --query-batch 64 > $O/bench_loop_config3_fiq_all_6016.json 2>> $O/err.txt   # BASELINE configs[3] whole (all three FashionIQ splits' query count) on ONE GPU
 python bench.py --mode loop --k 200 --subset 5 --loop-queries 512 --query-batch 64 > $O/bench_loop_config4_k200_512.json 2>> $O/err.txt          # BASELINE configs[4] whole on ONE GPU
-python bench.py --dtype text32 --steps 10 --warmup 3 --no-cpu-baseline --no-precision-table > $O/bench_text32.json 2>> $O/err.txt   # round 5: the factories' mode for real weights
+python bench.py --dtype text32 --steps 20 --warmup 5 --no-cpu-baseline --no-precision-table > $O/bench_text32.json 2>> $O/err.txt   # the factories' mode for real weights (round 6: split8 operands)
+python bench.py --dtype text32x3 --steps 10 --warmup 3 --no-cpu-baseline --no-precision-table > $O/bench_text32x3.json 2>> $O/err.txt   # round 5's three-product form
+python bench.py --dtype text32 --image-size 384 --queries 16 --steps 6 --warmup 2 --no-cpu-baseline --no-precision-table > $O/bench_384px_text32.json 2>> $O/err.txt
+python bench.py --tokens 40 --steps 10 --warmup 3 --no-cpu-baseline --no-precision-table --no-rank-fidelity > $O/bench_tokens40.json 2>> $O/err.txt   # captions beyond the fold's 32 tokens: projected cross-attention path
+python bench.py --tokens 40 --dtype text32 --steps 10 --warmup 3 --no-cpu-baseline --no-precision-table --no-rank-fidelity > $O/bench_tokens40_text32.json 2>> $O/err.txt
+python tools/split8_bench.py > $O/split8_gemm_shapes.txt 2>> $O/err.txt
+tools/f8_probe > $O/f8_probe.txt 2>> $O/err.txt
+tools/attn_mem_probe > $O/attn_mem_probe.txt 2>> $O/err.txt
 python bench.py --mode latency --k 100 --steps 40 --warmup 5 > $O/bench_latency_k100.json 2>> $O/err.txt                         # one query, launch by launch vs one HIP graph
 CIR_VIT_LNFOLD=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-precision-table --no-rank-fidelity > $O/bench_lnfold_off.json 2>> $O/err.txt
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-precision-table --no-rank-fidelity > $O/bench_lnfold_on.json 2>> $O/err.txt
