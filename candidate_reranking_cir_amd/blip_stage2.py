@@ -266,12 +266,25 @@ class BLIP_NLVR(_EngineHost):
     def img_embed(self, image, train=True, atts=False):
         """(B,3,H,W) -> (B, N, D) fp32 image tokens [+ ones (B, N) int64], blip_stage2.py:57-63.  In `.train()` mode with autograd enabled and
         a trainable ViT (`--blip-img-tune`, stage2_train.py:87-92, 191-199) the tokens carry a graph: `train_vit.vit_train`, whose reverse
-        pass fills `.grad` of every visual_encoder parameter; otherwise (eval mode, torch.no_grad(), frozen ViT) the inference engine."""
+        pass fills `.grad` of every visual_encoder parameter; in `.train()` mode without a graph (frozen ViT / torch.no_grad(),
+        stage2_train.py:183-190) the encoder still draws DropPath like the reference's (`VitEngine.forward_drop_path`); in eval mode the
+        inference engine."""
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for n, p in self.named_parameters() if n.startswith("visual_encoder.")):
             if self.device.type != "cuda":
                 raise RuntimeError("BLIP_NLVR runs on an MI355X only: move the model to 'cuda' (no CPU path)")
             from .train_vit import vit_train
             y32 = vit_train(self, image)
+        elif self.training and float(getattr(self.vit_geometry, "drop_path_rate", 0.0)) > 0.0 and self.vit_geometry.depth > 1 and self.token_dtype != torch.float32:
+            # .train() mode without a graph (frozen ViT, or under torch.no_grad(): stage2_train.py:183-190): the reference's DropPath modules
+            # are in training mode there and drop each sample's residual branches (vit.py:98-109, rate linspace(0, 0.1, depth)[i]) - so do we
+            # (round 6; rounds 3-5 ran the inference engine here).  The draws come from torch's global generator, like timm's.
+            with torch.no_grad():
+                geo = self.vit_geometry
+                rates = torch.linspace(0.0, float(geo.drop_path_rate), geo.depth)                       # vit.py:153
+                keep = 1.0 - rates
+                draw = torch.rand((geo.depth, 2, image.shape[0]))
+                scales = (draw < keep[:, None, None]).float() / keep[:, None, None]                     # timm drop_path: floor(keep + U) / keep
+                y32 = self.engines(text=False)[0].forward_drop_path(image.to(self.device), scales.to(self.device))
         else:
             with torch.no_grad():
                 y32, _ = self.engines(text=False)[0].forward(image.to(self.device), want32=True)

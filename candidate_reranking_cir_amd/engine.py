@@ -54,10 +54,14 @@ def _mark_split(mode: int, layers, *extra):
         mark(w)
 
 
-def _split_mode(split3, dtype) -> int:
-    """engine argument `split3` (kept name): False / 0 = the f32-input MFMA, True / 3 = three fp16 products, 8 = split8 rows"""
+def _split_mode(split3, dtype, geo=None) -> int:
+    """engine argument `split3` (kept name): False / 0 = the f32-input MFMA, True / 3 = three fp16 products, 8 = split8 rows.
+    split8 needs whole K-tile pairs in each of its three K segments (every Linear's depth a multiple of 256: hidden 768 / 1024, FFN 3072 / 4096,
+    cls_head 2 x hidden); a geometry outside that (the 128-wide test geometries) takes the three-product form instead."""
     if dtype != torch.float32 or not split3:
         return 0
+    if split3 == 8 and geo is not None and (geo.hidden_size % 256 or geo.intermediate_size % 256):
+        return 3
     return 8 if split3 == 8 else 3
 
 
@@ -181,6 +185,37 @@ class VitEngine:
         return (y32.view(bsz, n, d) if want32 else None), y16.view(bsz, n, d)
 
 
+    @torch.no_grad()
+    def forward_drop_path(self, image: torch.Tensor, scales: torch.Tensor) -> torch.Tensor:
+        """The same encoder with timm's DropPath around both residual branches of every block (vit.py:98-109; blip_stage2.py:37 builds the
+        stage-II image encoder with drop_path_rate 0.1): `scales` (depth, 2, B) fp32 holds 0 for a dropped (block, branch, sample) and
+        1 / keep for a kept one.  What `img_embed` runs in .train() mode WITHOUT a graph (frozen ViT, stage2_train.py:183-190 under
+        torch.no_grad(): the reference's DropPath modules are active there) - round 6.  fp32 residual stream, the engine's 16-bit weights;
+        returns fp32 tokens (B, N, D).  Not a benchmark path: the branch outputs take a separate scale-and-add pass."""
+        from . import train_ops as T
+        geo, dt = self.geo, self.dtype
+        if dt == torch.float32:
+            raise RuntimeError("DropPath embeds run on 16-bit operands: leave the exact mode for training")
+        bsz, d, n = image.shape[0], geo.width, geo.num_tokens
+        assert tuple(scales.shape) == (geo.depth, 2, bsz) and scales.dtype == torch.float32
+        if image.dtype not in (torch.float32, dt):
+            image = image.float()
+        f32 = torch.float32
+        patches = ops.patchify(image.contiguous(), geo.patch_size, dt)
+        x = ops.vit_assemble(ops.gemm(patches, self.w_patch, self.b_patch, out_dtype=f32), self.cls, self.pos, bsz).view(bsz * n, d)
+        ctx = torch.empty((bsz, n, d), dtype=dt, device=x.device)
+        for i, blk in enumerate(self.blocks):
+            _, xb = ops.layernorm(x, blk["g1"], blk["b1"], geo.layer_norm_eps, want32=False, dtype16=dt, stream_dtype=f32)
+            qkv = ops.gemm(xb, blk["wqkv"], blk["bqkv"]).view(bsz, n, 3, d)
+            ops.attention(qkv[:, :, 0].unsqueeze(1), qkv[:, :, 1].unsqueeze(1), qkv[:, :, 2].unsqueeze(1), ctx.unsqueeze(1), 64 ** -0.5)
+            x = T.rows_scale_add(x, ops.gemm(ctx.view(bsz * n, d), blk["wo"], blk["bo"], out_dtype=f32), scales[i, 0].contiguous(), n)   # vit.py:108
+            _, xb = ops.layernorm(x, blk["g2"], blk["b2"], geo.layer_norm_eps, want32=False, dtype16=dt, stream_dtype=f32)
+            f = ops.gemm(xb, blk["w1"], blk["c1"], act=ops.ACT_GELU)
+            x = T.rows_scale_add(x, ops.gemm(f, blk["w2"], blk["c2"], out_dtype=f32), scales[i, 1].contiguous(), n)                       # vit.py:109
+        y32, _ = ops.layernorm(x, self.gf, self.bf, geo.layer_norm_eps, want32=True, dtype16=None, stream_dtype=f32)
+        return y32.view(bsz, n, d)
+
+
 # =================================================================================================
 class KVBank(list):
     """Per-layer cross-attention K|V of an index-feature bank: entry i is (n_index, N, 4D) - or None for
@@ -200,7 +235,7 @@ class MedEngine:
                  stream_dtype: Optional[torch.dtype] = None, cross_dtype: Optional[torch.dtype] = None, split3: bool = False):
         geo.validate()
         self.geo, self.dtype, self.device, self.stream_dtype = geo, dtype, device, _auto_stream(dtype, stream_dtype)
-        self.split = _split_mode(split3, dtype)
+        self.split = _split_mode(split3, dtype, geo)
         self.split3 = self.split != 0
         self.xdtype = xdt = cross_dtype or dtype       # operand type of the image-facing block (module docstring)
         e = prefix + "embeddings."
@@ -283,7 +318,7 @@ class NlvrEngine:
                  stream_dtype: Optional[torch.dtype] = None, cross_dtype: Optional[torch.dtype] = None, split3: bool = False):
         geo.validate()
         self.geo, self.dtype, self.device, self.fold_merge, self.stream_dtype = geo, dtype, device, fold_merge, _auto_stream(dtype, stream_dtype)
-        self.split = _split_mode(split3, dtype)
+        self.split = _split_mode(split3, dtype, geo)
         self.split3 = self.split != 0
         self.xdtype = xdt = cross_dtype or dtype   # operand type of the cross-attention block = type of the candidate tokens (module docstring)
         self.trim_last = True   # last layer: per-token work on the CLS rows only (results identical for the rows that are used)

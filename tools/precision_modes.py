@@ -56,8 +56,8 @@ def apply(m, mode):
     if hasattr(m, "set_text_stream32_from"):                       # (the stage-I model has no two-branch encoder)
         m.set_text_stream32_from(MODES[mode][4] if len(MODES[mode]) > 4 else None)
     if dt == F32:
-        m.text_split3 = MODES[mode][5] if len(MODES[mode]) > 5 else 8
-        return m.set_precision("exact" if idt is None else "text32")
+        arith = MODES[mode][5] if len(MODES[mode]) > 5 else 8
+        return m.set_precision("exact" if idt is None else ("text32" if arith == 8 else "text32x3"))
     if m.compute_dtype == F32:
         m.set_precision("f16")
     m.set_compute_dtype(dt, idt)
