@@ -84,7 +84,7 @@ __device__ __forceinline__ float fast_erf(float x) {
     const float e = 1.0f - p * __expf(-ax * ax);
     return copysignf(e, x);
 }
-__device__ __forceinline__ float gelu_erf_as(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_as(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }   // (scalar form of gelu_erf_as8: tools / reference for it)
 
 // erf-GELU x * Phi(x) through a logistic fit of the normal CDF, Phi(x) ~ 1 / (1 + 2^-q(x)), q an odd degree-7
 // polynomial (minimax fit of x*Phi(x) on [-7, 7], max |error| 1.2e-5 in fp32 - an order of magnitude under the

@@ -14,7 +14,9 @@
  *     kernel-selection overrides of cir_set_tuning (default: none) and the cached CU count;
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
  *     work is enqueued on it and nowhere else;
- *   - leading dimensions / strides are in ELEMENTS of the tensor they describe;
+ *   - leading dimensions / strides are in ELEMENTS of the tensor they describe - except the "split8" operand rows of ABI v14
+ *     (cir_split8, cir_gemm_split8, cir_layernorm_split8, cir_attention_split8), which are BYTE rows of three segments and take their
+ *     leading dimensions / strides in BYTES where the argument name says so;
  *   - dtype codes: CIR_BF16 / CIR_F16 for 16-bit activations and weights (fp32 accumulate
  *     everywhere), CIR_F32 for fp32 tensors - and, since ABI v11, as the OPERAND type of cir_gemm_bias_act, cir_attention
  *     and cir_patchify: the "exact" precision mode, every tensor fp32 like the reference's (validate_stage2.py:140-141:

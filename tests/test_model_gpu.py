@@ -300,7 +300,15 @@ def test_full224(cuda, tag, dtype):
     assert ok and decided >= (30 if dtype == HF else 9)     # of 45 pairs (bf16 on these clustered logits: few, see rank224)
     # exact sorted order of the K = 10 candidates: fp16 operands reproduce it; bf16 measured 0.80 / 0.60 (test / spread weights:
     # one resp. two swaps of neighbours whose reference gap is below the bf16 drift)
-    assert exact >= (1.0 if dtype == HF else 0.4)          # (10 clustered logits, sigma 0.026: bf16 0.4 - 0.6 across the rounds' rounding changes)
+    # (10 clustered logits, sigma 0.026: bf16 0.4 - 0.6 across the rounds' rounding changes; fp16 1.0 through round 5 and 0.8 - ONE swap of
+    #  neighbours - since round 6's lazy softmax rescale re-rolled the ViT's roundings: what fp16 must hold is every pair the reference separates
+    #  by more than the logit tolerance itself, i.e. any position that differs is a neighbour swap inside the tolerance)
+    assert exact >= (0.8 if dtype == HF else 0.4)
+    if dtype == HF:
+        iu = np.triu_indices(len(logits), 1)
+        d_ref, d_our = (z["logits"][:, None] - z["logits"][None, :])[iu], (logits[:, None] - logits[None, :])[iu]
+        sep = np.abs(d_ref) > tol
+        assert np.all(np.sign(d_ref[sep]) == np.sign(d_our[sep])) and int(sep.sum()) >= 38
 
 
 def test_full384_cirr_loop(cuda):
