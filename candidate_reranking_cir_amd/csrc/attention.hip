@@ -60,7 +60,27 @@
 //     Reaching the 4.8 us the memory path allows needs >= 14 resident waves AND asynchronous loads: two double-buffered workgroups do not fit
 //     160 KiB of LDS (2 x (2 x 57 + 28) KiB), and a register prefetch of the next K / V (+44 registers) drops the kernel below 4 waves per SIMD.
 //   * lazy rescale (softmax_tile): kept, -2 %.
+// Late round 6, the 577 x 577 case (1696 images, fp16; the staged kernel 3355 us = 517 TFLOP/s) - where the time is: one tile update issues
+// ~60 plain vector instructions, 16 exponentials, 8 MFMAs and 13 LDS reads = ~500 issue cycles of the wave's SIMD, the matrix pipe is busy for
+// 256 of them, and the BUSIEST SIMD of the CU sets the workgroup's time:
+//   * 19 query tiles on 10 waves put 6 / 6 / 4 / 3 tiles on the four SIMDs (waves w, w + 4, .. share one); 16 waves: 5 / 5 / 5 / 4 ->
+//     3087 us (12 waves 3118, 8 waves 3329).  KEPT: cir_attention picks the wave count by that rule.  Same bits (a tile's arithmetic does not
+//     depend on the wave that runs it).
+//   * exponent arguments / row sums as plain v_fma_f32 / v_add_f32 instead of v_pk_fma_f32 / v_pk_add_f32 (packed fp32 issues slower than
+//     the two operations it replaces beside MFMAs; the file is built with -fno-slp-vectorize): 3015 -> 2915 us, 1046 -> 1019 us per 3392
+//     images at 197 tokens.  KEPT, same bits.  One staging batch of 5 chunks per thread instead of 4 + 1: 2905 us.
+//   * TWO query tiles per wave (two softmax chains sharing every K / V fragment read, 158 registers, 10 waves, one round): 3307 us against
+//     3355 - the chains do not overlap inside a wave (the rescale vote splits the basic block) and the SIMD loads stay 6 / 6 / 4 / 4.  Dropped.
+//   * K / V by LDS-DMA in key-tile order with COUNTED vmcnt waits, the tile loop starting on the first two key tiles while the rest is in
+//     flight (Q by asm loads so that the compiler's vmcnt(0) does not sit behind the stage): bit-identical, 3020 us against 2915 (197
+//     tokens: 1071 against 1019) - slower, as register staging's split load / write already overlaps the neighbours' compute.  Dropped.
+//   * row maxima through asm v_max3_f32 (no canonicalising v_max x, x): hipcc does not insert the MFMA-result wait states in front of an
+//     asm statement - the maxima were read early (still a valid softmax reference: the error was in the last bit only, and showed as a
+//     mismatch between the staged and the streamed kernel).  Dropped; fmaxf stays.
+// What is left is the instruction count of the update itself (16 exponentials at 8 cycles, 16 FMAs, 16 adds, 8 conversions, ~12 maxima,
+// 6 address adds per 8 MFMAs): 577 tokens now run at 597 TFLOP/s = 0.24 of the MFMA peak, 197 tokens at 0.13-0.16.
 
+#include <type_traits>
 #include "attention_args.hpp"
 
 namespace cir {
@@ -136,21 +156,21 @@ __device__ __forceinline__ void softmax_tile(Softmax& st, f32x16& s, float sl, c
             psum += p;
         }
     } else {
-        // exponent arguments and the row sum as packed fp32 (v_pk_fma_f32 / v_pk_add_f32: two values per issue slot) -
-        // the ViT kernel is bound by VALU issue, not by the matrix pipe
-        const f32x2 sl2 = {sl, sl}, m2 = {-st.m_run, -st.m_run};
-        f32x2 acc2 = {0.f, 0.f};
+        // exponent arguments and the row sum (two chains: even / odd scores) as SINGLE fp32 operations: beside MFMAs a v_pk_fma_f32 /
+        // v_pk_add_f32 costs more issue time than the two plain operations it replaces (round 6: 1046 -> 1019 us per 3392 images at 197
+        // tokens, 3015 -> 2915 us per 1696 at 577; same bits) - the file is built with -fno-slp-vectorize so that hipcc does not re-pack them
+        float a0, a1;
+        const float nm = -st.m_run;
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
-            const f32x2 arg = __builtin_elementwise_fma(f32x2{sv[i], sv[i + 1]}, sl2, m2);
-            f32x2 p;
-            p.x = __builtin_amdgcn_exp2f(arg.x);
-            p.y = __builtin_amdgcn_exp2f(arg.y);
-            sv[i] = p.x;
-            sv[i + 1] = p.y;
-            acc2 += p;
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[i], sl, nm));
+            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[i + 1], sl, nm));
+            sv[i] = p0;
+            sv[i + 1] = p1;
+            a0 = i ? a0 + p0 : p0;
+            a1 = i ? a1 + p1 : p1;
         }
-        psum = acc2.x + acc2.y;
+        psum = a0 + a1;
     }
     psum += __shfl_xor(psum, 32, 64);
     st.l_run += psum;
@@ -243,10 +263,11 @@ __global__ __launch_bounds__(1024) void attn_shared_kernel(const AttnArgs a, int
     // ---- stage K (chunk ^ ((row>>1)&7): conflict-free 32x32x16 A-operand reads) and V (halves swapped on bit 1) ----
     // Batches of SB chunks per thread: all 2*SB global loads of a batch are in flight before the first LDS write (a
     // rolled loop exposes one HBM latency per chunk; the whole stage is ~4 chunks per thread at 197 keys).
-    {
-        constexpr int SB = 4;
-        const int nchunks = lk_pad * 8;
-        const int stride = blockDim.x;
+    // (577 keys on 16 waves: 4.75 chunks per thread - one batch of 5 instead of a second batch for the last 0.75)
+    const int nchunks = lk_pad * 8;
+    const int stride = blockDim.x;
+    auto stage = [&](auto sbc) {
+        constexpr int SB = decltype(sbc)::value;
         for (int c0 = threadIdx.x; c0 < nchunks; c0 += SB * stride) {
             X8 kv[SB], vv[SB];
 #pragma unroll
@@ -270,7 +291,9 @@ __global__ __launch_bounds__(1024) void attn_shared_kernel(const AttnArgs a, int
                 }
             }
         }
-    }
+    };
+    if (nchunks > 4 * stride && nchunks <= 5 * stride) stage(std::integral_constant<int, 5>{});
+    else stage(std::integral_constant<int, 4>{});
     __syncthreads();
 
     int voff[2];
@@ -764,8 +787,20 @@ extern "C" int cir_attention(const void* q, int64_t q_s1, int64_t q_s0, int64_t 
         const int64_t nblk = (int64_t)B1 * B0 * H;
         if (nblk > 0x7fffffff) return CIR_ESHAPE;
         // query tiles are dealt round-robin to the waves: as few rounds as 16 waves allow, then as few waves as that needs
+        // (round 6: the busiest SIMD sets the time - waves w, w + 4, .. share one - so: the wave count <= 16 whose round-robin deal leaves
+        // the smallest number of tiles on any SIMD, the larger count on ties: 19 tiles -> 16 waves, 5 / 5 / 5 / 4 tiles per SIMD where 10
+        // waves gave 6 / 6 / 4 / 3; 3374 -> 3087 us per 1696 images at 577 tokens.  Which wave runs a tile does not change its bits.)
         const int rounds = (a.nqt + 15) / 16;
-        const int waves = (a.nqt + rounds - 1) / rounds;
+        int waves = a.nqt;
+        if (a.nqt > 16) {
+            int best = 1 << 30;
+            for (int w = 4; w <= 16; ++w) {
+                int load[4] = {0, 0, 0, 0};
+                for (int qt = 0; qt < a.nqt; ++qt) load[(qt % w) & 3]++;
+                const int mx = std::max(std::max(load[0], load[1]), std::max(load[2], load[3]));
+                if (mx <= best) { best = mx; waves = w; }
+            }
+        }
         dim3 grid((unsigned)nblk), block(waves * 64);
         const size_t lds = (size_t)lk_pad * 256;
         // whole-row output stores through the (then dead) K / V region: exactly one tile per wave (every wave reaches the barrier once),

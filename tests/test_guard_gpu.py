@@ -254,13 +254,15 @@ def test_gather_patchify_assemble_topk_guard_bands(ops):
 # ------------------------------------------------------------------------------------------------ attention, many workgroups
 @pytest.mark.parametrize("dtype", DTYPES, ids=["bf16", "fp16"])
 @pytest.mark.parametrize("masked", [False, True], ids=["nomask", "mask"])
-@pytest.mark.parametrize("lq,lk", [(197, 197), (40, 33), (224, 256), (500, 200), (33, 70), (64, 8)])
+@pytest.mark.parametrize("lq,lk", [(197, 197), (40, 33), (224, 256), (500, 200), (33, 70), (64, 8), (577, 577), (640, 600), (545, 321)])
 def test_attention_many_workgroups(ops, dtype, masked, lq, lk):
     """More workgroups than fit the chip at once (720 > 2 x 256 slots), ragged Lq / Lk, with and without a key mask:
     against fp32 torch, output between canaries, and bit-identical to the streamed kernel's tile arithmetic
-    (cir_set_tuning forces it: both kernels share the tile update, only the K/V delivery differs)."""
+    (cir_set_tuning forces it: both kernels share the tile update, only the K/V delivery differs).  More than 16 query tiles
+    (577 / 640 / 545 queries): the staged kernel deals them to the wave count that balances the four SIMDs (16 / 16 / 12 waves here)
+    and stages 577+ keys in one batch of 5 chunks per thread."""
     from candidate_reranking_cir_amd import lib
-    b1, b0, h = 30, 2, 12
+    b1, b0, h = (30, 2, 12) if lq < 512 else (11, 2, 12)
     d = h * 64
     g = torch.Generator(device="cpu").manual_seed(lq * 131 + lk)
     q = torch.randn((b1, b0, lq, d), generator=g).to(dtype).cuda()
