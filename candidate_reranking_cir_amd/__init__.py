@@ -8,4 +8,4 @@ Importing the package does not load the library; the first op does and fails lou
 from .config import BertGeometry, VitGeometry, HEAD_DIM  # noqa: F401
 
 __version__ = "0.1.0"
-ABI_VERSION = 14  # CIR_ABI_VERSION in include/cirrank.h
+ABI_VERSION = 15  # CIR_ABI_VERSION in include/cirrank.h

@@ -6,6 +6,7 @@
 // triplet, head)), row softmax with additive mask and counter-based dropout (+ backward), LayerNorm backward, GELU / ReLU
 // forward-backward, dropout, column sums, embedding scatter-add, AdamW.  None of it is on the inference path.
 
+#include <algorithm>
 #include "common.hpp"
 
 namespace cir {
@@ -591,9 +592,107 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
     p[i] = w;
 }
 
+// ---- the optimizer step without a host read (round 6) -------------------------------------------------------------------------------
+// state (device, 8 x 32 bit): [0] found_inf of the step in flight, [1] applied steps t, [2] skipped steps, [3] / [4] the fp32 bias
+// corrections 1 - beta^t of the step in flight.  cir_grads_check ORs into [0]; cir_adamw_begin turns the flag into t / skipped and the
+// corrections; cir_adamw_step_dev returns at once when the flag is set - GradScaler.step's found_inf skip (stage2_train.py:215-218) with
+// the decision taken where the gradients are.
+__global__ __launch_bounds__(256) void grads_check_kernel(float* g, int64_t n4, int64_t n, float scale, int* state) {
+    int bad = 0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 x = reinterpret_cast<float4*>(g)[i];
+        if (scale != 1.f) {
+            x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale;
+            reinterpret_cast<float4*>(g)[i] = x;
+        }
+        // (finite <=> exponent field not all ones)
+        auto nf = [](float f) { return (int)((__float_as_uint(f) & 0x7f800000u) == 0x7f800000u); };
+        bad |= nf(x.x) | nf(x.y) | nf(x.z) | nf(x.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) {           // tail of a length that is not a multiple of 4
+        float x = g[4 * n4 + threadIdx.x];
+        if (scale != 1.f) { x *= scale; g[4 * n4 + threadIdx.x] = x; }
+        bad |= (__float_as_uint(x) & 0x7f800000u) == 0x7f800000u;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(state, 1);
+}
+
+__global__ void adamw_begin_kernel(int* state, float b1, float b2) {
+    if (threadIdx.x || blockIdx.x) return;
+    if (state[0]) { state[2] += 1; return; }
+    const int t = state[1] + 1;
+    state[1] = t;
+    reinterpret_cast<float*>(state)[3] = (float)(1.0 - pow((double)b1, (double)t));
+    reinterpret_cast<float*>(state)[4] = (float)(1.0 - pow((double)b2, (double)t));
+}
+
+template <typename T16>
+__global__ __launch_bounds__(256) void adamw_dev_kernel(float* p, const float* g, float* m, float* v, int64_t n4, int64_t n, float lr, float b1, float b2,
+                                                        float eps, float wd, const int* state, T16* p16) {
+    if (state[0]) return;                                               // non-finite gradients somewhere in this step: nothing is applied
+    const float bc1 = reinterpret_cast<const float*>(state)[3], bc2 = reinterpret_cast<const float*>(state)[4];
+    auto upd = [&](float& pi, float gi, float& mi, float& vi) {
+        mi = b1 * mi + (1.f - b1) * gi;
+        vi = b2 * vi + (1.f - b2) * gi * gi;
+        float w = pi * (1.f - lr * wd);
+        w -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+        pi = w;
+    };
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
+        reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+        if (p16) {
+            u32x2 h;
+            h.x = pack2<T16>(pp.x, pp.y); h.y = pack2<T16>(pp.z, pp.w);
+            reinterpret_cast<u32x2*>(p16)[i] = h;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) {
+        const int64_t j = 4 * n4 + threadIdx.x;
+        float pi = p[j], mi = m[j], vi = v[j];
+        upd(pi, g[j], mi, vi);
+        p[j] = pi; m[j] = mi; v[j] = vi;
+        if (p16) p16[j] = static_cast<T16>(pi);
+    }
+}
+
 }  // namespace cir
 
 using namespace cir;
+
+extern "C" int cir_grads_check(float* g, int64_t n, float scale, int32_t* state, void* stream) {
+    CIR_CHECK_PTR(g); CIR_CHECK_PTR(state);
+    if (n <= 0) return CIR_EINVAL;
+    if (!cir_aligned16(g)) return CIR_EALIGN;
+    const int64_t n4 = n / 4;
+    const unsigned blocks = (unsigned)std::min<int64_t>(std::max<int64_t>((n4 + 255) / 256, 1), 256 * 16);
+    hipLaunchKernelGGL(grads_check_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, n4, n, scale, state);
+    CIR_LAUNCH_RESULT();
+}
+
+extern "C" int cir_adamw_begin(int32_t* state, float beta1, float beta2, void* stream) {
+    CIR_CHECK_PTR(state);
+    hipLaunchKernelGGL(adamw_begin_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), state, beta1, beta2);
+    CIR_LAUNCH_RESULT();
+}
+
+extern "C" int cir_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                                  float weight_decay, const int32_t* state, void* p16, int dtype16, void* stream) {
+    CIR_CHECK_PTR(p); CIR_CHECK_PTR(g); CIR_CHECK_PTR(m); CIR_CHECK_PTR(v); CIR_CHECK_PTR(state);
+    if (n <= 0) return CIR_EINVAL;
+    if (p16 && dtype16 != CIR_BF16 && dtype16 != CIR_F16) return CIR_EDTYPE;
+    if (!cir_aligned16(p) || !cir_aligned16(g) || !cir_aligned16(m) || !cir_aligned16(v) || (p16 && (reinterpret_cast<uintptr_t>(p16) & 7))) return CIR_EALIGN;
+    const int64_t n4 = n / 4;
+    const dim3 grid((unsigned)std::max<int64_t>((n4 + 255) / 256, 1)), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (p16 && dtype16 == CIR_BF16) hipLaunchKernelGGL((adamw_dev_kernel<__bf16>), grid, block, 0, s, p, g, m, v, n4, n, lr, beta1, beta2, eps, weight_decay, state, reinterpret_cast<__bf16*>(p16));
+    else hipLaunchKernelGGL((adamw_dev_kernel<_Float16>), grid, block, 0, s, p, g, m, v, n4, n, lr, beta1, beta2, eps, weight_decay, state, reinterpret_cast<_Float16*>(p16));
+    CIR_LAUNCH_RESULT();
+}
 
 extern "C" int cir_transpose16(const void* src, void* dst, int rows, int cols, int64_t ld_src, int64_t ld_dst, int batch, int64_t s_src,
                                int64_t s_dst, int dtype, void* stream) {

@@ -87,6 +87,9 @@ SIGNATURES = {
     "cir_colsum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "cir_embed_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "cir_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p]),
+    "cir_grads_check": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p]),
+    "cir_adamw_begin": (c_int, [c_void_p, c_float, c_float, c_void_p]),
+    "cir_adamw_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_int, c_void_p]),
 }
 
 _lib = None

@@ -29,11 +29,12 @@ fills `.grad` of every trainable parameter (accumulating, as autograd does); `Ad
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Dict, List, Optional
 
 import torch
 
-from . import ops, train_ops as T
+from . import lib, ops, train_ops as T
 
 
 def _cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -57,6 +58,9 @@ def _gemm_ok(m: int, n: int, k: int) -> bool:
     return k % 64 == 0 and n % 16 == 0
 
 
+_SLABS: Dict[int, "weakref.ref"] = {}     # flat32 base pointer -> the slab that owns it (AdamW.step finds the 16-bit copy to write along)
+
+
 class _Slab:
     """The trained parameters as ONE flat fp32 buffer (each nn.Parameter's `.data` re-pointed to its slice: optimizers update the
     buffer in place), their 16-bit operand copies as one flat buffer refreshed by one cast per step, and their gradients as one
@@ -77,7 +81,9 @@ class _Slab:
             v = self._view(self.flat32, n)
             v.copy_(p.data)
             p.data = v
+        _SLABS[self.flat32.data_ptr()] = weakref.ref(self)
         self.flat16 = self.flat16t = self.gflat = self.plan = None
+        self._fresh16 = None                                                        # (flat32._version, PARAM_EPOCH) flat16 was written for
 
     def _view(self, flat: torch.Tensor, n: str) -> torch.Tensor:
         p = self.params[n]
@@ -93,10 +99,16 @@ class _Slab:
         if self.flat16 is None:
             self.flat16 = torch.empty(self.flat32.shape, dtype=self.dtype, device=self.flat32.device)
             self.flat16t = torch.zeros_like(self.flat16)
-        T.eltwise(self.flat32, T.MODE_SCALE, p_drop=1.0, out=self.flat16)
+        if self._fresh16 != (self.flat32._version, lib.PARAM_EPOCH[0]):             # (AdamW.step below writes flat16 in its own pass)
+            T.eltwise(self.flat32, T.MODE_SCALE, p_drop=1.0, out=self.flat16)
         if self.plan is not None:
             self.plan.run(self.flat16, self.flat16t)
         self.gflat = torch.zeros_like(self.flat32)
+
+    def mark_fresh16(self):
+        """flat16 holds the 16-bit copy of flat32 AS IT IS NOW (the optimizer wrote both): the next begin_step skips its cast unless a torch
+        op (another optimizer, a manual edit: the version counter moves) or another of our launches (PARAM_EPOCH) touches the parameters first."""
+        self._fresh16 = (self.flat32._version, lib.PARAM_EPOCH[0])
 
     def w32(self, n): return self._view(self.flat32, n)
     def w16(self, n): return self._view(self.flat16, n)
@@ -633,12 +645,20 @@ class NlvrTrainer:
     def _collect(self) -> Dict[str, torch.Tensor]:
         """{name: gradient}: views of the flat gradient buffer (unscaled in one launch when the pass ran on S * dlogits)."""
         slab = self.slab
-        if self.grad_scale != 1.0:
+        # fp16 operands: an intermediate gradient above 65504 turns into inf -> NaN in the weight gradients.  What GradScaler's unscale_ /
+        # found_inf do for the reference (stage2_train.py:215-218) in ONE pass over the buffer: divide by S and note any non-finite element
+        # in a device flag that AdamW.step consumes on the device (round 6; before: one scaling pass + the five passes of torch.isfinite)
+        self.grads_finite = _unscale_and_check(slab.gflat, self.grad_scale) if self.dtype == torch.float16 else None
+        if self.dtype != torch.float16 and self.grad_scale != 1.0:
             slab.gflat = T.eltwise(slab.gflat, T.MODE_SCALE, p_drop=1.0 / self.grad_scale)
-        # fp16 operands: an intermediate gradient above 65504 turns into inf -> NaN in the weight gradients.  What GradScaler's
-        # found_inf does for the reference (stage2_train.py:215-218): one reduction, read by AdamW.step (which skips the update)
-        self.grads_finite = torch.isfinite(slab.gflat).all() if self.dtype == torch.float16 else None
         return {n: slab.grad(n) for n in slab.names}
+
+
+def _unscale_and_check(gflat: torch.Tensor, grad_scale: float) -> torch.Tensor:
+    """gflat /= grad_scale in place; returns a 0-dim bool tensor "all finite" (no host read)."""
+    st = torch.zeros((8,), dtype=torch.int32, device=gflat.device)
+    T.grads_check(gflat, st, 1.0 / grad_scale)
+    return st[0] == 0
 
 
 def _install_grads(tr, grads: Dict[str, torch.Tensor]):
@@ -733,7 +753,10 @@ class AdamW:
         self.model = model
         self.check_finite = check_finite
         self.params = [p for p in params if p.requires_grad]
-        self.betas, self.eps, self.wd, self.t = betas, eps, weight_decay, 0
+        self.betas, self.eps, self.wd = betas, eps, weight_decay
+        self._state = None                                    # device: [found_inf, t, skipped, bc1, bc2, ...] (cir_adamw_begin)
+        self._calls = 0
+        self._plans: Dict[tuple, tuple] = {}                  # (param storage, first param) -> cached flat layout of a parameter group
         # torch.optim's surface as far as the reference's loop uses it: utils.cosine_lr_schedule (utils.py:216-221, called once per epoch at
         # stage2_train.py:159) writes `param_group['lr']`; one group, its 'lr' is what step() applies
         self.param_groups = [{"params": self.params, "lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}]
@@ -759,83 +782,112 @@ class AdamW:
             return None
         return st.data_ptr(), st.nbytes() // 4
 
+    # applied / skipped step counts live on the device (the skip decision is taken there): reading them is a host read
+    @property
+    def t(self) -> int:
+        return 0 if self._state is None else int(self._state[1])
+
+    @property
+    def skipped_steps(self) -> int:
+        return 0 if self._state is None else int(self._state[2])
+
+    def _plan(self, grp):
+        """Flat layout of a group of parameters that tile ONE fp32 storage (the trainer's slab): (base pointer, elements, per-parameter
+        element offsets) - computed once per group; None when they do not tile one."""
+        key = (grp[0].data.untyped_storage().data_ptr(), len(grp), id(grp[0]), id(grp[-1]))
+        if key not in self._plans:
+            fp = self._flat_range([p.data for p in grp])
+            self._plans[key] = None if fp is None else (fp[0], fp[1], [(p.data_ptr() - fp[0]) // 4 for p in grp])
+        return self._plans[key]
+
+    @staticmethod
+    def _grads_match(grp, plan):
+        """The gradients of `grp` are slices of ONE flat buffer laid out like the parameters (what the trainers install): its base pointer."""
+        g0 = grp[0].grad
+        base = g0.data_ptr() - 4 * plan[2][0]
+        if g0.untyped_storage().data_ptr() != base or g0.untyped_storage().nbytes() != 4 * plan[1]:
+            return None
+        for p, o in zip(grp, plan[2]):
+            g = p.grad
+            if g.data_ptr() != base + 4 * o or g.dtype != torch.float32 or not g.is_contiguous():
+                return None
+        return base
+
     @torch.no_grad()
     def step(self):
-        self.t += 1
+        """One AdamW step; with fp16 operands the update is skipped when a gradient is inf / NaN (GradScaler.step, stage2_train.py:215-218).
+        Nothing here reads the device (round 6): the finite test ORs into a device flag, cir_adamw_begin turns it into the step count /
+        bias corrections or the skip count, and the update kernels return at once under a set flag.  The test runs on the buffers this call
+        APPLIES - .grad as it is now, after any accumulation over micro-batches - and does not depend on `model=`."""
         ps = [p for p in self.params if p.grad is not None]
         if not ps:
             return
-        # Non-finite gradients (an fp16 intermediate above 65504 -> inf -> NaN in the weight gradients): skip this update like
-        # GradScaler.step would.  The test runs on the buffers this call APPLIES - .grad as it is now, i.e. after any accumulation over
-        # micro-batches (an overflowed earlier micro-batch followed by a finite one stays non-finite in the sum) - and does not depend on
-        # `model=` (round-4 advisor findings: the per-backward flag of the trainer saw only the last micro-batch and only with model=).
+        dev = ps[0].device
+        if self._state is None:
+            self._state = torch.zeros((8,), dtype=torch.int32, device=dev)
+        st = self._state
+        self._calls += 1
+        st[0:1].zero_()
         need = self.check_finite
         trainers = [] if self.model is None else [tr for tr in (getattr(self.model, "_trainer", None), getattr(self.model, "_vit_trainer", None)) if tr is not None]
         if need is None:
             need = self.model is None or not trainers or any(getattr(tr, "dtype", None) == torch.float16 for tr in trainers)
-        bad = any(getattr(tr, "grads_finite", None) is not None and not bool(tr.grads_finite) for tr in trainers)   # (a flag a test / caller set)
-        if need and not bad:
-            bad = not self._grads_finite(ps)
-        if bad:
-            self.t -= 1
-            self.skipped_steps = getattr(self, "skipped_steps", 0) + 1
-            return
-        if self.model is not None:
-            self.model._text_stale = True                     # the weights change HERE: the next eval / score call repacks
-            if getattr(self.model, "_vit_trainer", None) is not None:
-                self.model._vit_stale = True
+        for tr in trainers:                                   # a flag a trainer's last backward (or a test / caller) set
+            gf = getattr(tr, "grads_finite", None)
+            if gf is not None:
+                st[0:1] |= (~torch.as_tensor(gf, device=dev).reshape(1)).to(torch.int32)
         # one launch per FLAT STORAGE (the two-branch encoder's slab; the ViT's when it is fine-tuned), per tensor for what is left
         groups: Dict[int, list] = {}
         for p in ps:
             groups.setdefault(p.data.untyped_storage().data_ptr(), []).append(p)
+        work = []                                             # (p flat, g flat, m, v, p16 or None, slab or None)
         for grp in groups.values():
-            if len(grp) < 2 or not self._step_flat(grp):
+            plan = self._plan(grp) if len(grp) > 1 else None
+            gbase = self._grads_match(grp, plan) if plan is not None else None
+            if gbase is None:
                 for p in grp:
-                    self._step_tensor(p)
-
-    def _grads_finite(self, ps) -> bool:
-        """All gradients about to be applied are finite: one reduction per flat gradient storage (per tensor otherwise), ONE host read."""
-        groups: Dict[int, list] = {}
-        for p in ps:
-            groups.setdefault(p.grad.untyped_storage().data_ptr(), []).append(p)
-        flags = []
-        for grp in groups.values():
-            fr = self._flat_range([p.grad for p in grp]) if len(grp) > 1 else None
-            if fr is not None:
-                flat = torch.empty(0, dtype=torch.float32, device=grp[0].grad.device).set_(grp[0].grad.untyped_storage(), 0, (fr[1],))
-                flags.append(torch.isfinite(flat).all())
-            else:
-                flags += [torch.isfinite(p.grad).all() for p in grp]
-        return bool(torch.stack(flags).all())
-
-    def _step_flat(self, ps) -> bool:
-        fp, fg = self._flat_range([p.data for p in ps]), self._flat_range([p.grad for p in ps])
-        if not (fp is not None and fg is not None and fp[1] == fg[1] and all(p.data_ptr() - fp[0] == p.grad.data_ptr() - fg[0] for p in ps)):
-            return False
-        n = fp[1]
-        flat = self._flats.get(fp[0])
-        if flat is None:
-            mf, vf = (torch.zeros((n,), dtype=torch.float32, device=ps[0].device) for _ in range(2))
-            for p in ps:                                      # carry over moments from per-tensor steps, then keep views
-                o = (p.data_ptr() - fp[0]) // 4
-                for store, fl in ((self.m, mf), (self.v, vf)):
-                    view = fl[o:o + p.numel()].view(p.shape)
-                    if id(p) in store:
-                        view.copy_(store[id(p)])
-                    store[id(p)] = view
-            flat = self._flats[fp[0]] = (mf, vf)
-        pflat = torch.empty(0, dtype=torch.float32, device=ps[0].device).set_(ps[0].data.untyped_storage(), 0, (n,))
-        gflat = torch.empty(0, dtype=torch.float32, device=ps[0].device).set_(ps[0].grad.untyped_storage(), 0, (n,))
-        T.adamw_step(pflat, gflat, flat[0], flat[1], self.lr, self.betas, self.eps, self.wd, self.t)
-        return True
-
-    def _step_tensor(self, p):
-        if id(p) not in self.m:
-            self.m[id(p)], self.v[id(p)] = torch.zeros_like(p, dtype=torch.float32), torch.zeros_like(p, dtype=torch.float32)
-        m, v = self.m[id(p)], self.v[id(p)]
-        if not (m.is_contiguous() and v.is_contiguous()):
-            m, v = self.m[id(p)], self.v[id(p)] = m.contiguous(), v.contiguous()
-        T.adamw_step(p.data, p.grad.contiguous(), m, v, self.lr, self.betas, self.eps, self.wd, self.t)
+                    if id(p) not in self.m:
+                        self.m[id(p)], self.v[id(p)] = torch.zeros_like(p, dtype=torch.float32), torch.zeros_like(p, dtype=torch.float32)
+                    m, v = self.m[id(p)], self.v[id(p)]
+                    if not (m.is_contiguous() and v.is_contiguous()):
+                        m, v = self.m[id(p)], self.v[id(p)] = m.contiguous(), v.contiguous()
+                    pd = p.data if p.data.is_contiguous() and p.data_ptr() % 16 == 0 else None       # (else: stepped through a copy)
+                    g = p.grad.contiguous().float()
+                    work.append((pd if pd is not None else p.data.contiguous().clone(), g if g.data_ptr() % 16 == 0 else g.clone(), m, v, None, None,
+                                 None if pd is not None else p))
+                continue
+            n = plan[1]
+            flat = self._flats.get(plan[0])
+            if flat is None:
+                mf, vf = (torch.zeros((n,), dtype=torch.float32, device=dev) for _ in range(2))
+                for p, o in zip(grp, plan[2]):                # carry over moments from per-tensor steps, then keep views
+                    for store, fl in ((self.m, mf), (self.v, vf)):
+                        view = fl[o:o + p.numel()].view(p.shape)
+                        if id(p) in store:
+                            view.copy_(store[id(p)])
+                        store[id(p)] = view
+                flat = self._flats[plan[0]] = (mf, vf)
+            pflat = torch.empty(0, dtype=torch.float32, device=dev).set_(grp[0].data.untyped_storage(), 0, (n,))
+            gflat = torch.empty(0, dtype=torch.float32, device=dev).set_(grp[0].grad.untyped_storage(), 0, (n,))
+            slab = _SLABS.get(plan[0])                        # the trainer's slab these parameters live in: its 16-bit copy is written along
+            slab = slab() if slab is not None else None
+            if slab is not None and (slab.flat32.data_ptr() != plan[0] or slab.flat16 is None or slab.flat16.numel() != n):
+                slab = None
+            work.append((pflat, gflat, flat[0], flat[1], None if slab is None else slab.flat16, slab, None))
+        if need:
+            for w in work:
+                T.grads_check(w[1], st)
+        T.adamw_begin(st, self.betas)
+        for pf, gf_, m, v, p16, slab, back in work:
+            T.adamw_step_dev(pf, gf_, m, v, st, self.lr, self.betas, self.eps, self.wd, p16=p16)
+            if back is not None:                              # (a non-contiguous parameter stepped through a contiguous copy)
+                back.data.copy_(pf)
+            if slab is not None:
+                slab.mark_fresh16()                           # (a skipped step leaves both copies as they were: still consistent)
+        if self.model is not None:
+            self.model._text_stale = True                     # the weights change HERE: the next eval / score call repacks
+            if getattr(self.model, "_vit_trainer", None) is not None:
+                self.model._vit_stale = True
 
     def zero_grad(self):
         for p in self.params:

@@ -303,3 +303,30 @@ def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tenso
     _lib.check(_lib.load().cir_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(betas[0]), float(betas[1]),
                                           float(eps), float(weight_decay), int(step), _stream()), "cir_adamw_step")
     _lib.PARAM_EPOCH[0] += 1
+
+
+def grads_check(g: torch.Tensor, state: torch.Tensor, scale: float = 1.0):
+    """g *= scale (in place, when scale != 1) and state[0] |= any non-finite element - one pass, no host read (cir_grads_check)."""
+    _need_cuda(g, state)
+    assert g.dtype == torch.float32 and g.is_contiguous() and state.dtype == torch.int32 and state.numel() >= 8
+    _lib.check(_lib.load().cir_grads_check(g.data_ptr(), g.numel(), float(scale), state.data_ptr(), _stream()), "cir_grads_check")
+
+
+def adamw_begin(state: torch.Tensor, betas=(0.9, 0.999)):
+    """After the step's checks: found_inf -> skipped += 1, else t += 1 and the bias corrections of the new t (cir_adamw_begin)."""
+    _need_cuda(state)
+    _lib.check(_lib.load().cir_adamw_begin(state.data_ptr(), float(betas[0]), float(betas[1]), _stream()), "cir_adamw_begin")
+
+
+def adamw_step_dev(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, state: torch.Tensor, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
+                   weight_decay: float = 0.01, p16: torch.Tensor = None):
+    """adamw_step with the step count / skip decision read from `state` on the device (cir_adamw_step_dev); `p16`: the 16-bit copy of the
+    updated parameters, written in the same pass."""
+    _need_cuda(p, g, m, v, state)
+    assert all(t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel() for t in (p, g, m, v))
+    assert p16 is None or (p16.is_contiguous() and p16.numel() == p.numel() and p16.dtype in (torch.float16, torch.bfloat16))
+    _lib.check(_lib.load().cir_adamw_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(betas[0]), float(betas[1]),
+                                              float(eps), float(weight_decay), state.data_ptr(), None if p16 is None else p16.data_ptr(),
+                                              0 if p16 is None else _DT[p16.dtype], _stream()), "cir_adamw_step_dev")
+    _lib.PARAM_EPOCH[0] += 1
+

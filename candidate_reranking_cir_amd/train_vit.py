@@ -22,7 +22,7 @@ import torch
 
 from . import lib as _lib
 from . import ops, train_ops as T
-from .train import _Lin, _LN, _Slab, _cast, _install_grads
+from .train import _Lin, _LN, _Slab, _cast, _install_grads, _unscale_and_check
 
 _P = "visual_encoder."
 
@@ -200,9 +200,9 @@ class VitTrainer:
         T.colsum(g3[:, 0], self.dcls)
         dproj16 = _cast(g3[:, 1:].contiguous().view(bsz * (n - 1), d), dt)
         self.pe.bwd16(sv["patches"], dproj16, need_dx=False, bias=True)             # pixels are inputs
-        if self.grad_scale != 1.0:
+        self.grads_finite = _unscale_and_check(slab.gflat, self.grad_scale) if dt == torch.float16 else None      # (one pass: train.py)
+        if dt != torch.float16 and self.grad_scale != 1.0:
             slab.gflat = T.eltwise(slab.gflat, T.MODE_SCALE, p_drop=1.0 / self.grad_scale)
-        self.grads_finite = torch.isfinite(slab.gflat).all() if dt == torch.float16 else None
         return {name: slab.grad(name) for name in slab.names}
 
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CIR_ABI_VERSION 14
+#define CIR_ABI_VERSION 15
 
 enum { CIR_BF16 = 0, CIR_F16 = 1, CIR_F32 = 2 };
 enum { CIR_ACT_NONE = 0, CIR_ACT_GELU = 1, CIR_ACT_RELU = 2 };
@@ -419,6 +419,18 @@ int cir_embed_bwd(const int64_t* ids, const float* dy, float* dword, float* dpos
 /* torch.optim.AdamW step in place on fp32 parameter / moments (stage2_train.py:120-126 builds that optimizer). */
 int cir_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                    int step, void* stream);
+/* The same step with GradScaler.step's found_inf decision (stage2_train.py:215-218: `scaler.step(optimizer)` skips the update when the
+ * unscaled gradients hold an inf / NaN) taken ON THE DEVICE - no host read between backward and the update (ABI 15).  `state` = 8 x 32 bit
+ * of device memory, zero-initialised by the caller once: [0] found_inf of the step in flight (the caller clears it before the first check of
+ * a step), [1] applied steps t, [2] skipped steps, [3] / [4] fp32 bias corrections 1 - beta^t of the step in flight.
+ *   cir_grads_check     g[i] *= scale (scale != 1: GradScaler.unscale_) and state[0] |= any non-finite g[i]; one pass over g.
+ *   cir_adamw_begin     after every check of the step: flag set -> state[2] += 1; else state[1] += 1 and the corrections for the new t.
+ *   cir_adamw_step_dev  cir_adamw_step's update with t / corrections from `state`; a no-op while state[0] is set.  `p16` (optional):
+ *                       the 16-bit operand copy of the updated parameters (dtype16 = CIR_F16 / CIR_BF16), written in the same pass. */
+int cir_grads_check(float* g, int64_t n, float scale, int32_t* state, void* stream);
+int cir_adamw_begin(int32_t* state, float beta1, float beta2, void* stream);
+int cir_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       const int32_t* state, void* p16, int dtype16, void* stream);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_symbol():
     cdll = lib.load()
     for name in _declared():
         assert hasattr(cdll, name), name
-    assert cdll.cir_version() == 14
+    assert cdll.cir_version() == 15
     assert b"aligned" in cdll.cir_strerror(-3)
 
 
@@ -123,6 +123,10 @@ def test_argument_validation_happens_before_any_launch():
     assert c.cir_colsum(P, 8, None, 4, 8, None) == EINVAL and c.cir_embed_bwd(P, P, P, None, 4, 2, 8, None) == EINVAL
     assert c.cir_adamw_step(P, P, P, None, 8, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, None) == EINVAL
     assert c.cir_adamw_step(P, P, P, P, 8, 1e-3, 0.9, 0.999, 1e-8, 0.01, 0, None) == EINVAL                           # step counts from 1
+    assert c.cir_grads_check(None, 8, 1.0, P, None) == EINVAL and c.cir_grads_check(P, 0, 1.0, P, None) == EINVAL
+    assert c.cir_adamw_begin(None, 0.9, 0.999, None) == EINVAL
+    assert c.cir_adamw_step_dev(P, P, P, P, 8, 1e-3, 0.9, 0.999, 1e-8, 0.01, None, None, 0, None) == EINVAL
+    assert c.cir_adamw_step_dev(P, P, P, P, 0, 1e-3, 0.9, 0.999, 1e-8, 0.01, P, None, 0, None) == EINVAL
     # kernel-selection overrides: range-checked, default automatic, and the library reads no environment variables
     assert c.cir_set_tuning(7, 0) == EINVAL and c.cir_set_tuning(0, 64) == EINVAL and c.cir_set_tuning(2, 9000) == EINVAL
     assert c.cir_set_tuning(0, 128) == 0 and c.cir_set_tuning(0, 0) == 0 and c.cir_set_tuning(2, -1) == 0 and c.cir_set_tuning(2, 0) == 0
