@@ -600,20 +600,26 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
 __global__ __launch_bounds__(256) void grads_check_kernel(float* g, int64_t n4, int64_t n, float scale, int* state) {
     int bad = 0;
     const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-        float4 x = reinterpret_cast<float4*>(g)[i];
-        if (scale != 1.f) {
-            x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale;
-            reinterpret_cast<float4*>(g)[i] = x;
-        }
-        // (finite <=> exponent field not all ones)
-        auto nf = [](float f) { return (int)((__float_as_uint(f) & 0x7f800000u) == 0x7f800000u); };
-        bad |= nf(x.x) | nf(x.y) | nf(x.z) | nf(x.w);
+    auto nf = [](float f) { return (int)((__float_as_uint(f) & 0x7f800000u) == 0x7f800000u); };      // (finite <=> exponent field not all ones)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += 4 * stride) {
+        float4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * stride < n4) x[u] = reinterpret_cast<float4*>(g)[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * stride < n4) {
+                if (scale != 1.f) {
+                    x[u].x *= scale; x[u].y *= scale; x[u].z *= scale; x[u].w *= scale;
+                    reinterpret_cast<float4*>(g)[i + u * stride] = x[u];
+                }
+                bad |= nf(x[u].x) | nf(x[u].y) | nf(x[u].z) | nf(x[u].w);
+            }
     }
     if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) {           // tail of a length that is not a multiple of 4
         float x = g[4 * n4 + threadIdx.x];
         if (scale != 1.f) { x *= scale; g[4 * n4 + threadIdx.x] = x; }
-        bad |= (__float_as_uint(x) & 0x7f800000u) == 0x7f800000u;
+        bad |= nf(x);
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(state, 1);
 }
@@ -639,16 +645,29 @@ __global__ __launch_bounds__(256) void adamw_dev_kernel(float* p, const float* g
         w -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
         pi = w;
     };
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n4) {
-        float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
-        const float4 gg = reinterpret_cast<const float4*>(g)[i];
-        upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
-        reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
-        if (p16) {
-            u32x2 h;
-            h.x = pack2<T16>(pp.x, pp.y); h.y = pack2<T16>(pp.z, pp.w);
-            reinterpret_cast<u32x2*>(p16)[i] = h;
+    // two float4 per thread, 256 apart: all eight 16-byte loads of a thread are in flight before the first update
+    const int64_t i0 = (int64_t)blockIdx.x * 512 + threadIdx.x;
+    float4 pp[2], mm[2], vv[2], gg[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int64_t i = i0 + 256 * u;
+        if (i < n4) {
+            pp[u] = reinterpret_cast<float4*>(p)[i]; mm[u] = reinterpret_cast<float4*>(m)[i]; vv[u] = reinterpret_cast<float4*>(v)[i];
+            gg[u] = reinterpret_cast<const float4*>(g)[i];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int64_t i = i0 + 256 * u;
+        if (i < n4) {
+            upd(pp[u].x, gg[u].x, mm[u].x, vv[u].x); upd(pp[u].y, gg[u].y, mm[u].y, vv[u].y);
+            upd(pp[u].z, gg[u].z, mm[u].z, vv[u].z); upd(pp[u].w, gg[u].w, mm[u].w, vv[u].w);
+            reinterpret_cast<float4*>(p)[i] = pp[u]; reinterpret_cast<float4*>(m)[i] = mm[u]; reinterpret_cast<float4*>(v)[i] = vv[u];
+            if (p16) {
+                u32x2 h;
+                h.x = pack2<T16>(pp[u].x, pp[u].y); h.y = pack2<T16>(pp[u].z, pp[u].w);
+                reinterpret_cast<u32x2*>(p16)[i] = h;
+            }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) {
@@ -669,7 +688,7 @@ extern "C" int cir_grads_check(float* g, int64_t n, float scale, int32_t* state,
     if (n <= 0) return CIR_EINVAL;
     if (!cir_aligned16(g)) return CIR_EALIGN;
     const int64_t n4 = n / 4;
-    const unsigned blocks = (unsigned)std::min<int64_t>(std::max<int64_t>((n4 + 255) / 256, 1), 256 * 16);
+    const unsigned blocks = (unsigned)std::min<int64_t>(std::max<int64_t>((n4 + 1023) / 1024, 1), 256 * 32);
     hipLaunchKernelGGL(grads_check_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g, n4, n, scale, state);
     CIR_LAUNCH_RESULT();
 }
@@ -687,7 +706,7 @@ extern "C" int cir_adamw_step_dev(float* p, const float* g, float* m, float* v, 
     if (p16 && dtype16 != CIR_BF16 && dtype16 != CIR_F16) return CIR_EDTYPE;
     if (!cir_aligned16(p) || !cir_aligned16(g) || !cir_aligned16(m) || !cir_aligned16(v) || (p16 && (reinterpret_cast<uintptr_t>(p16) & 7))) return CIR_EALIGN;
     const int64_t n4 = n / 4;
-    const dim3 grid((unsigned)std::max<int64_t>((n4 + 255) / 256, 1)), block(256);
+    const dim3 grid((unsigned)std::max<int64_t>((n4 + 511) / 512, 1)), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (p16 && dtype16 == CIR_BF16) hipLaunchKernelGGL((adamw_dev_kernel<__bf16>), grid, block, 0, s, p, g, m, v, n4, n, lr, beta1, beta2, eps, weight_decay, state, reinterpret_cast<__bf16*>(p16));
     else hipLaunchKernelGGL((adamw_dev_kernel<_Float16>), grid, block, 0, s, p, g, m, v, n4, n, lr, beta1, beta2, eps, weight_decay, state, reinterpret_cast<_Float16*>(p16));

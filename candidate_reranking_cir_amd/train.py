@@ -83,6 +83,7 @@ class _Slab:
             p.data = v
         _SLABS[self.flat32.data_ptr()] = weakref.ref(self)
         self.flat16 = self.flat16t = self.gflat = self.plan = None
+        self.checked = None                                                         # (gradient buffer pointer, its "all finite" device flag)
         self._fresh16 = None                                                        # (flat32._version, PARAM_EPOCH) flat16 was written for
 
     def _view(self, flat: torch.Tensor, n: str) -> torch.Tensor:
@@ -649,6 +650,7 @@ class NlvrTrainer:
         # found_inf do for the reference (stage2_train.py:215-218) in ONE pass over the buffer: divide by S and note any non-finite element
         # in a device flag that AdamW.step consumes on the device (round 6; before: one scaling pass + the five passes of torch.isfinite)
         self.grads_finite = _unscale_and_check(slab.gflat, self.grad_scale) if self.dtype == torch.float16 else None
+        slab.checked = None if self.grads_finite is None else (slab.gflat.data_ptr(), self.grads_finite, slab.gflat._version)     # (AdamW.step: this buffer is tested)
         if self.dtype != torch.float16 and self.grad_scale != 1.0:
             slab.gflat = T.eltwise(slab.gflat, T.MODE_SCALE, p_drop=1.0 / self.grad_scale)
         return {n: slab.grad(n) for n in slab.names}
@@ -672,6 +674,7 @@ def _install_grads(tr, grads: Dict[str, torch.Tensor]):
     if (prev is not None and prev is not slab.gflat and prev.numel() == slab.gflat.numel()
             and all(p.grad is not None and p.grad.data_ptr() == prev.data_ptr() + 4 * slab.off[n] and p.grad.is_contiguous() for n, p in live)):
         slab.gflat = T.eltwise(slab.gflat, T.MODE_ADD, prev)
+        slab.checked = None                                   # (the sum is a buffer nobody has tested: AdamW.step tests it)
         for n, p in live:
             p.grad = slab.grad(n)
     else:
@@ -876,7 +879,13 @@ class AdamW:
             work.append((pflat, gflat, flat[0], flat[1], None if slab is None else slab.flat16, slab, None))
         if need:
             for w in work:
-                T.grads_check(w[1], st)
+                # the trainer's backward tested exactly this buffer and no torch op has written to it since (version counter of the buffer
+                # and its views): its flag stands; anything else - accumulated sums, edited gradients, foreign buffers - is tested here
+                ck = None if w[5] is None else w[5].checked
+                if ck is not None and ck[0] == w[1].data_ptr() and w[5].gflat is not None and w[5].gflat.data_ptr() == ck[0] and w[5].gflat._version == ck[2]:
+                    st[0:1] |= (~ck[1].reshape(1)).to(torch.int32)
+                else:
+                    T.grads_check(w[1], st)
         T.adamw_begin(st, self.betas)
         for pf, gf_, m, v, p16, slab, back in work:
             T.adamw_step_dev(pf, gf_, m, v, st, self.lr, self.betas, self.eps, self.wd, p16=p16)

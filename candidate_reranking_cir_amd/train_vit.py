@@ -201,6 +201,7 @@ class VitTrainer:
         dproj16 = _cast(g3[:, 1:].contiguous().view(bsz * (n - 1), d), dt)
         self.pe.bwd16(sv["patches"], dproj16, need_dx=False, bias=True)             # pixels are inputs
         self.grads_finite = _unscale_and_check(slab.gflat, self.grad_scale) if dt == torch.float16 else None      # (one pass: train.py)
+        slab.checked = None if self.grads_finite is None else (slab.gflat.data_ptr(), self.grads_finite, slab.gflat._version)
         if dt != torch.float16 and self.grad_scale != 1.0:
             slab.gflat = T.eltwise(slab.gflat, T.MODE_SCALE, p_drop=1.0 / self.grad_scale)
         return {name: slab.grad(name) for name in slab.names}
