@@ -313,6 +313,50 @@ def test_flat_adamw_matches_torch_adamw(cuda):
     m.eval()
 
 
+@pytest.mark.parametrize("n", [1, 3, 8, 1027, 262147])
+def test_device_side_optimizer_step_ops(cuda, n):
+    """cir_grads_check / cir_adamw_begin / cir_adamw_step_dev (ABI 15; GradScaler.unscale_ + found_inf + scaler.step of stage2_train.py:215-218
+    without a host read): lengths that are not multiples of 4, the unscale factor, non-finite values in the body and in the tail, the skip
+    (nothing moves, the skipped count does), the applied step against torch.optim.AdamW, and the 16-bit copy written along."""
+    from candidate_reranking_cir_amd import train_ops as T
+    gen = torch.Generator().manual_seed(n)
+    g0 = torch.randn((n,), generator=gen).cuda()
+    st = torch.zeros((8,), dtype=torch.int32, device=cuda)
+    g = (g0 * 1024.0).clone()
+    T.grads_check(g, st, 1.0 / 1024.0)
+    assert torch.equal(g, g0) and st.tolist()[:3] == [0, 0, 0]                   # (a power of two: exact)
+    for pos, bad in ((n - 1, float("inf")), (0, float("nan")), (n // 2, float("-inf"))):
+        st.zero_()
+        gb = g0.clone()
+        gb[pos] = bad
+        T.grads_check(gb, st)
+        assert int(st[0]) == 1
+    kw = dict(lr=1e-2, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.05)
+    p = torch.randn((n,), generator=gen).cuda()
+    ref_p = p.clone().requires_grad_(True)
+    ref = torch.optim.AdamW([ref_p], **kw)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for dt16 in (torch.float16, torch.bfloat16):
+        p16 = torch.full((n,), 7.0, dtype=dt16, device=cuda)
+        # a skipped step: flag set -> parameters, moments, the 16-bit copy and t stay; skipped += 1
+        skipped0 = int(st[2])
+        st[0] = 1
+        p0, m0, v0, t0 = p.clone(), m.clone(), v.clone(), int(st[1])
+        T.adamw_begin(st, kw["betas"])
+        T.adamw_step_dev(p, g0, m, v, st, kw["lr"], kw["betas"], kw["eps"], kw["weight_decay"], p16=p16)
+        assert torch.equal(p, p0) and torch.equal(m, m0) and torch.equal(v, v0) and int(st[1]) == t0 and int(st[2]) == skipped0 + 1
+        assert (p16.float() == 7.0).all()
+        # an applied step
+        st[0] = 0
+        T.adamw_begin(st, kw["betas"])
+        T.adamw_step_dev(p, g0, m, v, st, kw["lr"], kw["betas"], kw["eps"], kw["weight_decay"], p16=p16)
+        ref_p.grad = g0.clone()
+        ref.step()
+        assert int(st[1]) == t0 + 1
+        torch.testing.assert_close(p, ref_p.detach(), atol=2e-6, rtol=2e-6)
+        assert torch.equal(p16, p.to(dt16))
+
+
 def test_inputs_requiring_grad(cuda):
     """z_t comes from the frozen stage-I model (stage2_train.py:201-203): asking for its gradient fails loudly instead of returning none.
     The target tokens may require one (blip_img_tune: round 4; the ViT's own reverse pass is tests/test_train_vit_gpu.py): their gradient is
