@@ -25,8 +25,8 @@ done
 cd $ROOT
 find $OUT/${TAG}_train_pmc_sq $OUT/${TAG}_train_pmc_fetch $OUT/${TAG}_train_pmc_write -name "*kernel_trace.csv" -delete
 python3 tools/pmc_summary.py $OUT/${TAG}_train_pmc_summary.json $OUT/${TAG}_train_pmc_sq $OUT/${TAG}_train_pmc_fetch $OUT/${TAG}_train_pmc_write > $OUT/${TAG}_train_pmc_summary.txt 2>&1
+python3 tools/train_trace.py $OUT/${TAG}_train_stats 3 4 50 > $OUT/${TAG}_train_kstats.txt 2>&1      # optimizer steps 3..6 = the 4 timed ones (2 warm-up before, 1 leg-instrumented after)
 find $OUT/${TAG}_train_stats -name "*kernel_trace.csv" -delete
-python3 tools/kstats.py $OUT/${TAG}_train_stats 7 > $OUT/${TAG}_train_kstats.txt 2>&1      # 2 warm-up + 4 timed + 1 step with per-leg syncs
 # keep what travels back small: the per-dispatch kernel traces are not needed (the counter CSVs carry timestamps)
 python3 tools/kstats_trace.py $OUT/${TAG}_stats 2 6 > $OUT/${TAG}_kstats.txt 2>&1          # the 6 timed steps' launches only
 # the mode the factories set for real weights (text32: split8 operands), same command
