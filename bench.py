@@ -517,6 +517,7 @@ def train_mode(args, m2, m1, dev, dt):
     for n, p in m2.named_parameters():
         p.requires_grad_(args.img_tune or not n.startswith("visual_encoder."))   # blip_img_tune (stage2_train.py:87-92)
     m2.train()
+    m1.train()                                              # stage2_train.py:165-166: both models; z_t is formed with the stage-I dropout on
     opt = AdamW([p for p in m2.parameters() if p.requires_grad], lr=2e-5, weight_decay=0.05)
     gt = torch.arange(b, device=dev)
     sync = torch.cuda.synchronize

@@ -69,10 +69,35 @@ class BLIP_Retrieval(_EngineHost):
     def z_t(self, ref_tokens: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> EncoderOutput:
         """Batched z_t: reference-image tokens (Q, N, D), ids/mask (Q, L) with [ENC] set."""
         t = ref_tokens.to(self.device)
+        fwd = self._dropout_forward() if self.training else None
+        if fwd is not None:
+            # model_stage1.train() (stage2_train.py:166): the reference forms z_t with every nn.Dropout of the stage-I BERT active, under
+            # no_grad (stage2_train.py:200-203) - train_med.py; .eval() (every validation script) takes the inference engine below
+            dt = fwd.eng.dtype
+            h32, h16 = fwd.forward(input_ids, attention_mask, t if t.dtype == dt else ops.gather_rows(t, None, dt))
+            return EncoderOutput(h32, h16)
         if t.dtype != self.token_dtype:
             t = ops.gather_rows(t, None, self.token_dtype)
         h32, h16 = self.engines()[0].forward(input_ids, attention_mask, t)
         return EncoderOutput(h32, h16)
+
+    def _dropout_forward(self):
+        """The train-mode forward of the text encoder (train_med.MedDropoutForward), or None when the med_config probabilities are zero.
+        Operands as the training plan has them (train.train_dtype): the model's 16-bit compute type, fp16 for the fp32 modes - the inference
+        engine's packed weights are shared when they are of that type, otherwise a 16-bit twin is packed once per engine build."""
+        geo = self.bert_geometry
+        ph, pa = float(geo.hidden_dropout_prob), float(geo.attention_probs_dropout_prob)
+        if ph <= 0.0 and pa <= 0.0:
+            return None
+        from .train_med import MedDropoutForward
+        eng = self.engines()[0]
+        cur = getattr(self, "_med_dropout", None)
+        if cur is None or cur[0] is not self._engines or (cur[1].p_hidden, cur[1].p_attn) != (ph, pa):
+            dt = self.compute_dtype if self.compute_dtype in (torch.float16, torch.bfloat16) else torch.float16
+            if not (eng.dtype == dt and eng.xdtype == dt):
+                eng = MedEngine(self.state_dict(), geo, dt, self.device, stream_dtype=torch.float32, cross_dtype=dt)
+            cur = self._med_dropout = (self._engines, MedDropoutForward(eng, ph, pa))
+        return cur[1]
 
     @torch.no_grad()
     def img_txt_fusion(self, r_image_embeds, t_image_embeds, text, train=True, return_raw=False):

@@ -134,10 +134,15 @@ def _n_layers(w: Weights, prefix: str) -> int:
 # ----------------------------------------------------------------------------------------------
 def med_forward(w: Weights, input_ids: torch.Tensor, attention_mask: torch.Tensor, enc: torch.Tensor,
                 enc_mask: Optional[torch.Tensor] = None, prefix: str = "text_encoder.",
-                n_heads: Optional[int] = None, eps: float = 1e-12) -> torch.Tensor:
+                n_heads: Optional[int] = None, eps: float = 1e-12, drop=None) -> torch.Tensor:
     """med.BertModel.forward in 'multimodal' mode, med.py:685-821; per layer med.py:348-398:
-    self-attn -> cross-attn(image tokens) -> FFN, each followed by residual + LayerNorm."""
-    h = bert_embeddings(w, input_ids, prefix, eps)
+    self-attn -> cross-attn(image tokens) -> FFN, each followed by residual + LayerNorm.
+    `drop(kind, layer, x)` (optional): the module's train-mode nn.Dropout sites with GIVEN masks - 'emb' (med.py:108), 'self_attn' /
+    'cross_attn' (the attention probabilities, med.py:225), 'self_out' / 'cross_out' (med.py:252), 'ffn_out' (med.py:330) - what the
+    reference's loop leaves on while it forms z_t (stage2_train.py:166, 200-203)."""
+    dr = (lambda kind, layer, x: x) if drop is None else drop
+    pd = (lambda kind, layer: None) if drop is None else (lambda kind, layer: (lambda p: drop(kind, layer, p)))
+    h = dr("emb", 0, bert_embeddings(w, input_ids, prefix, eps))
     d = h.shape[-1]
     n_heads = n_heads or d // 64
     smask = self_mask_additive(attention_mask)
@@ -147,23 +152,23 @@ def med_forward(w: Weights, input_ids: torch.Tensor, attention_mask: torch.Tenso
     for i in range(_n_layers(w, prefix)):
         p = f"{prefix}encoder.layer.{i}."
         a = p + "attention.self."
-        ctx = _sdpa(_lin(w, a + "query", h), _lin(w, a + "key", h), _lin(w, a + "value", h), smask, n_heads)
-        h = _ln(w, p + "attention.output.LayerNorm", _lin(w, p + "attention.output.dense", ctx) + h, eps)  # med.py:250-253
+        ctx = _sdpa(_lin(w, a + "query", h), _lin(w, a + "key", h), _lin(w, a + "value", h), smask, n_heads, pdrop=pd("self_attn", i))
+        h = _ln(w, p + "attention.output.LayerNorm", dr("self_out", i, _lin(w, p + "attention.output.dense", ctx)) + h, eps)  # med.py:250-253
         c = p + "crossattention.self."
-        ctx = _sdpa(_lin(w, c + "query", h), _lin(w, c + "key", enc), _lin(w, c + "value", enc), emask, n_heads)
-        h = _ln(w, p + "crossattention.output.LayerNorm", _lin(w, p + "crossattention.output.dense", ctx) + h, eps)
+        ctx = _sdpa(_lin(w, c + "query", h), _lin(w, c + "key", enc), _lin(w, c + "value", enc), emask, n_heads, pdrop=pd("cross_attn", i))
+        h = _ln(w, p + "crossattention.output.LayerNorm", dr("cross_out", i, _lin(w, p + "crossattention.output.dense", ctx)) + h, eps)
         f = F.gelu(_lin(w, p + "intermediate.dense", h))                       # med.py:319-322
-        h = _ln(w, p + "output.LayerNorm", _lin(w, p + "output.dense", f) + h, eps)  # med.py:331-335
+        h = _ln(w, p + "output.LayerNorm", dr("ffn_out", i, _lin(w, p + "output.dense", f)) + h, eps)  # med.py:329-335
     return h
 
 
 def stage1_z_t(w: Weights, ref_tokens: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor,
-               enc_token_id: int = 30523) -> torch.Tensor:
+               enc_token_id: int = 30523, drop=None) -> torch.Tensor:
     """BLIP_Retrieval.img_txt_fusion(..., train=False, return_raw=True).last_hidden_state,
     blip_stage1.py:67-86: ids[:,0] <- [ENC]; med encoder with the reference-image tokens."""
     ids = input_ids.clone()
     ids[:, 0] = enc_token_id                                                   # blip_stage1.py:73
-    return med_forward(w, ids, attention_mask, ref_tokens)
+    return med_forward(w, ids, attention_mask, ref_tokens, drop=drop)
 
 
 # ----------------------------------------------------------------------------------------------
