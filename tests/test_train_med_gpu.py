@@ -2,7 +2,6 @@
 (stage2_train.py:166, 200-203), so the stage-I BERT's nn.Dropout sites (med.py:108, 225, 252, 330) are active.  train_med.py is that
 forward on the fused training kernels; here it meets the CPU oracle's MED forward with EXACTLY the masks the kernels drew (regenerated on
 the host from the counters: tests/helpers.pair_keep / splitmix_keep), plus the mode switch (`.eval()` = the inference engine, bit for bit)."""
-import json
 
 import numpy as np
 import pytest
