@@ -54,6 +54,41 @@ def test_adamw_flat_detection():
     assert AdamW._flat_range([a, flat[16:40].view(4, 6).t()]) is None                        # not contiguous
 
 
+def test_adamw_group_plan_and_gradient_match():
+    """The cached flat layout of a parameter group and the per-step check that the gradients are slices of ONE buffer laid out alike
+    (round 6: one pointer comparison per tensor instead of re-deriving the layout of 572 tensors three times per step)."""
+    flat, gflat = torch.zeros(40), torch.zeros(40)
+    ps = [torch.nn.Parameter(torch.zeros(1)) for _ in range(2)]
+    ps[0].data, ps[1].data = flat[0:12].view(3, 4), flat[16:40].view(6, 4)
+    opt = AdamW(ps, lr=1e-3)
+    plan = opt._plan(ps)
+    assert plan == (flat.untyped_storage().data_ptr(), 40, [0, 16]) and opt._plan(ps) is plan          # cached
+    ps[0].grad, ps[1].grad = gflat[0:12].view(3, 4), gflat[16:40].view(6, 4)
+    assert AdamW._grads_match(ps, plan) == gflat.data_ptr()
+    ps[1].grad = torch.zeros(6, 4)                                                                     # a gradient from elsewhere
+    assert AdamW._grads_match(ps, plan) is None
+    ps[1].grad = gflat[16:40].view(4, 6).t()                                                           # right place, not contiguous
+    assert AdamW._grads_match(ps, plan) is None
+    other = torch.zeros(48)                                                                            # same offsets inside a LARGER buffer
+    ps[0].grad, ps[1].grad = other[0:12].view(3, 4), other[16:40].view(6, 4)
+    assert AdamW._grads_match(ps, plan) is None
+    lone = [torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(7))]                     # separate storages: no plan
+    assert AdamW(lone)._plan(lone) is None
+    assert opt.t == 0 and opt.skipped_steps == 0                                                       # no device state before the first step
+
+
+def test_stage1_dropout_site_seeds():
+    """train_med.site_seed: one 62-bit counter-based seed per (call, layer, site) - distinct across the sites of a call, a pure function of
+    its arguments (the host-side mask regeneration of tests/test_train_med_gpu.py depends on it)."""
+    from candidate_reranking_cir_amd import train_med as M
+    sites = (M.SITE_EMB, M.SITE_SELF_ATTN, M.SITE_SELF_OUT, M.SITE_CROSS_ATTN, M.SITE_CROSS_OUT, M.SITE_FFN_OUT)
+    assert sites == (0, 1, 2, 3, 4, 5)
+    seeds = {M.site_seed(12345, layer, s) for layer in range(12) for s in sites}
+    assert len(seeds) == 72 and all(0 <= x < 2 ** 62 for x in seeds)
+    assert M.site_seed(12345, 3, 2) == M.site_seed(12345, 3, 2) != M.site_seed(12346, 3, 2)
+    assert M.site_seed(2 ** 62 - 1, 11, 5) < 2 ** 62
+
+
 def test_train_flop_model():
     import bench
     b, l, n, d = 2, 8, 17, 768
